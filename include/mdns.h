@@ -1,0 +1,177 @@
+/*
+ * mdns.h -- C ABI of libmdns_hip.so, the MI355X (gfx950) implementation of the
+ * massivedatans hot path: batched spectral-line log-likelihoods and the RadFriends
+ * neighbourhood / safe-radius tests.
+ *
+ * Plain C: pointers and sizes only, no C++ or torch types.  Every entry point names the
+ * reference interface it stands in for (paths under the reference checkout).
+ *
+ * The library has NO CPU fallback: every compute entry point runs HIP kernels on the
+ * selected device and reports failure (return code / NaN, message via mdns_last_error())
+ * when no device is usable.
+ *
+ * Part 1  drop-in entry points with the reference's argument lists (host pointers);
+ *         the three shim libraries clike.so / cmuselike.so / cneighbors.so re-export them
+ *         under the reference's symbol names.
+ * Part 2  device-resident handles (spectra stay in HBM, candidates are scored in batches).
+ * Part 3  raw device entry points, memory, stream and event helpers (bench / multi-GPU).
+ */
+#ifndef MDNS_H
+#define MDNS_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* Library state                                                                        */
+/* ------------------------------------------------------------------------------------ */
+
+/* Select the device of this process (one process per GPU).  device < 0: MDNS_DEVICE, else
+ * LOCAL_RANK modulo the device count, else 0.  Called implicitly by the first compute call.
+ * Returns 0 on success. */
+int mdns_init(int device);
+/* Number of visible HIP devices (0 when there is none). */
+int mdns_device_count(void);
+/* Message of the last failure in this thread's process ("" if none). */
+const char *mdns_last_error(void);
+/* ABI version, bumped on any signature change. */
+int mdns_abi_version(void);
+
+/* ------------------------------------------------------------------------------------ */
+/* Part 1: drop-in entry points (reference argument lists, host pointers)               */
+/* ------------------------------------------------------------------------------------ */
+
+/*
+ * K1 -- stands in for `like` of clike.so: clike.c:34-40, bound at sample.py:85-96, called at
+ * sample.py:106.  x f64[nx]; yy f64[nx,ndata] C-order (element (j,i) at i + j*ndata);
+ * data_mask C bool[ndata]; Lout f64[mask.sum()], compacted in mask order and ACCUMULATED
+ * (+=, clike.c:72) -- the caller pre-zeroes it (sample.py:104).  Returns 0 (the reference
+ * always does); non-zero only on a device failure.
+ * The spectra are uploaded on every call unless the yy pointer was registered with
+ * mdns_register_spectra() (then the HBM-resident copy is used).
+ */
+int mdns_gauss_like(const void *x, const void *yy, int ndata, int nx,
+                    double A, double mu, double sig, double noise_level,
+                    const void *data_mask, void *Lout);
+
+/*
+ * K2 -- stands in for `like` of cmuselike.so: cmuselike.c:34-38, bound at
+ * musefuse.py:509-517, called at musefuse.py:534.  yy, vv f64[nx,ndata]; ypred f64[nx];
+ * Lout f64[ndata] NOT compacted, only masked entries are written (cmuselike.c:49,62).
+ */
+int mdns_muse_like(const void *yy, const void *vv, const void *ypred, const void *data_mask,
+                   int ndata, int nx, void *Lout);
+
+/* Keep a device copy of a host spectra array for the drop-in calls above: later calls whose
+ * yy (and vv) pointer, ndata and nx match use it instead of uploading.  The caller promises
+ * not to modify the array while it is registered.  vv may be NULL (K1). */
+int mdns_register_spectra(const void *yy, const void *vv, int ndata, int nx);
+int mdns_unregister_spectra(const void *yy);
+
+/* K5 -- cneighbors.c:32-34 (clustering/neighbors.py:100-110). */
+double mdns_most_distant_nearest_neighbor(const void *xx, int nsamples, int ndim);
+/* K4 -- cneighbors.c:77-79 (clustering/neighbors.py:112-124); 1 = inside. */
+int mdns_is_within_distance_of(const void *xx, int nsamples, int ndim, double maxdistance,
+                               const void *y);
+/* K3 -- cneighbors.c:95-98 (clustering/neighbors.py:126-159).  out f64[nothers] is
+ * incremented in place, with the reference's countmax early-stop semantics. */
+int mdns_count_within_distance_of(const void *xx, int nsamples, int ndim, double maxdistance,
+                                  const void *yy, int nothers, void *out, const int countmax);
+/* K6 -- cneighbors.c:125-130 (clustering/neighbors.py:161-177).  choice f64[nsamples,
+ * nbootstraps], tested != 0. */
+double mdns_bootstrapped_maxdistance(const void *xx, int nsamples, int ndim,
+                                     const void *choice, int nbootstraps);
+
+/* ------------------------------------------------------------------------------------ */
+/* Part 2: device-resident spectra + batched scoring (extension)        */
+/* ------------------------------------------------------------------------------------ */
+
+typedef struct mdns_spectra mdns_spectra;
+
+#define MDNS_LAYOUT_CHANNEL_MAJOR 0   /* reference layout [nx, ndata] (sample.py:31)        */
+#define MDNS_LAYOUT_DATASET_MAJOR 1   /* [ndata, nx]: one spectrum per contiguous row        */
+
+/* Upload spectra once; they stay in HBM as [ndata, nx] rows.  x f64[nx] (may be NULL when
+ * only precomputed templates are scored); v per-pixel variances (NULL for K1-only use). */
+mdns_spectra *mdns_spectra_create(const double *x, const double *y, const double *v,
+                                  int ndata, int nx, int layout);
+void mdns_spectra_destroy(mdns_spectra *s);
+int mdns_spectra_ndata(const mdns_spectra *s);
+int mdns_spectra_nx(const mdns_spectra *s);
+
+/*
+ * Score B candidate lines against M selected spectra in one pass over the spectra.
+ * params f64[B,3] = (A, mu, sig) per candidate (sig already linear, sample.py:103);
+ * row_ids int32[M] = indices of the selected spectra in ascending mask order (NULL = all,
+ * M = ndata); Lout f64[B,M] receives the log-likelihoods  -0.5 * sum_j ((m_j - y_ij)/noise)^2
+ * (what sample.py:108 returns), compacted like the reference's output.
+ */
+int mdns_gauss_loglike_batch(mdns_spectra *s, const double *params, int B, double noise_level,
+                             const int *row_ids, int M, double *Lout);
+
+/* Same for the scale-marginalised likelihood (cmuselike.c:45-64) against B precomputed
+ * templates ypred f64[B,nx]; Lout f64[B,M] = -0.5*chi. */
+int mdns_muse_loglike_batch(mdns_spectra *s, const double *ypred, int B,
+                            const int *row_ids, int M, double *Lout);
+
+/* Config-C5 template (three Gaussians on a flat continuum, massivedatans_amd/gen.py
+ * muse_template) evaluated ON DEVICE for B parameter vectors params f64[B,5], then scored
+ * exactly as mdns_muse_loglike_batch. */
+int mdns_muse3_loglike_batch(mdns_spectra *s, const double *params, int B,
+                             const int *row_ids, int M, double *Lout);
+
+/* ------------------------------------------------------------------------------------ */
+/* Part 3: raw device entry points (all pointers are DEVICE pointers; asynchronous on the */
+/* library stream; no host synchronisation)                                             */
+/* ------------------------------------------------------------------------------------ */
+
+void *mdns_dev_alloc(size_t bytes);
+void mdns_dev_free(void *p);
+int mdns_h2d(void *dst, const void *src, size_t bytes);   /* synchronous */
+int mdns_d2h(void *dst, const void *src, size_t bytes);   /* synchronous */
+int mdns_sync(void);                                      /* wait for the library stream */
+/* Run on a caller-owned hipStream_t (e.g. the stream of an RCCL collective); NULL restores
+ * the library's own stream. */
+int mdns_set_stream(void *hip_stream);
+
+/* HIP events on the library stream (bench.py times launches with these). */
+void *mdns_event_create(void);
+void mdns_event_destroy(void *ev);
+int mdns_event_record(void *ev);
+double mdns_event_elapsed_ms(void *ev_start, void *ev_stop);   /* synchronises on ev_stop */
+
+/* Per-launch timing of the dominant kernels with HIP events on the library stream.
+ * mdns_profile(1) clears the statistics and starts recording, mdns_profile(0) stops.
+ * mdns_profile_read synchronises and returns, for kernel class `which` (0 = gauss rows,
+ * 1 = muse rows, 2 = count-within, 3 = bootstrap nearest-chosen), the number of launches
+ * timed and the sum of their durations in milliseconds. */
+int mdns_profile(int enable);
+int mdns_profile_read(int which, long long *launches, double *total_ms);
+
+/* d_params f64[B,3], d_row_ids int32[M] or NULL, d_Lout f64[B,M]. */
+int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_params, int B,
+                                 double noise_level, const int *d_row_ids, int M,
+                                 double *d_Lout);
+int mdns_muse_loglike_batch_dev(mdns_spectra *s, const double *d_ypred, int B,
+                                const int *d_row_ids, int M, double *d_Lout);
+int mdns_muse3_loglike_batch_dev(mdns_spectra *s, const double *d_params, int B,
+                                 const int *d_row_ids, int M, double *d_Lout);
+
+/* K3 on device: d_members f64[K,ndim], d_cands f64[M,ndim]; d_counts int32[M] is
+ * OVERWRITTEN with the number of members strictly within maxdistance (no early stop). */
+int mdns_count_within_dev(const double *d_members, int K, int ndim, double maxdistance,
+                          const double *d_cands, int M, int *d_counts);
+/* K6 on device: d_chosen f64[K,nbootstraps]; d_round_sq f64[nbootstraps] receives, per round,
+ * max over left-out points i>=1 of the squared distance to the nearest chosen point
+ * (radius = sqrt of the max over rounds). */
+int mdns_bootstrap_round_maxsq_dev(const double *d_members, int K, int ndim,
+                                   const double *d_chosen, int nbootstraps,
+                                   double *d_round_sq);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDNS_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of ``libmdns_hip.so`` (C ABI declared in ``include/mdns.h``).
+
+There is no CPU fallback: :func:`load` raises if the library has not been built
+(``make -C massivedatans_amd/csrc`` or ``__graft_entry__.build()``), and every wrapper raises
+:class:`MdnsError` when the library reports a failure (e.g. no GPU visible).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libmdns_hip.so")
+DROPIN_DIR = os.path.join(PKG_DIR, "dropin")
+
+#: every symbol include/mdns.h declares (tests check that the built library exports them all)
+ABI_SYMBOLS = (
+    "mdns_init", "mdns_device_count", "mdns_last_error", "mdns_abi_version",
+    "mdns_gauss_like", "mdns_muse_like", "mdns_register_spectra", "mdns_unregister_spectra",
+    "mdns_most_distant_nearest_neighbor", "mdns_is_within_distance_of",
+    "mdns_count_within_distance_of", "mdns_bootstrapped_maxdistance",
+    "mdns_spectra_create", "mdns_spectra_destroy", "mdns_spectra_ndata", "mdns_spectra_nx",
+    "mdns_gauss_loglike_batch", "mdns_muse_loglike_batch", "mdns_muse3_loglike_batch",
+    "mdns_dev_alloc", "mdns_dev_free", "mdns_h2d", "mdns_d2h", "mdns_sync", "mdns_set_stream",
+    "mdns_event_create", "mdns_event_destroy", "mdns_event_record", "mdns_event_elapsed_ms",
+    "mdns_profile", "mdns_profile_read",
+    "mdns_gauss_loglike_batch_dev", "mdns_muse_loglike_batch_dev", "mdns_muse3_loglike_batch_dev",
+    "mdns_count_within_dev", "mdns_bootstrap_round_maxsq_dev",
+)
+
+
+class MdnsError(RuntimeError):
+    pass
+
+
+_f64 = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_f64_or_null = C.c_void_p
+_lib = None
+
+
+def _declare(lib):
+    vp, i, d, sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
+    sig = {
+        "mdns_init": (i, [i]),
+        "mdns_device_count": (i, []),
+        "mdns_last_error": (C.c_char_p, []),
+        "mdns_abi_version": (i, []),
+        "mdns_gauss_like": (i, [vp, vp, i, i, d, d, d, d, vp, vp]),
+        "mdns_muse_like": (i, [vp, vp, vp, vp, i, i, vp]),
+        "mdns_register_spectra": (i, [vp, vp, i, i]),
+        "mdns_unregister_spectra": (i, [vp]),
+        "mdns_most_distant_nearest_neighbor": (d, [vp, i, i]),
+        "mdns_is_within_distance_of": (i, [vp, i, i, d, vp]),
+        "mdns_count_within_distance_of": (i, [vp, i, i, d, vp, i, vp, i]),
+        "mdns_bootstrapped_maxdistance": (d, [vp, i, i, vp, i]),
+        "mdns_spectra_create": (vp, [vp, vp, vp, i, i, i]),
+        "mdns_spectra_destroy": (None, [vp]),
+        "mdns_spectra_ndata": (i, [vp]),
+        "mdns_spectra_nx": (i, [vp]),
+        "mdns_gauss_loglike_batch": (i, [vp, vp, i, d, vp, i, vp]),
+        "mdns_muse_loglike_batch": (i, [vp, vp, i, vp, i, vp]),
+        "mdns_muse3_loglike_batch": (i, [vp, vp, i, vp, i, vp]),
+        "mdns_dev_alloc": (vp, [sz]),
+        "mdns_dev_free": (None, [vp]),
+        "mdns_h2d": (i, [vp, vp, sz]),
+        "mdns_d2h": (i, [vp, vp, sz]),
+        "mdns_sync": (i, []),
+        "mdns_set_stream": (i, [vp]),
+        "mdns_event_create": (vp, []),
+        "mdns_event_destroy": (None, [vp]),
+        "mdns_event_record": (i, [vp]),
+        "mdns_event_elapsed_ms": (d, [vp, vp]),
+        "mdns_profile": (i, [i]),
+        "mdns_profile_read": (i, [i, vp, vp]),
+        "mdns_gauss_loglike_batch_dev": (i, [vp, vp, i, d, vp, i, vp]),
+        "mdns_muse_loglike_batch_dev": (i, [vp, vp, i, vp, i, vp]),
+        "mdns_muse3_loglike_batch_dev": (i, [vp, vp, i, vp, i, vp]),
+        "mdns_count_within_dev": (i, [vp, i, i, d, vp, i, vp]),
+        "mdns_bootstrap_round_maxsq_dev": (i, [vp, i, i, vp, i, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+
+
+def load():
+    """Load (once) and return the ctypes handle of libmdns_hip.so."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MdnsError(
+                "libmdns_hip.so is not built (%s): run `make -C massivedatans_amd/csrc` or "
+                "`python -c 'import __graft_entry__ as g; g.build()'`. There is no CPU fallback."
+                % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        _declare(lib)
+        _lib = lib
+    return _lib
+
+
+def last_error():
+    return load().mdns_last_error().decode("utf-8", "replace")
+
+
+def check(rc, what):
+    if rc != 0:
+        raise MdnsError("%s failed: %s" % (what, last_error()))
+
+
+def require_device():
+    lib = load()
+    if lib.mdns_device_count() <= 0:
+        raise MdnsError("no HIP device visible: the massivedatans_amd hot path has no CPU fallback")
+    check(lib.mdns_init(-1), "mdns_init")
+    return lib
+
+
+def ptr(a):
+    """Raw data pointer of a C-contiguous numpy array (kept alive by the caller)."""
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)

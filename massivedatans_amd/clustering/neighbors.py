@@ -1,0 +1,106 @@
+"""RadFriends neighbourhood functions, same names and argument meaning as the reference's
+``clustering/neighbors.py:100-231`` ctypes wrappers, running on the GPU through
+``libmdns_hip.so``.
+
+There is no scipy fallback here (the reference silently falls back when its library is
+missing, neighbors.py:179-182; this module raises instead).
+"""
+import ctypes as C
+
+import numpy
+
+from .. import _lib
+
+
+def _pts(a, name):
+    a = _lib.as_f64(a)
+    if a.ndim != 2:
+        raise ValueError("%s must be [n, ndim]" % name)
+    return a
+
+
+def most_distant_nearest_neighbor(xx):
+    """max_i min_{j != i} |x_i - x_j|  (neighbors.py:107-110, cneighbors.c:32-75)."""
+    xx = _pts(xx, "xx")
+    lib = _lib.require_device()
+    r = lib.mdns_most_distant_nearest_neighbor(_lib.ptr(xx), xx.shape[0], xx.shape[1])
+    if r != r:
+        raise _lib.MdnsError("most_distant_nearest_neighbor failed: " + _lib.last_error())
+    return r
+
+
+def is_within_distance_of(xx, maxdistance, y):
+    """True if any member is strictly closer than maxdistance to the point y
+    (neighbors.py:121-124)."""
+    xx = _pts(xx, "xx")
+    y = _lib.as_f64(y)
+    lib = _lib.require_device()
+    r = lib.mdns_is_within_distance_of(_lib.ptr(xx), xx.shape[0], xx.shape[1], float(maxdistance),
+                                       _lib.ptr(y))
+    if r < 0:
+        raise _lib.MdnsError("is_within_distance_of failed: " + _lib.last_error())
+    return r == 1
+
+
+def _count(xx, maxdistance, yy, countmax):
+    xx, yy = _pts(xx, "xx"), _pts(yy, "yy")
+    if xx.shape[1] != yy.shape[1]:
+        raise ValueError("members and points differ in dimension")
+    counts = numpy.zeros(len(yy))
+    lib = _lib.require_device()
+    _lib.check(lib.mdns_count_within_distance_of(
+        _lib.ptr(xx), xx.shape[0], xx.shape[1], float(maxdistance), _lib.ptr(yy), len(yy),
+        _lib.ptr(counts), countmax), "count_within_distance_of")
+    return counts
+
+
+def count_within_distance_of(xx, maxdistance, yy):
+    """Number of members within maxdistance of each point (neighbors.py:137-147)."""
+    return _count(xx, maxdistance, yy, 0).astype(int)
+
+
+def any_within_distance_of(xx, maxdistance, yy):
+    """Whether any member is within maxdistance of each point (neighbors.py:149-159)."""
+    return _count(xx, maxdistance, yy, 1) > 0
+
+
+def draw_bootstrap_choice(nsamples, nbootstraps):
+    """The ``chosen`` matrix exactly as neighbors.py:170-174 builds it: one
+    ``numpy.random.choice(arange(n), size=n, replace=True)`` per round on the GLOBAL legacy
+    RNG stream (the call order is part of the results)."""
+    chosen = numpy.zeros((nsamples, nbootstraps))
+    for b in range(nbootstraps):
+        chosen[numpy.random.choice(numpy.arange(nsamples), size=nsamples, replace=True), b] = 1.
+    return chosen
+
+
+def bootstrapped_maxdistance_chosen(xx, chosen):
+    """K6 for a given chosen matrix (cneighbors.c:125-179)."""
+    xx = _pts(xx, "xx")
+    chosen = _lib.as_f64(chosen)
+    if chosen.ndim != 2 or chosen.shape[0] != xx.shape[0]:
+        raise ValueError("chosen must be [nsamples, nbootstraps]")
+    lib = _lib.require_device()
+    r = lib.mdns_bootstrapped_maxdistance(_lib.ptr(xx), xx.shape[0], xx.shape[1], _lib.ptr(chosen),
+                                          chosen.shape[1])
+    if r != r:
+        raise _lib.MdnsError("bootstrapped_maxdistance failed: " + _lib.last_error())
+    return r
+
+
+def bootstrapped_maxdistance(xx, nbootstraps):
+    """RadFriends safe radius (neighbors.py:169-177)."""
+    xx = _pts(xx, "xx")
+    return bootstrapped_maxdistance_chosen(xx, draw_bootstrap_choice(xx.shape[0], nbootstraps))
+
+
+def nearest_rdistance_guess(u, metric='euclidean'):
+    """neighbors.py:185-187 (euclidean only: the scipy branch is not part of the hot path)."""
+    assert metric == 'euclidean', metric
+    return most_distant_nearest_neighbor(u)
+
+
+def find_rdistance(u, verbose=False, nbootstraps=15, metric='euclidean'):
+    """neighbors.py:229-231: dispatches to the bootstrapped radius."""
+    assert metric == 'euclidean', metric
+    return bootstrapped_maxdistance(u, nbootstraps)

@@ -1,0 +1,711 @@
+// libmdns_hip.so -- context, memory, resident spectra and the host-pointer entry points.
+// Kernels live in mdns_like.hip and mdns_neighbors.hip.
+#include "mdns_internal.h"
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
+
+namespace mdns {
+
+// ---------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------
+static char g_error[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof(g_error), fmt, ap);
+	va_end(ap);
+	if (getenv("MDNS_VERBOSE")) fprintf(stderr, "[mdns] %s\n", g_error);
+}
+
+bool hip_ok(hipError_t e, const char *what, const char *file, int line)
+{
+	if (e == hipSuccess) return true;
+	set_error("%s failed: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+	return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------
+static Context g_ctx;
+static bool g_ctx_ready = false;
+static std::mutex g_ctx_mutex;
+
+static int init_locked(int device)
+{
+	if (g_ctx_ready && (device < 0 || device == g_ctx.device)) return 0;
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+		set_error("no HIP device visible: libmdns_hip has no CPU path");
+		return 1;
+	}
+	if (device < 0) {
+		const char *e = getenv("MDNS_DEVICE");
+		if (e && *e) device = atoi(e);
+		else if ((e = getenv("LOCAL_RANK")) && *e) device = atoi(e) % count;
+		else device = 0;
+	}
+	if (device >= count) {
+		set_error("device %d requested but only %d visible", device, count);
+		return 1;
+	}
+	if (g_ctx_ready) {       // switching device: drop per-device scratch
+		if (g_ctx.d_ws) (void) hipFree(g_ctx.d_ws);
+		if (g_ctx.h_pin) (void) hipHostFree(g_ctx.h_pin);
+		if (g_ctx.own_stream) (void) hipStreamDestroy(g_ctx.own_stream);
+		g_ctx = Context();
+		g_ctx_ready = false;
+	}
+	if (!MDNS_HIP(hipSetDevice(device))) return 1;
+	hipDeviceProp_t prop;
+	if (!MDNS_HIP(hipGetDeviceProperties(&prop, device))) return 1;
+	g_ctx.device = device;
+	g_ctx.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+	if (!MDNS_HIP(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking))) return 1;
+	g_ctx.stream = g_ctx.own_stream;
+	g_ctx_ready = true;
+	return 0;
+}
+
+Context *ctx()
+{
+	std::lock_guard<std::mutex> lock(g_ctx_mutex);
+	if (!g_ctx_ready && init_locked(-1) != 0) return nullptr;
+	// the runtime's current device is per thread: make sure it is ours
+	(void) hipSetDevice(g_ctx.device);
+	return &g_ctx;
+}
+
+void *device_scratch(size_t bytes)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (bytes <= c->d_ws_bytes) return c->d_ws;
+	if (c->d_ws) {
+		(void) hipStreamSynchronize(c->stream);
+		(void) hipFree(c->d_ws);
+		c->d_ws = nullptr; c->d_ws_bytes = 0;
+	}
+	size_t cap = bytes + bytes / 2 + 4096;
+	if (!MDNS_HIP(hipMalloc(&c->d_ws, cap))) return nullptr;
+	c->d_ws_bytes = cap;
+	return c->d_ws;
+}
+
+void *pinned_scratch(size_t bytes)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (bytes <= c->h_pin_bytes) return c->h_pin;
+	if (c->h_pin) {
+		(void) hipStreamSynchronize(c->stream);
+		(void) hipHostFree(c->h_pin);
+		c->h_pin = nullptr; c->h_pin_bytes = 0;
+	}
+	size_t cap = bytes + bytes / 2 + 4096;
+	if (!MDNS_HIP(hipHostMalloc(&c->h_pin, cap, hipHostMallocDefault))) return nullptr;
+	c->h_pin_bytes = cap;
+	return c->h_pin;
+}
+
+// smallest non-negative double T with sqrt(T) >= r.  sqrt on doubles is correctly rounded
+// and monotone, so  sqrt(d) < r  <=>  d < T.  Binary search over the bit patterns of the
+// non-negative doubles (their integer order is their numeric order).
+double sqrt_threshold(double r)
+{
+	if (std::isnan(r)) return r;             // d < NaN is false, as sqrt(d) < NaN is
+	if (!(r > 0)) return 0.0;                // sqrt(d) >= 0 >= r: never inside
+	if (std::isinf(r)) return r;             // every finite d is inside
+	uint64_t lo = 0, hi;                     // predicate false at lo (sqrt(0) = 0 < r)
+	double inf = INFINITY;
+	memcpy(&hi, &inf, 8);                    // predicate true at +inf
+	while (hi - lo > 1) {
+		uint64_t mid = lo + (hi - lo) / 2;
+		double t;
+		memcpy(&t, &mid, 8);
+		if (std::sqrt(t) >= r) hi = mid; else lo = mid;
+	}
+	double T;
+	memcpy(&T, &hi, 8);
+	return T;
+}
+
+// ---------------------------------------------------------------------------------------
+// per-launch event timing
+// ---------------------------------------------------------------------------------------
+struct TimedLaunch { int which; hipEvent_t start, stop; };
+static bool g_profiling = false;
+static std::vector<TimedLaunch> g_pending;
+static std::vector<hipEvent_t> g_event_pool;
+static long long g_prof_count[4] = {0, 0, 0, 0};
+static double g_prof_ms[4] = {0, 0, 0, 0};
+
+static hipEvent_t pooled_event()
+{
+	if (!g_event_pool.empty()) { hipEvent_t e = g_event_pool.back(); g_event_pool.pop_back(); return e; }
+	hipEvent_t e = nullptr;
+	if (hipEventCreate(&e) != hipSuccess) return nullptr;
+	return e;
+}
+
+static void drain_pending()
+{
+	for (TimedLaunch &t : g_pending) {
+		float ms = 0;
+		if (hipEventSynchronize(t.stop) == hipSuccess && hipEventElapsedTime(&ms, t.start, t.stop) == hipSuccess) {
+			g_prof_count[t.which] += 1;
+			g_prof_ms[t.which] += ms;
+		}
+		g_event_pool.push_back(t.start);
+		g_event_pool.push_back(t.stop);
+	}
+	g_pending.clear();
+}
+
+ProfileScope::ProfileScope(int which) : slot(-1)
+{
+	if (!g_profiling || !g_ctx_ready) return;
+	TimedLaunch t{which, pooled_event(), pooled_event()};
+	if (!t.start || !t.stop) return;
+	(void) hipEventRecord(t.start, g_ctx.stream);
+	g_pending.push_back(t);
+	slot = (int) g_pending.size() - 1;
+}
+
+ProfileScope::~ProfileScope()
+{
+	if (slot < 0) return;
+	(void) hipEventRecord(g_pending[slot].stop, g_ctx.stream);
+	if (g_pending.size() >= 4096) drain_pending();      // bound the number of live events
+}
+
+template <typename T>
+static bool grow(T **p, size_t *cap, size_t need)
+{
+	if (need <= *cap) return true;
+	Context *c = ctx();
+	if (!c) return false;
+	if (*p) { (void) hipStreamSynchronize(c->stream); (void) hipFree(*p); *p = nullptr; *cap = 0; }
+	size_t n = need + need / 2 + 64;
+	if (!MDNS_HIP(hipMalloc((void **) p, n * sizeof(T)))) return false;
+	*cap = n;
+	return true;
+}
+
+}  // namespace mdns
+
+using namespace mdns;
+
+// ---------------------------------------------------------------------------------------
+// library state
+// ---------------------------------------------------------------------------------------
+extern "C" int mdns_abi_version(void) { return 1; }
+extern "C" const char *mdns_last_error(void) { return g_error; }
+
+extern "C" int mdns_device_count(void)
+{
+	int count = 0;
+	if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+	return count;
+}
+
+extern "C" int mdns_init(int device)
+{
+	std::lock_guard<std::mutex> lock(g_ctx_mutex);
+	return init_locked(device);
+}
+
+// ---------------------------------------------------------------------------------------
+// raw device helpers
+// ---------------------------------------------------------------------------------------
+extern "C" void *mdns_dev_alloc(size_t bytes)
+{
+	if (!ctx()) return nullptr;
+	void *p = nullptr;
+	if (!MDNS_HIP(hipMalloc(&p, bytes ? bytes : 8))) return nullptr;
+	return p;
+}
+extern "C" void mdns_dev_free(void *p) { if (p && ctx()) (void) hipFree(p); }
+extern "C" int mdns_h2d(void *dst, const void *src, size_t bytes)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
+}
+extern "C" int mdns_d2h(void *dst, const void *src, size_t bytes)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream))) return 1;
+	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
+}
+extern "C" int mdns_sync(void)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
+}
+extern "C" int mdns_set_stream(void *hip_stream)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	c->stream = hip_stream ? (hipStream_t) hip_stream : c->own_stream;
+	return 0;
+}
+extern "C" void *mdns_event_create(void)
+{
+	if (!ctx()) return nullptr;
+	hipEvent_t ev;
+	if (!MDNS_HIP(hipEventCreate(&ev))) return nullptr;
+	return (void *) ev;
+}
+extern "C" void mdns_event_destroy(void *ev) { if (ev) (void) hipEventDestroy((hipEvent_t) ev); }
+extern "C" int mdns_event_record(void *ev)
+{
+	Context *c = ctx();
+	if (!c || !ev) return 1;
+	return MDNS_HIP(hipEventRecord((hipEvent_t) ev, c->stream)) ? 0 : 1;
+}
+extern "C" double mdns_event_elapsed_ms(void *a, void *b)
+{
+	if (!a || !b) return NAN;
+	if (!MDNS_HIP(hipEventSynchronize((hipEvent_t) b))) return NAN;
+	float ms = 0;
+	if (!MDNS_HIP(hipEventElapsedTime(&ms, (hipEvent_t) a, (hipEvent_t) b))) return NAN;
+	return (double) ms;
+}
+
+extern "C" int mdns_profile(int enable)
+{
+	if (!ctx()) return 1;
+	drain_pending();
+	if (enable) for (int k = 0; k < 4; k++) { g_prof_count[k] = 0; g_prof_ms[k] = 0; }
+	g_profiling = enable != 0;
+	return 0;
+}
+extern "C" int mdns_profile_read(int which, long long *launches, double *total_ms)
+{
+	if (!ctx() || which < 0 || which > 3) return 1;
+	drain_pending();
+	if (launches) *launches = g_prof_count[which];
+	if (total_ms) *total_ms = g_prof_ms[which];
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// resident spectra
+// ---------------------------------------------------------------------------------------
+static bool upload_rows(const double *h_src, int ndata, int nx, int layout, double *d_dst, int ld,
+                        bool invert)
+{
+	// stage the host array as it is, then re-lay it on the device into [ndata, ld] rows
+	Context *c = ctx();
+	const size_t n = (size_t) ndata * nx;
+	double *d_tmp = nullptr;
+	if (!MDNS_HIP(hipMalloc((void **) &d_tmp, (n ? n : 1) * sizeof(double)))) return false;
+	bool ok = MDNS_HIP(hipMemcpyAsync(d_tmp, h_src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+	if (ok) {
+		if (layout == MDNS_LAYOUT_CHANNEL_MAJOR) ok = launch_transpose(d_tmp, nx, ndata, d_dst, ld, invert);
+		else ok = launch_copy_rows(d_tmp, nx, ndata, d_dst, ld, invert);
+	}
+	ok = MDNS_HIP(hipStreamSynchronize(c->stream)) && ok;
+	(void) hipFree(d_tmp);
+	return ok;
+}
+
+extern "C" mdns_spectra *mdns_spectra_create(const double *x, const double *y, const double *v,
+                                             int ndata, int nx, int layout)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (ndata < 0 || nx < 0 || !y || (layout != 0 && layout != 1)) {
+		set_error("mdns_spectra_create: bad arguments (ndata=%d nx=%d layout=%d)", ndata, nx, layout);
+		return nullptr;
+	}
+	mdns_spectra *s = new mdns_spectra();
+	s->ndata = ndata; s->nx = nx; s->ld = (nx + 1) & ~1;
+	// +2 doubles of slack: the row kernels read whole 16-byte pairs
+	const size_t elems = (size_t) ndata * s->ld + 2;
+	bool ok = MDNS_HIP(hipMalloc((void **) &s->d_y, elems * sizeof(double)));
+	ok = ok && MDNS_HIP(hipMemsetAsync(s->d_y, 0, elems * sizeof(double), c->stream));
+	ok = ok && upload_rows(y, ndata, nx, layout, s->d_y, s->ld, false);
+	if (ok && v) {
+		ok = MDNS_HIP(hipMalloc((void **) &s->d_w, elems * sizeof(double)));
+		ok = ok && MDNS_HIP(hipMemsetAsync(s->d_w, 0, elems * sizeof(double), c->stream));
+		ok = ok && upload_rows(v, ndata, nx, layout, s->d_w, s->ld, true);
+	}
+	if (ok && x) {
+		ok = MDNS_HIP(hipMalloc((void **) &s->d_x, (nx ? nx : 1) * sizeof(double)));
+		ok = ok && MDNS_HIP(hipMemcpyAsync(s->d_x, x, nx * sizeof(double), hipMemcpyHostToDevice, c->stream));
+		ok = ok && MDNS_HIP(hipStreamSynchronize(c->stream));
+	}
+	if (!ok) { mdns_spectra_destroy(s); return nullptr; }
+	return s;
+}
+
+extern "C" void mdns_spectra_destroy(mdns_spectra *s)
+{
+	if (!s) return;
+	Context *c = ctx();
+	if (c) (void) hipStreamSynchronize(c->stream);
+	void *bufs[] = {s->d_y, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out};
+	for (void *b : bufs) if (b) (void) hipFree(b);
+	delete s;
+}
+extern "C" int mdns_spectra_ndata(const mdns_spectra *s) { return s ? s->ndata : -1; }
+extern "C" int mdns_spectra_nx(const mdns_spectra *s) { return s ? s->nx : -1; }
+
+// ---------------------------------------------------------------------------------------
+// batched scoring, device pointers
+// ---------------------------------------------------------------------------------------
+static bool check_batch(const mdns_spectra *s, int B, int M, const char *who)
+{
+	if (!s) { set_error("%s: null spectra handle", who); return false; }
+	if (B < 0 || M < 0 || M > s->ndata) {
+		set_error("%s: bad sizes B=%d M=%d (ndata=%d)", who, B, M, s->ndata);
+		return false;
+	}
+	return true;
+}
+
+extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_params, int B,
+                                            double noise_level, const int *d_row_ids, int M,
+                                            double *d_Lout)
+{
+	if (!ctx() || !check_batch(s, B, M, "mdns_gauss_loglike_batch_dev")) return 1;
+	if (!s->d_x) { set_error("spectra were created without a wavelength grid"); return 1; }
+	if (B == 0 || M == 0) return 0;
+	const int ldm = model_ld(s->nx);
+	if (!grow(&s->d_model, &s->model_cap, (size_t) B * ldm)) return 1;
+	if (!launch_gauss_model(s->d_x, s->nx, d_params, B, s->d_model, ldm)) return 1;
+	const double scale = -0.5 / (noise_level * noise_level);
+	return launch_gauss_rows(s, s->d_model, ldm, B, scale, d_row_ids, M, d_Lout) ? 0 : 1;
+}
+
+extern "C" int mdns_muse_loglike_batch_dev(mdns_spectra *s, const double *d_ypred, int B,
+                                           const int *d_row_ids, int M, double *d_Lout)
+{
+	if (!ctx() || !check_batch(s, B, M, "mdns_muse_loglike_batch_dev")) return 1;
+	if (!s->d_w) { set_error("spectra were created without variances"); return 1; }
+	if (B == 0 || M == 0) return 0;
+	const int ldm = model_ld(s->nx);
+	if (!grow(&s->d_model, &s->model_cap, (size_t) B * ldm)) return 1;
+	if (!launch_pad_model(d_ypred, s->nx, B, s->d_model, ldm)) return 1;
+	return launch_muse_rows(s, s->d_model, ldm, B, d_row_ids, M, d_Lout) ? 0 : 1;
+}
+
+extern "C" int mdns_muse3_loglike_batch_dev(mdns_spectra *s, const double *d_params, int B,
+                                            const int *d_row_ids, int M, double *d_Lout)
+{
+	if (!ctx() || !check_batch(s, B, M, "mdns_muse3_loglike_batch_dev")) return 1;
+	if (!s->d_w || !s->d_x) { set_error("spectra need variances and a wavelength grid"); return 1; }
+	if (B == 0 || M == 0) return 0;
+	const int ldm = model_ld(s->nx);
+	if (!grow(&s->d_model, &s->model_cap, (size_t) B * ldm)) return 1;
+	if (!launch_muse3_model(s->d_x, s->nx, d_params, B, s->d_model, ldm)) return 1;
+	return launch_muse_rows(s, s->d_model, ldm, B, d_row_ids, M, d_Lout) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// batched scoring, host pointers
+// ---------------------------------------------------------------------------------------
+typedef int (*dev_batch_fn)(mdns_spectra *, const double *, int, const int *, int, double *, double);
+
+static int host_batch(mdns_spectra *s, const double *params, int B, int nparam,
+                      const int *row_ids, int M, double *Lout, double extra, dev_batch_fn fn,
+                      const char *who)
+{
+	Context *c = ctx();
+	if (!c || !check_batch(s, B, M, who)) return 1;
+	if (B == 0 || M == 0) return 0;
+	if (row_ids) {
+		for (int k = 0; k < M; k++)
+			if (row_ids[k] < 0 || row_ids[k] >= s->ndata) {
+				set_error("%s: row_ids[%d]=%d outside [0,%d)", who, k, row_ids[k], s->ndata);
+				return 1;
+			}
+	}
+	const size_t np = (size_t) B * nparam, no = (size_t) B * M;
+	if (!grow(&s->d_params, &s->params_cap, np)) return 1;
+	if (!grow(&s->d_out, &s->out_cap, no)) return 1;
+	if (row_ids && !grow(&s->d_rows, &s->rows_cap, (size_t) M)) return 1;
+	// stage through pinned memory so both copies are truly asynchronous
+	const size_t stage_bytes = np * 8 + (row_ids ? (size_t) M * 4 : 0);
+	const size_t out_off = (stage_bytes + 15) & ~(size_t) 15;
+	char *pin = (char *) pinned_scratch(out_off + no * 8);
+	if (!pin) return 1;
+	memcpy(pin, params, np * 8);
+	bool ok = MDNS_HIP(hipMemcpyAsync(s->d_params, pin, np * 8, hipMemcpyHostToDevice, c->stream));
+	if (ok && row_ids) {
+		memcpy(pin + np * 8, row_ids, (size_t) M * 4);
+		ok = MDNS_HIP(hipMemcpyAsync(s->d_rows, pin + np * 8, (size_t) M * 4, hipMemcpyHostToDevice, c->stream));
+	}
+	if (!ok) return 1;
+	if (fn(s, s->d_params, B, row_ids ? s->d_rows : nullptr, M, s->d_out, extra) != 0) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(pin + out_off, s->d_out, no * 8, hipMemcpyDeviceToHost, c->stream))) return 1;
+	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+	memcpy(Lout, pin + out_off, no * 8);
+	return 0;
+}
+
+static int fn_gauss(mdns_spectra *s, const double *p, int B, const int *r, int M, double *o, double noise)
+{ return mdns_gauss_loglike_batch_dev(s, p, B, noise, r, M, o); }
+static int fn_muse(mdns_spectra *s, const double *p, int B, const int *r, int M, double *o, double)
+{ return mdns_muse_loglike_batch_dev(s, p, B, r, M, o); }
+static int fn_muse3(mdns_spectra *s, const double *p, int B, const int *r, int M, double *o, double)
+{ return mdns_muse3_loglike_batch_dev(s, p, B, r, M, o); }
+
+extern "C" int mdns_gauss_loglike_batch(mdns_spectra *s, const double *params, int B,
+                                        double noise_level, const int *row_ids, int M, double *Lout)
+{
+	return host_batch(s, params, B, 3, row_ids, M, Lout, noise_level, fn_gauss, "mdns_gauss_loglike_batch");
+}
+extern "C" int mdns_muse_loglike_batch(mdns_spectra *s, const double *ypred, int B,
+                                       const int *row_ids, int M, double *Lout)
+{
+	return host_batch(s, ypred, B, s ? s->nx : 0, row_ids, M, Lout, 0, fn_muse, "mdns_muse_loglike_batch");
+}
+extern "C" int mdns_muse3_loglike_batch(mdns_spectra *s, const double *params, int B,
+                                        const int *row_ids, int M, double *Lout)
+{
+	return host_batch(s, params, B, 5, row_ids, M, Lout, 0, fn_muse3, "mdns_muse3_loglike_batch");
+}
+
+// ---------------------------------------------------------------------------------------
+// drop-in likelihood entry points (reference argument lists)
+// ---------------------------------------------------------------------------------------
+struct Registered {
+	const void *yy; const void *vv; int ndata; int nx; mdns_spectra *s;
+};
+static std::vector<Registered> g_registered;
+
+static mdns_spectra *find_registered(const void *yy, const void *vv, int ndata, int nx)
+{
+	for (const Registered &r : g_registered)
+		if (r.yy == yy && r.ndata == ndata && r.nx == nx && (vv == nullptr || r.vv == vv)) return r.s;
+	return nullptr;
+}
+
+extern "C" int mdns_register_spectra(const void *yy, const void *vv, int ndata, int nx)
+{
+	mdns_unregister_spectra(yy);
+	mdns_spectra *s = mdns_spectra_create(nullptr, (const double *) yy, (const double *) vv, ndata, nx,
+	                                      MDNS_LAYOUT_CHANNEL_MAJOR);
+	if (!s) return 1;
+	g_registered.push_back(Registered{yy, vv, ndata, nx, s});
+	return 0;
+}
+
+extern "C" int mdns_unregister_spectra(const void *yy)
+{
+	for (size_t i = 0; i < g_registered.size(); i++)
+		if (g_registered[i].yy == yy) {
+			mdns_spectra_destroy(g_registered[i].s);
+			g_registered.erase(g_registered.begin() + i);
+			return 0;
+		}
+	return 1;
+}
+
+// mask (C bool per data set) -> ascending row ids; returns the count
+static int mask_to_rows(const void *data_mask, int ndata, std::vector<int> &rows)
+{
+	const unsigned char *m = (const unsigned char *) data_mask;
+	rows.clear();
+	for (int i = 0; i < ndata; i++) if (m[i]) rows.push_back(i);
+	return (int) rows.size();
+}
+
+extern "C" int mdns_gauss_like(const void *xp, const void *yyp, int ndata, int nx,
+                               double A, double mu, double sig, double noise_level,
+                               const void *data_maskp, void *Loutp)
+{
+	if (!ctx()) return 1;
+	std::vector<int> rows;
+	const int M = mask_to_rows(data_maskp, ndata, rows);
+	if (M == 0 || nx <= 0) return 0;
+	mdns_spectra *s = find_registered(yyp, nullptr, ndata, nx);
+	const bool temporary = (s == nullptr);
+	if (temporary) {
+		s = mdns_spectra_create((const double *) xp, (const double *) yyp, nullptr, ndata, nx,
+		                        MDNS_LAYOUT_CHANNEL_MAJOR);
+		if (!s) return 1;
+	} else {
+		// the grid belongs to the call, not to the registration (clike.c:35 takes x every call)
+		Context *c = ctx();
+		if (!s->d_x && !MDNS_HIP(hipMalloc((void **) &s->d_x, nx * sizeof(double)))) return 1;
+		if (!MDNS_HIP(hipMemcpyAsync(s->d_x, xp, nx * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
+		if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+	}
+	const double params[3] = {A, mu, sig};
+	std::vector<double> L((size_t) M);
+	int rc = mdns_gauss_loglike_batch(s, params, 1, noise_level, M == ndata ? nullptr : rows.data(), M, L.data());
+	if (temporary) mdns_spectra_destroy(s);
+	if (rc != 0) return rc;
+	// clike.c:72 accumulates the raw sums  sum_j ((m_j - y_ij)/noise)^2 = -2 * loglike
+	double *Lout = (double *) Loutp;
+	for (int k = 0; k < M; k++) Lout[k] += -2.0 * L[k];
+	return 0;
+}
+
+extern "C" int mdns_muse_like(const void *yyp, const void *vvp, const void *ypredp,
+                              const void *data_maskp, int ndata, int nx, void *Loutp)
+{
+	if (!ctx()) return 1;
+	std::vector<int> rows;
+	const int M = mask_to_rows(data_maskp, ndata, rows);
+	if (M == 0) return 0;
+	mdns_spectra *s = find_registered(yyp, vvp, ndata, nx);
+	const bool temporary = (s == nullptr);
+	if (temporary) {
+		s = mdns_spectra_create(nullptr, (const double *) yyp, (const double *) vvp, ndata, nx,
+		                        MDNS_LAYOUT_CHANNEL_MAJOR);
+		if (!s) return 1;
+	}
+	std::vector<double> L((size_t) M);
+	int rc = mdns_muse_loglike_batch(s, (const double *) ypredp, 1, M == ndata ? nullptr : rows.data(), M, L.data());
+	if (temporary) mdns_spectra_destroy(s);
+	if (rc != 0) return rc;
+	double *Lout = (double *) Loutp;          // not compacted; unmasked entries untouched
+	for (int k = 0; k < M; k++) Lout[rows[k]] = L[k];
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// drop-in neighbourhood entry points
+// ---------------------------------------------------------------------------------------
+extern "C" int mdns_count_within_dev(const double *d_members, int K, int ndim, double maxdistance,
+                                     const double *d_cands, int M, int *d_counts)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	if (K < 0 || M < 0 || ndim <= 0) { set_error("mdns_count_within_dev: bad sizes"); return 1; }
+	if (M == 0) return 0;
+	if (!MDNS_HIP(hipMemsetAsync(d_counts, 0, (size_t) M * sizeof(int), c->stream))) return 1;
+	if (K == 0) return 0;
+	return launch_count_within(d_members, K, ndim, sqrt_threshold(maxdistance), d_cands, M, d_counts) ? 0 : 1;
+}
+
+extern "C" int mdns_bootstrap_round_maxsq_dev(const double *d_members, int K, int ndim,
+                                              const double *d_chosen, int nbootstraps,
+                                              double *d_round_sq)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	if (K < 0 || nbootstraps < 0 || ndim <= 0) { set_error("mdns_bootstrap_round_maxsq_dev: bad sizes"); return 1; }
+	if (nbootstraps == 0) return 0;
+	if (!MDNS_HIP(hipMemsetAsync(d_round_sq, 0, (size_t) nbootstraps * sizeof(double), c->stream))) return 1;
+	if (K == 0) return 0;
+	return launch_bootstrap(d_members, K, ndim, d_chosen, nbootstraps, d_round_sq) ? 0 : 1;
+}
+
+// upload a few host arrays into the context's device scratch (16-byte aligned slots) and
+// hand back the device pointers; one H2D per array on the library stream
+static bool stage_in(const void *const *src, const size_t *bytes, int n, size_t extra_bytes, char **d_ptrs,
+                     char **d_extra)
+{
+	Context *c = ctx();
+	size_t total = 0;
+	for (int i = 0; i < n; i++) total += (bytes[i] + 255) & ~(size_t) 255;
+	char *base = (char *) device_scratch(total + extra_bytes + 256);
+	if (!base) return false;
+	size_t off = 0;
+	for (int i = 0; i < n; i++) {
+		d_ptrs[i] = base + off;
+		if (bytes[i] && !MDNS_HIP(hipMemcpyAsync(d_ptrs[i], src[i], bytes[i], hipMemcpyHostToDevice, c->stream)))
+			return false;
+		off += (bytes[i] + 255) & ~(size_t) 255;
+	}
+	*d_extra = base + off;
+	return true;
+}
+
+extern "C" int mdns_count_within_distance_of(const void *xx, int nsamples, int ndim, double maxdistance,
+                                             const void *yy, int nothers, void *outp, const int countmax)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	if (nothers <= 0) return 0;
+	if (nsamples <= 0) return 0;               // no member: nothing is incremented
+	if (ndim <= 0) { set_error("mdns_count_within_distance_of: ndim=%d", ndim); return 1; }
+	const void *src[2] = {xx, yy};
+	const size_t bytes[2] = {(size_t) nsamples * ndim * 8, (size_t) nothers * ndim * 8};
+	char *d[2], *d_counts;
+	if (!stage_in(src, bytes, 2, (size_t) nothers * 4, d, &d_counts)) return 1;
+	if (mdns_count_within_dev((const double *) d[0], nsamples, ndim, maxdistance, (const double *) d[1],
+	                          nothers, (int *) d_counts) != 0) return 1;
+	std::vector<int> hits((size_t) nothers);
+	if (!MDNS_HIP(hipMemcpyAsync(hits.data(), d_counts, (size_t) nothers * 4, hipMemcpyDeviceToHost, c->stream))) return 1;
+	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+	// cneighbors.c:108-115: out[j]++ per member inside, scanning stops once out[j] >= countmax
+	double *out = (double *) outp;
+	for (int j = 0; j < nothers; j++) {
+		int h = hits[j];
+		if (countmax > 0) {
+			while (h > 0) { out[j] += 1; h--; if (out[j] >= countmax) break; }
+		} else {
+			for (; h > 0; h--) out[j] += 1;
+		}
+	}
+	return 0;
+}
+
+extern "C" int mdns_is_within_distance_of(const void *xx, int nsamples, int ndim, double maxdistance,
+                                          const void *y)
+{
+	double out = 0;
+	if (nsamples <= 0) return 0;
+	if (mdns_count_within_distance_of(xx, nsamples, ndim, maxdistance, y, 1, &out, 1) != 0) return -1;
+	return out > 0 ? 1 : 0;
+}
+
+extern "C" double mdns_bootstrapped_maxdistance(const void *xx, int nsamples, int ndim,
+                                                const void *choice, int nbootstraps)
+{
+	Context *c = ctx();
+	if (!c) return NAN;
+	if (nsamples <= 0 || nbootstraps <= 0 || ndim <= 0) {
+		set_error("mdns_bootstrapped_maxdistance: bad sizes (%d, %d, %d)", nsamples, ndim, nbootstraps);
+		return NAN;
+	}
+	const void *src[2] = {xx, choice};
+	const size_t bytes[2] = {(size_t) nsamples * ndim * 8, (size_t) nsamples * nbootstraps * 8};
+	char *d[2], *d_round;
+	if (!stage_in(src, bytes, 2, (size_t) nbootstraps * 8, d, &d_round)) return NAN;
+	if (mdns_bootstrap_round_maxsq_dev((const double *) d[0], nsamples, ndim, (const double *) d[1],
+	                                   nbootstraps, (double *) d_round) != 0) return NAN;
+	std::vector<double> sq((size_t) nbootstraps);
+	if (!MDNS_HIP(hipMemcpyAsync(sq.data(), d_round, (size_t) nbootstraps * 8, hipMemcpyDeviceToHost, c->stream))) return NAN;
+	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return NAN;
+	// sqrt is monotone: max_i sqrt(min_j d_ij) = sqrt(max_i min_j d_ij) (cneighbors.c:160-174)
+	double best = 0;
+	for (int b = 0; b < nbootstraps; b++) { const double r = std::sqrt(sq[b]); if (r > best) best = r; }
+	return best;
+}
+
+extern "C" double mdns_most_distant_nearest_neighbor(const void *xx, int nsamples, int ndim)
+{
+	Context *c = ctx();
+	if (!c) return NAN;
+	if (nsamples <= 0 || ndim <= 0) { set_error("mdns_most_distant_nearest_neighbor: bad sizes"); return NAN; }
+	const void *src[1] = {xx};
+	const size_t bytes[1] = {(size_t) nsamples * ndim * 8};
+	char *d[1], *d_out;
+	if (!stage_in(src, bytes, 1, 8, d, &d_out)) return NAN;
+	if (!MDNS_HIP(hipMemsetAsync(d_out, 0, 8, c->stream))) return NAN;
+	if (!launch_nn_maxsq((const double *) d[0], nsamples, ndim, (double *) d_out)) return NAN;
+	double sq = 0;
+	if (!MDNS_HIP(hipMemcpyAsync(&sq, d_out, 8, hipMemcpyDeviceToHost, c->stream))) return NAN;
+	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return NAN;
+	return std::sqrt(sq);
+}

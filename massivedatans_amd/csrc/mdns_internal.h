@@ -1,0 +1,88 @@
+// Internal declarations shared by the translation units of libmdns_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+#include "mdns.h"
+
+namespace mdns {
+
+// ---- error handling ---------------------------------------------------------------------
+void set_error(const char *fmt, ...);
+bool hip_ok(hipError_t e, const char *what, const char *file, int line);
+#define MDNS_HIP(call) ::mdns::hip_ok((call), #call, __FILE__, __LINE__)
+
+// ---- per-process context (one process drives one GPU) -----------------------------------
+struct Context {
+	int device = -1;
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;     // stream every launch goes to (own_stream unless overridden)
+	int num_cus = 256;
+	// grow-only scratch: device workspace and pinned host staging
+	void *d_ws = nullptr;   size_t d_ws_bytes = 0;
+	void *h_pin = nullptr;  size_t h_pin_bytes = 0;
+};
+// nullptr (and mdns_last_error set) when no device can be initialised
+Context *ctx();
+// scratch accessors; return nullptr on allocation failure.  Contents are NOT preserved
+// across a growing call.
+void *device_scratch(size_t bytes);
+void *pinned_scratch(size_t bytes);
+
+// ---- resident spectra -------------------------------------------------------------------
+}  // namespace mdns
+
+struct mdns_spectra {
+	int ndata = 0;      // number of spectra (rows)
+	int nx = 0;         // channels per spectrum
+	int ld = 0;         // row stride in doubles (nx rounded up to even => 16-byte aligned rows)
+	double *d_y = nullptr;   // [ndata, ld]
+	double *d_w = nullptr;   // [ndata, ld] inverse variances 1/v (K2), or nullptr
+	double *d_x = nullptr;   // [nx] wavelength grid, or nullptr
+	// per-handle grow-only device buffers for the host-pointer batch API
+	double *d_model = nullptr; size_t model_cap = 0;   // [B, ldm]
+	double *d_params = nullptr; size_t params_cap = 0;
+	int *d_rows = nullptr; size_t rows_cap = 0;
+	double *d_out = nullptr; size_t out_cap = 0;
+};
+
+namespace mdns {
+
+// model row stride for nx channels: multiple of 512 doubles (zero padded), so that every
+// lane / thread of the row kernels can load its channel pair without a bounds test
+inline int model_ld(int nx) { return nx <= 0 ? 512 : ((nx + 511) / 512) * 512; }
+
+// launchers implemented in mdns_like.hip (all asynchronous on ctx()->stream)
+bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B,
+                        double *d_model, int ldm);
+bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B,
+                        double *d_model, int ldm);
+bool launch_gauss_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
+                       double scale, const int *d_rows, int M, double *d_out);
+bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
+                      const int *d_rows, int M, double *d_out);
+bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld,
+                      bool invert);
+bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int ld,
+                      bool invert);
+bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm);
+
+// launchers implemented in mdns_neighbors.hip
+bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
+                         const double *d_cands, int M, int *d_counts);
+bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_chosen,
+                      int nbootstraps, double *d_round_sq);
+bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out);
+
+// optional per-launch event timing (mdns_profile); which: 0 gauss rows, 1 muse rows,
+// 2 count-within, 3 nearest-chosen.  Use as:  { ProfileScope ps(which); launch...; }
+struct ProfileScope {
+	int slot;
+	explicit ProfileScope(int which);
+	~ProfileScope();
+};
+
+// smallest double T with sqrt(T) >= r, so that  sqrt(d) < r  <=>  d < T  for every d >= 0
+double sqrt_threshold(double r);
+
+}  // namespace mdns

@@ -1,0 +1,454 @@
+// Likelihood kernels for gfx950 (MI355X): spectral templates and the per-spectrum
+// residual reductions that replace the reference's clike.c / cmuselike.c loops.
+//
+// Data layout in HBM: spectra are rows, Y[ndata][ld] (ld = nx rounded up to even, so every
+// row starts 16-byte aligned and lanes read double2 = 16 B: a wave reads 1 KiB contiguous per
+// load instruction).  Templates ("models") are M[B][ldm], ldm a multiple of 512 and
+// zero-padded past nx, so lanes beyond the last channel contribute (0-0)^2 = 0.
+//
+// K1 (gauss rows): one wavefront scores R spectra at a time.  Lane l owns channel pairs
+//   {p*128 + 2l, p*128 + 2l + 1}, p < NP; the spectrum values stay in registers while the
+//   wave walks over the candidates in tiles of BT, so each spectrum is fetched from HBM
+//   exactly once per launch however many candidates are scored.  Partial sums are reduced
+//   across the 64 lanes with shuffles and written as log-likelihoods.
+// K2 (muse rows): one 256-thread workgroup per spectrum (rows are 32 KiB at 4096 channels);
+//   y and 1/v stay in registers over both passes of cmuselike.c:50-61 (scale, then chi), so
+//   the reference's two strided passes become one HBM pass.
+#include "mdns_internal.h"
+
+namespace mdns {
+
+static constexpr int kBlock = 256;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+	return v;
+}
+
+// ---------------------------------------------------------------------------------------
+// templates
+// ---------------------------------------------------------------------------------------
+
+// single Gaussian line, clike.c:65:  A * exp(-0.5 * ((mu - x_j)/sig)^2)
+__global__ void k_gauss_model(const double *__restrict__ x, int nx, const double *__restrict__ params,
+                              double *__restrict__ model, int ldm)
+{
+	const int b = blockIdx.y;
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= ldm) return;
+	double m = 0.0;
+	if (j < nx) {
+		const double A = params[3 * b], mu = params[3 * b + 1], sig = params[3 * b + 2];
+		const double t = (mu - x[j]) / sig;
+		m = A * exp(-0.5 * (t * t));
+	}
+	model[(size_t) b * ldm + j] = m;
+}
+
+// three lines on a flat continuum (config C5; massivedatans_amd/gen.py muse_template)
+__global__ void k_muse3_model(const double *__restrict__ x, int nx, const double *__restrict__ params,
+                              double *__restrict__ model, int ldm)
+{
+	const int b = blockIdx.y;
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= ldm) return;
+	double m = 0.0;
+	if (j < nx) {
+		const double *p = params + 5 * b;
+		const double amp = pow(10.0, p[0]), z = p[1], ws = pow(10.0, p[2]);
+		const double ratio[3] = {p[3], 1.0, p[4]};
+		const double mu0[3] = {4861.3, 5006.8, 6562.8};
+		const double a0[3] = {0.35, 1.0, 0.8};
+		const double sg[3] = {4.0, 4.0, 5.0};
+		const double xj = x[j];
+		m = 1.0;
+#pragma unroll
+		for (int g = 0; g < 3; g++) {
+			const double t = (xj - mu0[g] * (1 + z)) / (sg[g] * ws);
+			m = m + amp * ratio[g] * a0[g] * exp(-0.5 * (t * t));
+		}
+	}
+	model[(size_t) b * ldm + j] = m;
+}
+
+// caller-supplied templates [B][nx] -> zero padded [B][ldm]
+__global__ void k_pad_model(const double *__restrict__ src, int nx, double *__restrict__ dst, int ldm)
+{
+	const int b = blockIdx.y;
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j >= ldm) return;
+	dst[(size_t) b * ldm + j] = j < nx ? src[(size_t) b * nx + j] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------
+// re-laying spectra at upload
+// ---------------------------------------------------------------------------------------
+
+// src [nx][ndata] (reference layout, sample.py:31 / clike.c:72) -> dst [ndata][ld]
+__global__ void k_transpose(const double *__restrict__ src, int nx, int ndata, double *__restrict__ dst,
+                            int ld, int invert)
+{
+	__shared__ double tile[32][33];
+	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
+	for (int jj = ty; jj < 32; jj += 8) {
+		const int j = j0 + jj, i = i0 + tx;
+		if (j < nx && i < ndata) tile[jj][tx] = src[(size_t) j * ndata + i];
+	}
+	__syncthreads();
+	for (int ii = ty; ii < 32; ii += 8) {
+		const int i = i0 + ii, j = j0 + tx;
+		if (i < ndata && j < nx) {
+			const double val = tile[tx][ii];
+			dst[(size_t) i * ld + j] = invert ? 1.0 / val : val;
+		}
+	}
+}
+
+__global__ void k_copy_rows(const double *__restrict__ src, int nx, int ndata, double *__restrict__ dst,
+                            int ld, int invert)
+{
+	const size_t n = (size_t) nx * ndata;
+	for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t) gridDim.x * blockDim.x) {
+		const size_t i = e / nx, j = e % nx;
+		const double val = src[e];
+		dst[i * ld + j] = invert ? 1.0 / val : val;
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: Gaussian-line rows
+// ---------------------------------------------------------------------------------------
+// NP  = channel pairs per lane (nx <= 128*NP);  BT = candidates per register tile;
+// R   = spectra in flight per wave;  HOIST = all candidates fit one tile, keep it in registers
+template <int NP, int BT, int R, bool HOIST>
+__global__ __launch_bounds__(kBlock) void k_gauss_rows(
+    const double *__restrict__ Y, int ld, int nx, const double *__restrict__ model, int ldm, int B,
+    double scale, const int *__restrict__ rows, int M, double *__restrict__ out)
+{
+	const int lane = threadIdx.x & 63;
+	const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+	const int nwaves = (gridDim.x * kBlock) >> 6;
+	const int ch = 2 * lane;
+
+	bool valid[NP];
+#pragma unroll
+	for (int p = 0; p < NP; p++) valid[p] = (p * 128 + ch) < nx;
+
+	double2 m[BT][NP];
+	if (HOIST) {
+#pragma unroll
+		for (int b = 0; b < BT; b++) {
+			const int bb = b < B ? b : B - 1;
+#pragma unroll
+			for (int p = 0; p < NP; p++)
+				m[b][p] = *reinterpret_cast<const double2 *>(model + (size_t) bb * ldm + p * 128 + ch);
+		}
+	}
+
+	for (int k0 = wave * R; k0 < M; k0 += nwaves * R) {
+		double2 y[R][NP];
+#pragma unroll
+		for (int r = 0; r < R; r++) {
+			const int k = (k0 + r < M) ? k0 + r : M - 1;
+			const int row = rows ? rows[k] : k;
+			const double *yr = Y + (size_t) row * ld + ch;
+#pragma unroll
+			for (int p = 0; p < NP; p++)
+				y[r][p] = valid[p] ? *reinterpret_cast<const double2 *>(yr + p * 128) : make_double2(0.0, 0.0);
+		}
+		for (int b0 = 0; b0 < B; b0 += BT) {
+			if (!HOIST) {
+#pragma unroll
+				for (int b = 0; b < BT; b++) {
+					const int bb = (b0 + b < B) ? b0 + b : B - 1;
+#pragma unroll
+					for (int p = 0; p < NP; p++)
+						m[b][p] = *reinterpret_cast<const double2 *>(model + (size_t) bb * ldm + p * 128 + ch);
+				}
+			}
+			double acc[BT][R];
+#pragma unroll
+			for (int b = 0; b < BT; b++)
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					double a = 0.0;
+#pragma unroll
+					for (int p = 0; p < NP; p++) {
+						const double d0 = m[b][p].x - y[r][p].x;
+						const double d1 = m[b][p].y - y[r][p].y;
+						a = fma(d0, d0, a);
+						a = fma(d1, d1, a);
+					}
+					acc[b][r] = a;
+				}
+			// reduce over the 64 lanes; lane (b*R + r) keeps value (b, r) so that the
+			// BT*R results leave in one store instruction
+			double mine = 0.0;
+#pragma unroll
+			for (int b = 0; b < BT; b++)
+#pragma unroll
+				for (int r = 0; r < R; r++) {
+					const double s = wave_sum(acc[b][r]);
+					if (lane == b * R + r) mine = s;
+				}
+			if (lane < BT * R) {
+				const int b = b0 + lane / R, k = k0 + lane % R;
+				if (b < B && k < M) out[(size_t) b * M + k] = mine * scale;
+			}
+		}
+	}
+}
+
+// any nx: channels walked in chunks of 128, templates re-read per chunk (L2 resident)
+template <int BT>
+__global__ __launch_bounds__(kBlock) void k_gauss_rows_generic(
+    const double *__restrict__ Y, int ld, int nx, const double *__restrict__ model, int ldm, int B,
+    double scale, const int *__restrict__ rows, int M, double *__restrict__ out)
+{
+	const int lane = threadIdx.x & 63;
+	const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+	const int nwaves = (gridDim.x * kBlock) >> 6;
+	const int ch = 2 * lane;
+	for (int k = wave; k < M; k += nwaves) {
+		const int row = rows ? rows[k] : k;
+		const double *yr = Y + (size_t) row * ld;
+		for (int b0 = 0; b0 < B; b0 += BT) {
+			double acc[BT];
+#pragma unroll
+			for (int b = 0; b < BT; b++) acc[b] = 0.0;
+			for (int c0 = 0; c0 < nx; c0 += 128) {
+				const bool ok = c0 + ch < nx;
+				const double2 yv = ok ? *reinterpret_cast<const double2 *>(yr + c0 + ch) : make_double2(0.0, 0.0);
+#pragma unroll
+				for (int b = 0; b < BT; b++) {
+					const int bb = (b0 + b < B) ? b0 + b : B - 1;
+					const double2 mv = *reinterpret_cast<const double2 *>(model + (size_t) bb * ldm + c0 + ch);
+					const double d0 = mv.x - yv.x, d1 = mv.y - yv.y;
+					acc[b] = fma(d0, d0, acc[b]);
+					acc[b] = fma(d1, d1, acc[b]);
+				}
+			}
+#pragma unroll
+			for (int b = 0; b < BT; b++) {
+				const double s = wave_sum(acc[b]);
+				if (lane == 0 && b0 + b < B) out[(size_t) (b0 + b) * M + k] = s * scale;
+			}
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: scale-marginalised chi^2 rows (cmuselike.c:45-64)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_sum4(double v, double *slot /* [4] in LDS */)
+{
+	v = wave_sum(v);
+	if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
+	__syncthreads();
+	return (slot[0] + slot[1]) + (slot[2] + slot[3]);
+}
+
+// NP = channel pairs per thread (nx <= 512*NP); W holds 1/v
+template <int NP>
+__global__ __launch_bounds__(kBlock) void k_muse_rows(
+    const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
+    const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M,
+    double *__restrict__ out)
+{
+	__shared__ double red[3][4];
+	const int ch = 2 * threadIdx.x;
+	bool valid[NP];
+#pragma unroll
+	for (int p = 0; p < NP; p++) valid[p] = (p * 512 + ch) < nx;
+
+	for (int k = blockIdx.x; k < M; k += gridDim.x) {
+		const int row = rows ? rows[k] : k;
+		const size_t base = (size_t) row * ld + ch;
+		double2 y[NP], w[NP];
+#pragma unroll
+		for (int p = 0; p < NP; p++) {
+			y[p] = valid[p] ? *reinterpret_cast<const double2 *>(Y + base + p * 512) : make_double2(0.0, 0.0);
+			w[p] = valid[p] ? *reinterpret_cast<const double2 *>(W + base + p * 512) : make_double2(0.0, 0.0);
+		}
+		// nx odd: the pad channel of the last pair must not contribute (its 1/v is garbage-free
+		// zero because the W buffer is zero-filled before the upload)
+		for (int b = 0; b < B; b++) {
+			double2 m[NP];
+			double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+			for (int p = 0; p < NP; p++) {
+				m[p] = *reinterpret_cast<const double2 *>(model + (size_t) b * ldm + p * 512 + ch);
+				s1 = fma(y[p].x * m[p].x, w[p].x, s1);
+				s1 = fma(y[p].y * m[p].y, w[p].y, s1);
+				s2 = fma(m[p].x * m[p].x, w[p].x, s2);
+				s2 = fma(m[p].y * m[p].y, w[p].y, s2);
+			}
+			const double t1 = block_sum4(s1, red[0]);
+			const double t2 = block_sum4(s2, red[1]);
+			const double s = t1 / (1e-10 + t2);           // cmuselike.c:52,57
+			double chi = 0.0;
+#pragma unroll
+			for (int p = 0; p < NP; p++) {
+				const double r0 = y[p].x - s * m[p].x;
+				const double r1 = y[p].y - s * m[p].y;
+				chi = fma(r0 * r0, w[p].x, chi);
+				chi = fma(r1 * r1, w[p].y, chi);
+			}
+			const double tot = block_sum4(chi, red[2]);
+			if (threadIdx.x == 0) out[(size_t) b * M + k] = -0.5 * tot;
+			// red[0] is rewritten only after every wave passed the two later barriers
+		}
+	}
+}
+
+// any nx: two passes over the row from memory (the row is L2-hot for the second pass)
+__global__ __launch_bounds__(kBlock) void k_muse_rows_generic(
+    const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
+    const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M,
+    double *__restrict__ out)
+{
+	__shared__ double red[3][4];
+	for (int k = blockIdx.x; k < M; k += gridDim.x) {
+		const int row = rows ? rows[k] : k;
+		const double *yr = Y + (size_t) row * ld, *wr = W + (size_t) row * ld;
+		for (int b = 0; b < B; b++) {
+			const double *mr = model + (size_t) b * ldm;
+			double s1 = 0.0, s2 = 0.0;
+			for (int j = threadIdx.x; j < nx; j += kBlock) {
+				s1 = fma(yr[j] * mr[j], wr[j], s1);
+				s2 = fma(mr[j] * mr[j], wr[j], s2);
+			}
+			const double t1 = block_sum4(s1, red[0]);
+			const double t2 = block_sum4(s2, red[1]);
+			const double s = t1 / (1e-10 + t2);
+			double chi = 0.0;
+			for (int j = threadIdx.x; j < nx; j += kBlock) {
+				const double r = yr[j] - s * mr[j];
+				chi = fma(r * r, wr[j], chi);
+			}
+			const double tot = block_sum4(chi, red[2]);
+			if (threadIdx.x == 0) out[(size_t) b * M + k] = -0.5 * tot;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+static bool launched(const char *name)
+{
+	hipError_t e = hipGetLastError();
+	if (e == hipSuccess) return true;
+	set_error("launch of %s failed: %s", name, hipGetErrorString(e));
+	return false;
+}
+
+bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B, double *d_model, int ldm)
+{
+	Context *c = ctx();
+	dim3 grid((ldm + kBlock - 1) / kBlock, B);
+	hipLaunchKernelGGL(k_gauss_model, grid, dim3(kBlock), 0, c->stream, d_x, nx, d_params, d_model, ldm);
+	return launched("k_gauss_model");
+}
+
+bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B, double *d_model, int ldm)
+{
+	Context *c = ctx();
+	dim3 grid((ldm + kBlock - 1) / kBlock, B);
+	hipLaunchKernelGGL(k_muse3_model, grid, dim3(kBlock), 0, c->stream, d_x, nx, d_params, d_model, ldm);
+	return launched("k_muse3_model");
+}
+
+bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm)
+{
+	Context *c = ctx();
+	dim3 grid((ldm + kBlock - 1) / kBlock, B);
+	hipLaunchKernelGGL(k_pad_model, grid, dim3(kBlock), 0, c->stream, d_src, nx, d_dst, ldm);
+	return launched("k_pad_model");
+}
+
+bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld, bool invert)
+{
+	Context *c = ctx();
+	if (nx == 0 || ndata == 0) return true;
+	dim3 grid((ndata + 31) / 32, (nx + 31) / 32);
+	hipLaunchKernelGGL(k_transpose, grid, dim3(kBlock), 0, c->stream, d_src, nx, ndata, d_dst, ld, invert ? 1 : 0);
+	return launched("k_transpose");
+}
+
+bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int ld, bool invert)
+{
+	Context *c = ctx();
+	if (nx == 0 || ndata == 0) return true;
+	const size_t n = (size_t) nx * ndata;
+	const int blocks = (int) ((n + kBlock - 1) / kBlock < 8192 ? (n + kBlock - 1) / kBlock : 8192);
+	hipLaunchKernelGGL(k_copy_rows, dim3(blocks), dim3(kBlock), 0, c->stream, d_src, nx, ndata, d_dst, ld, invert ? 1 : 0);
+	return launched("k_copy_rows");
+}
+
+template <int NP, int BT, int R>
+static void launch_gauss_rows_t(const mdns_spectra *s, const double *d_model, int ldm, int B, double scale,
+                                const int *d_rows, int M, double *d_out, hipStream_t stream, int num_cus)
+{
+	const int waves_needed = (M + R - 1) / R;
+	int blocks = (waves_needed + 3) / 4;
+	const int cap = num_cus * 8;
+	if (blocks > cap) blocks = cap;
+	if (blocks < 1) blocks = 1;
+	if (B <= BT)
+		hipLaunchKernelGGL((k_gauss_rows<NP, BT, R, true>), dim3(blocks), dim3(kBlock), 0, stream,
+		                   s->d_y, s->ld, s->nx, d_model, ldm, B, scale, d_rows, M, d_out);
+	else
+		hipLaunchKernelGGL((k_gauss_rows<NP, BT, R, false>), dim3(blocks), dim3(kBlock), 0, stream,
+		                   s->d_y, s->ld, s->nx, d_model, ldm, B, scale, d_rows, M, d_out);
+}
+
+bool launch_gauss_rows(const mdns_spectra *s, const double *d_model, int ldm, int B, double scale,
+                       const int *d_rows, int M, double *d_out)
+{
+	Context *c = ctx();
+	const int nx = s->nx;
+	ProfileScope prof(0);
+	if (nx <= 128) {
+		if (B == 1) launch_gauss_rows_t<1, 1, 4>(s, d_model, ldm, B, scale, d_rows, M, d_out, c->stream, c->num_cus);
+		else        launch_gauss_rows_t<1, 4, 4>(s, d_model, ldm, B, scale, d_rows, M, d_out, c->stream, c->num_cus);
+	} else if (nx <= 256) {
+		if (B == 1) launch_gauss_rows_t<2, 1, 4>(s, d_model, ldm, B, scale, d_rows, M, d_out, c->stream, c->num_cus);
+		else        launch_gauss_rows_t<2, 4, 4>(s, d_model, ldm, B, scale, d_rows, M, d_out, c->stream, c->num_cus);
+	} else if (nx <= 512) {
+		if (B == 1) launch_gauss_rows_t<4, 1, 2>(s, d_model, ldm, B, scale, d_rows, M, d_out, c->stream, c->num_cus);
+		else        launch_gauss_rows_t<4, 4, 2>(s, d_model, ldm, B, scale, d_rows, M, d_out, c->stream, c->num_cus);
+	} else {
+		int blocks = (M + 3) / 4;
+		if (blocks > c->num_cus * 8) blocks = c->num_cus * 8;
+		hipLaunchKernelGGL((k_gauss_rows_generic<4>), dim3(blocks), dim3(kBlock), 0, c->stream,
+		                   s->d_y, s->ld, nx, d_model, ldm, B, scale, d_rows, M, d_out);
+	}
+	return launched("k_gauss_rows");
+}
+
+bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int B, const int *d_rows,
+                      int M, double *d_out)
+{
+	Context *c = ctx();
+	const int nx = s->nx;
+	int blocks = M < c->num_cus * 8 ? M : c->num_cus * 8;
+	if (blocks < 1) blocks = 1;
+	ProfileScope prof(1);
+#define MUSE_LAUNCH(NP) hipLaunchKernelGGL((k_muse_rows<NP>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+	s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out)
+	if (nx <= 512) MUSE_LAUNCH(1);
+	else if (nx <= 1024) MUSE_LAUNCH(2);
+	else if (nx <= 2048) MUSE_LAUNCH(4);
+	else if (nx <= 4096) MUSE_LAUNCH(8);
+	else
+		hipLaunchKernelGGL(k_muse_rows_generic, dim3(blocks), dim3(kBlock), 0, c->stream,
+		                   s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out);
+#undef MUSE_LAUNCH
+	return launched("k_muse_rows");
+}
+
+}  // namespace mdns

@@ -1,0 +1,262 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the
+committed golden vectors (made from the reference's own C).
+
+Bars: geometry (K3-K6) bit-exact; likelihoods (K1, K2) within 1e-6 relative as BASELINE.json
+states -- the tests assert the much tighter 1e-12 the kernels actually reach.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from massivedatans_amd import _lib, gen
+
+pytestmark = pytest.mark.gpu
+
+RTOL_L = 1e-12      # asserted; the contract in BASELINE.json is 1e-6 relative
+
+
+def rel_err(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-300)) if a.size else 0.0
+
+
+@pytest.fixture(scope="module")
+def nb():
+    from massivedatans_amd.clustering import neighbors
+    return neighbors
+
+
+# ---------------------------------------------------------------- K1 ----------------------
+def test_k1_dropin_matches_golden(hip, golden):
+    for name in ("horns", "nothing"):
+        x, y = golden["k1_%s_x" % name], golden["k1_%s_y" % name]
+        nx, nd = y.shape
+        for mi, m in enumerate(golden["k1_%s_masks" % name]):
+            m = np.ascontiguousarray(m)
+            want = golden["k1_%s_out%d" % (name, mi)]
+            for p, w in zip(golden["k1_%s_params" % name], want):
+                out = np.zeros(int(m.sum()))
+                rc = hip.mdns_gauss_like(_lib.ptr(x), _lib.ptr(y), nd, nx, p[0], p[1], 10 ** p[2], 0.01,
+                                         _lib.ptr(m), _lib.ptr(out))
+                assert rc == 0, hip.mdns_last_error()
+                assert out.shape == w.shape
+                assert rel_err(out, w) < RTOL_L
+    # += semantics of clike.c:72
+    pre = golden["k1_accum_pre"].copy()
+    x, y = golden["k1_horns_x"], golden["k1_horns_y"]
+    m = np.ones(y.shape[1], dtype=np.bool_)
+    assert hip.mdns_gauss_like(_lib.ptr(x), _lib.ptr(y), y.shape[1], y.shape[0], 0.3, 640., 4., 0.01,
+                               _lib.ptr(m), _lib.ptr(pre)) == 0
+    assert rel_err(pre, golden["k1_accum_out"]) < RTOL_L
+
+
+def test_k1_dropin_shim_library(golden):
+    """Through the drop-in clike.so exactly as sample.py:84-106 binds it."""
+    lib = C.CDLL(os.path.join(_lib.DROPIN_DIR, "clike.so"))
+    nd_ = np.ctypeslib.ndpointer
+    lib.like.argtypes = [nd_(dtype=np.float64, ndim=1, flags='C_CONTIGUOUS'),
+                         nd_(dtype=np.float64, ndim=2, flags='C_CONTIGUOUS'), C.c_int, C.c_int,
+                         C.c_double, C.c_double, C.c_double, C.c_double,
+                         nd_(dtype=np.bool_, ndim=1, flags='C_CONTIGUOUS'),
+                         nd_(dtype=np.float64, ndim=1, flags='C_CONTIGUOUS')]
+    x, y = golden["k1_horns_x"], golden["k1_horns_y"]
+    m = np.ascontiguousarray(golden["k1_horns_masks"][1])
+    p = golden["k1_horns_params"][0]
+    Lout = np.zeros(m.sum())
+    assert lib.like(x, y, y.shape[1], y.shape[0], p[0], p[1], 10 ** p[2], 0.01, m, Lout) == 0
+    assert rel_err(Lout, golden["k1_horns_out1"][0]) < RTOL_L
+
+
+@pytest.mark.parametrize("nd,nx", [(1, 1), (3, 7), (130, 128), (257, 200), (64, 255), (40, 300),
+                                   (33, 512), (9, 777)])
+def test_k1_batch_vs_oracle_ragged(oracle, nd, nx):
+    from massivedatans_amd.like import GaussLineSpectra
+    rng = np.random.RandomState(nd * 1000 + nx)
+    x = np.sort(rng.uniform(400, 800, nx))
+    y = np.ascontiguousarray(rng.normal(0, 0.05, size=(nx, nd)))
+    sp = GaussLineSpectra(x, y, noise_level=0.01)
+    for B in (1, 3, 4, 9):
+        params = np.column_stack([rng.uniform(0.01, 1, B), rng.uniform(400, 800, B),
+                                  10 ** rng.uniform(0, 2, B)])
+        for mask in (np.ones(nd, bool), rng.uniform(size=nd) < 0.5, np.zeros(nd, bool)):
+            got = sp.loglike_batch(params, mask)
+            assert got.shape == (B, mask.sum())
+            for b in range(B):
+                want = -0.5 * oracle.gauss_like(x, y, params[b, 0], params[b, 1], params[b, 2], 0.01, mask)
+                assert rel_err(got[b], want) < RTOL_L
+    # reference call signature (sample.py:101-108): params = (A, mu, log10 sig)
+    L = sp.multi_loglikelihood(np.array([0.5, 600., 1.0]), np.ones(nd, bool))
+    want = -0.5 * oracle.gauss_like(x, y, 0.5, 600., 10.0, 0.01, np.ones(nd, bool))
+    assert rel_err(L, want) < RTOL_L
+    sp.close()
+
+
+def test_k1_dataset_major_layout_and_row_ids(oracle):
+    from massivedatans_amd.like import GaussLineSpectra
+    d = gen.horns(300)
+    sp = GaussLineSpectra(d["x"], np.ascontiguousarray(d["y"].T), layout="dataset_major")
+    rows = np.array([7, 3, 299, 0, 3], dtype=np.int32)       # any order, repeats allowed
+    got = sp.loglike_batch(np.array([[0.2, 650., 5.0]]), rows)[0]
+    full = -0.5 * oracle.gauss_like(d["x"], d["y"], 0.2, 650., 5.0, 0.01, np.ones(300, bool))
+    assert rel_err(got, full[rows]) < RTOL_L
+
+
+def test_k1_full_size_properties():
+    """Config C2 size (10 000 x 200): size-independent properties instead of the oracle."""
+    from massivedatans_amd.like import GaussLineSpectra
+    d = gen.horns(10000)
+    sp = GaussLineSpectra(d["x"], d["y"])
+    rng = np.random.RandomState(5)
+    params = np.column_stack([rng.uniform(0.01, 1, 16), rng.uniform(400, 800, 16), 10 ** rng.uniform(0, 2, 16)])
+    full = sp.loglike_batch(params)
+    assert full.shape == (16, 10000) and np.all(np.isfinite(full)) and np.all(full <= 0)
+    # (1) batching is transparent: B candidates at once == one at a time (bitwise)
+    for b in (0, 7, 15):
+        assert np.array_equal(sp.loglike_batch(params[b:b + 1])[0], full[b])
+    # (2) masking is a gather of the full result (bitwise), for dense and sparse masks
+    for frac in (0.5, 0.01):
+        m = rng.uniform(size=10000) < frac
+        assert np.array_equal(sp.loglike_batch(params, m), full[:, m])
+    # (3) A -> 0 reproduces the closed-form null evidence of plotevidences.py:17
+    null = sp.loglike_batch(np.array([[0.0, 600., 5.0]]))[0]
+    want = (-0.5 * (d["y"] / 0.01) ** 2).sum(axis=0)
+    assert rel_err(null, want) < 1e-12
+    # (4) a spectrum scored against its own noiseless line: chi^2 is that of pure noise
+    i = 123
+    L = sp.loglike_batch(np.array([[d["height_narrow"][i], d["mean_narrow"][i], 5.0]]))[0][i]
+    assert -0.5 * 200 * 2.0 < L < -0.5 * 200 * 0.5
+
+
+# ---------------------------------------------------------------- K2 ----------------------
+def test_k2_dropin_matches_golden(hip, golden):
+    yy, vv = golden["k2_y"], golden["k2_v"]
+    nx, nd = yy.shape
+    for mi, m in enumerate(golden["k2_masks"]):
+        m = np.ascontiguousarray(m)
+        for yp, w in zip(golden["k2_ypred"], golden["k2_out%d" % mi]):
+            L = np.full(nd, 12345.0)
+            yp = np.ascontiguousarray(yp)
+            assert hip.mdns_muse_like(_lib.ptr(yy), _lib.ptr(vv), _lib.ptr(yp), _lib.ptr(m), nd, nx,
+                                      _lib.ptr(L)) == 0, hip.mdns_last_error()
+            assert np.all(L[~m] == 12345.0)                   # unmasked entries untouched
+            assert rel_err(L[m], w[m]) < 1e-11
+
+
+@pytest.mark.parametrize("nd,nx", [(5, 3), (17, 96), (9, 513), (6, 1500), (4, 4096), (3, 5000)])
+def test_k2_batch_vs_oracle(oracle, nd, nx):
+    from massivedatans_amd.like import MuseSpectra
+    cube = gen.muse_like(nd, nx=nx)
+    sp = MuseSpectra(cube["x"], cube["y"], cube["v"])
+    rng = np.random.RandomState(nx)
+    pars = np.column_stack([rng.uniform(-0.5, 0.5, 3), rng.uniform(0, 0.02, 3), rng.uniform(-0.1, 0.2, 3),
+                            rng.uniform(0.5, 1.5, 3), rng.uniform(0.5, 1.5, 3)])
+    ypred = np.array([gen.muse_template(cube["x"], p) for p in pars])
+    for mask in (np.ones(nd, bool), np.arange(nd) % 2 == 0):
+        got = sp.loglike_batch(ypred, mask)
+        got_dev = sp.loglike_batch_lines(pars, mask)          # template evaluated on the device
+        for b in range(3):
+            want = oracle.muse_like(cube["y"], cube["v"], np.ascontiguousarray(ypred[b]), mask)[mask]
+            assert rel_err(got[b], want) < 1e-11
+            assert rel_err(got_dev[b], want) < 1e-9
+    sp.close()
+
+
+# ---------------------------------------------------------------- K3-K6 -------------------
+def test_k3_k4_golden_bit_exact(hip, nb, golden):
+    for ndim in (3, 5):
+        t = "k3_d%d" % ndim
+        mem, cand, r = golden[t + "_members"], golden[t + "_cands"], float(golden[t + "_r"])
+        for cm in (0, 1, 3):
+            out = np.zeros(len(cand))
+            assert hip.mdns_count_within_distance_of(_lib.ptr(mem), len(mem), ndim, r, _lib.ptr(cand),
+                                                     len(cand), _lib.ptr(out), cm) == 0
+            assert np.array_equal(out, golden[t + "_count%d" % cm])
+        pre = golden[t + "_pre"].copy()
+        assert hip.mdns_count_within_distance_of(_lib.ptr(mem), len(mem), ndim, r, _lib.ptr(cand),
+                                                 len(cand), _lib.ptr(pre), 2) == 0
+        assert np.array_equal(pre, golden[t + "_count2_pre"])
+        got = np.array([nb.is_within_distance_of(mem, r, c) for c in cand[:40]])
+        assert np.array_equal(got, golden[t + "_any"])
+        assert np.array_equal(nb.count_within_distance_of(mem, r, cand), golden[t + "_count0"].astype(int))
+        assert np.array_equal(nb.any_within_distance_of(mem, r, cand), golden[t + "_count1"] > 0)
+    # strict comparison at distance exactly r
+    out = np.zeros(3)
+    assert hip.mdns_count_within_distance_of(_lib.ptr(golden["k3_edge_members"]), 1, 3,
+                                             float(golden["k3_edge_r"]), _lib.ptr(golden["k3_edge_cands"]),
+                                             3, _lib.ptr(out), 0) == 0
+    assert np.array_equal(out, golden["k3_edge_count0"])
+
+
+def test_k5_k6_golden_bit_exact(nb, golden):
+    for ndim in (3, 5, 2):
+        t = "k6_d%d" % ndim
+        pts = golden[t + "_pts"]
+        assert nb.most_distant_nearest_neighbor(pts) == float(golden[t + "_nn"])
+        for chosen, r in zip(golden[t + "_chosen"], golden[t + "_radius"]):
+            assert nb.bootstrapped_maxdistance_chosen(pts, chosen) == r
+    assert nb.bootstrapped_maxdistance_chosen(golden["k6_quirk_pts"], golden["k6_quirk_chosen"]) == \
+        float(golden["k6_quirk_radius"])
+
+
+def test_k6_rng_call_order(nb, oracle):
+    """bootstrapped_maxdistance draws its chosen matrix from the global legacy stream exactly as
+    clustering/neighbors.py:170-174 does."""
+    rng = np.random.RandomState(3)
+    pts = rng.uniform(size=(150, 3))
+    np.random.seed(11)
+    got = nb.find_rdistance(pts, nbootstraps=10)
+    after = np.random.uniform()
+    np.random.seed(11)
+    chosen = np.zeros((150, 10))
+    for b in range(10):
+        chosen[np.random.choice(np.arange(150), size=150, replace=True), b] = 1.
+    assert got == oracle.bootstrapped_maxdistance(pts, chosen)
+    assert after == np.random.uniform()
+
+
+@pytest.mark.parametrize("ndim", [1, 2, 3, 4, 5, 8, 11])
+def test_geometry_vs_oracle_sweep(nb, oracle, ndim):
+    rng = np.random.RandomState(100 + ndim)
+    for K, M in ((1, 5), (2, 1), (63, 300), (700, 1000), (1500, 257)):
+        pts = rng.uniform(size=(K, ndim))
+        cand = rng.uniform(-0.2, 1.2, size=(M, ndim))
+        cand[: min(M, K, 3)] = pts[: min(M, K, 3)]
+        r = 0.4 * ndim ** 0.5 * rng.uniform(0.2, 1.0)
+        assert np.array_equal(nb.count_within_distance_of(pts, r, cand),
+                              oracle.count_within_distance_of(pts, r, cand).astype(int))
+        assert np.array_equal(nb.any_within_distance_of(pts, r, cand),
+                              oracle.count_within_distance_of(pts, r, cand, countmax=1) > 0)
+        assert nb.most_distant_nearest_neighbor(pts) == oracle.most_distant_nearest_neighbor(pts)
+        for nboot in (1, 10, 19):
+            chosen = np.zeros((K, nboot))
+            for b in range(nboot):
+                chosen[rng.choice(np.arange(K), size=K, replace=True), b] = 1.
+            assert nb.bootstrapped_maxdistance_chosen(pts, chosen) == oracle.bootstrapped_maxdistance(pts, chosen)
+
+
+def test_geometry_full_size_properties(nb):
+    """K = 10 000 pool points (config C2 late-run size): properties that need no oracle."""
+    rng = np.random.RandomState(9)
+    pts = rng.uniform(size=(10000, 3))
+    cand = rng.uniform(size=(10000, 3))
+    r = 0.05
+    counts = nb.count_within_distance_of(pts, r, cand)
+    # counting is additive over a split of the members
+    a = nb.count_within_distance_of(pts[:3777], r, cand)
+    b = nb.count_within_distance_of(pts[3777:], r, cand)
+    assert np.array_equal(counts, a + b)
+    assert np.array_equal(nb.any_within_distance_of(pts, r, cand), counts > 0)
+    # members are within any positive radius of themselves; radius grows monotonically the count
+    assert np.all(nb.count_within_distance_of(pts, r, pts[:500]) >= 1)
+    assert np.all(nb.count_within_distance_of(pts, 2 * r, cand) >= counts)
+    # bootstrap radius: with everything chosen nothing is left out -> 0; K5 >= any K6 round of
+    # the full pool is not implied, but K6 is invariant under permuting the rounds
+    chosen = np.zeros((10000, 10))
+    for k in range(10):
+        chosen[rng.choice(np.arange(10000), size=10000, replace=True), k] = 1.
+    r6 = nb.bootstrapped_maxdistance_chosen(pts, chosen)
+    assert r6 == nb.bootstrapped_maxdistance_chosen(pts, np.ascontiguousarray(chosen[:, ::-1]))
+    assert nb.bootstrapped_maxdistance_chosen(pts, np.ones((10000, 3))) == 0.0
+    assert 0 < r6 < 1
