@@ -60,6 +60,7 @@ static int init_locked(int device)
 	}
 	if (g_ctx_ready) {       // switching device: drop per-device scratch
 		if (g_ctx.d_ws) (void) hipFree(g_ctx.d_ws);
+		if (g_ctx.d_mask) (void) hipFree(g_ctx.d_mask);
 		if (g_ctx.h_pin) (void) hipHostFree(g_ctx.h_pin);
 		if (g_ctx.own_stream) (void) hipStreamDestroy(g_ctx.own_stream);
 		g_ctx = Context();
@@ -99,6 +100,22 @@ void *device_scratch(size_t bytes)
 	if (!MDNS_HIP(hipMalloc(&c->d_ws, cap))) return nullptr;
 	c->d_ws_bytes = cap;
 	return c->d_ws;
+}
+
+void *mask_scratch(size_t bytes)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (bytes <= c->d_mask_bytes) return c->d_mask;
+	if (c->d_mask) {
+		(void) hipStreamSynchronize(c->stream);
+		(void) hipFree(c->d_mask);
+		c->d_mask = nullptr; c->d_mask_bytes = 0;
+	}
+	size_t cap = bytes + bytes / 2 + 4096;
+	if (!MDNS_HIP(hipMalloc(&c->d_mask, cap))) return nullptr;
+	c->d_mask_bytes = cap;
+	return c->d_mask;
 }
 
 void *pinned_scratch(size_t bytes)
@@ -315,7 +332,7 @@ static bool upload_rows(const double *h_src, int ndata, int nx, int layout, doub
 	if (!MDNS_HIP(hipMalloc((void **) &d_tmp, (n ? n : 1) * sizeof(double)))) return false;
 	bool ok = MDNS_HIP(hipMemcpyAsync(d_tmp, h_src, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
 	if (ok) {
-		if (layout == MDNS_LAYOUT_CHANNEL_MAJOR) ok = launch_transpose(d_tmp, nx, ndata, d_dst, ld, invert);
+		if (layout == MDNS_LAYOUT_CHANNEL_MAJOR) ok = launch_transpose(d_tmp, nx, ndata, d_dst, ld, invert, ndata);
 		else ok = launch_copy_rows(d_tmp, nx, ndata, d_dst, ld, invert);
 	}
 	ok = MDNS_HIP(hipStreamSynchronize(c->stream)) && ok;
@@ -339,6 +356,16 @@ extern "C" mdns_spectra *mdns_spectra_create(const double *x, const double *y, c
 	bool ok = MDNS_HIP(hipMalloc((void **) &s->d_y, elems * sizeof(double)));
 	ok = ok && MDNS_HIP(hipMemsetAsync(s->d_y, 0, elems * sizeof(double), c->stream));
 	ok = ok && upload_rows(y, ndata, nx, layout, s->d_y, s->ld, false);
+	if (ok && !v && nx > 0 && ndata > 0) {
+		// K1 also keeps a channel-major replica [nx][ldT] for dense candidate batches
+		s->ldT = ((ndata + 63) / 64) * 64;
+		const size_t telems = (size_t) cols_nx(nx) * s->ldT;
+		ok = MDNS_HIP(hipMalloc((void **) &s->d_yT, telems * sizeof(double)));
+		ok = ok && MDNS_HIP(hipMemsetAsync(s->d_yT, 0, telems * sizeof(double), c->stream));
+		// rows [ndata][ld] -> [nx][ldT] is the same re-lay with the roles of the axes swapped
+		ok = ok && launch_transpose(s->d_y, ndata, nx, s->d_yT, s->ldT, false, s->ld);
+		ok = ok && MDNS_HIP(hipStreamSynchronize(c->stream));
+	}
 	if (ok && v) {
 		ok = MDNS_HIP(hipMalloc((void **) &s->d_w, elems * sizeof(double)));
 		ok = ok && MDNS_HIP(hipMemsetAsync(s->d_w, 0, elems * sizeof(double), c->stream));
@@ -358,7 +385,7 @@ extern "C" void mdns_spectra_destroy(mdns_spectra *s)
 	if (!s) return;
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
-	void *bufs[] = {s->d_y, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out};
+	void *bufs[] = {s->d_y, s->d_yT, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	delete s;
 }
@@ -385,10 +412,27 @@ extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_par
 	if (!ctx() || !check_batch(s, B, M, "mdns_gauss_loglike_batch_dev")) return 1;
 	if (!s->d_x) { set_error("spectra were created without a wavelength grid"); return 1; }
 	if (B == 0 || M == 0) return 0;
+	const double scale = -0.5 / (noise_level * noise_level);
+	// Two kernels, chosen by shape only (never by data), so a run is reproducible:
+	//  * batches of 5+ candidates on dense selections (at least one spectrum in eight) are
+	//    arithmetic-bound: one LANE per spectrum on the channel-major replica, templates as
+	//    scalar operands (k_gauss_cols);
+	//  * 1-4 candidates, or sparse selections, are bandwidth/latency-bound: one WAVE per
+	//    spectrum row, reading exactly the selected rows once (k_gauss_rows).
+	// Measured crossover on MI355X, 10 000 x 200: rows 7/12/12/19 us at B = 1/2/4/8, cols ~17 us.
+	static const char *forced = getenv("MDNS_K1_PATH");      // "rows" | "cols": experiments only
+	bool use_cols = s->d_yT && B > 4 && (size_t) M * 8 >= (size_t) s->ndata;
+	if (forced && !strcmp(forced, "rows")) use_cols = false;
+	if (forced && !strcmp(forced, "cols") && s->d_yT) use_cols = true;
+	if (use_cols) {
+		const int bt = gauss_cols_tile(M, B);
+		if (!grow(&s->d_model, &s->model_cap, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
+		if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model)) return 1;
+		return launch_gauss_cols(s, s->d_model, bt, B, scale, d_row_ids, M, d_Lout) ? 0 : 1;
+	}
 	const int ldm = model_ld(s->nx);
 	if (!grow(&s->d_model, &s->model_cap, (size_t) B * ldm)) return 1;
 	if (!launch_gauss_model(s->d_x, s->nx, d_params, B, s->d_model, ldm)) return 1;
-	const double scale = -0.5 / (noise_level * noise_level);
 	return launch_gauss_rows(s, s->d_model, ldm, B, scale, d_row_ids, M, d_Lout) ? 0 : 1;
 }
 
@@ -591,8 +635,7 @@ extern "C" int mdns_count_within_dev(const double *d_members, int K, int ndim, d
 	if (!c) return 1;
 	if (K < 0 || M < 0 || ndim <= 0) { set_error("mdns_count_within_dev: bad sizes"); return 1; }
 	if (M == 0) return 0;
-	if (!MDNS_HIP(hipMemsetAsync(d_counts, 0, (size_t) M * sizeof(int), c->stream))) return 1;
-	if (K == 0) return 0;
+	if (K == 0) return MDNS_HIP(hipMemsetAsync(d_counts, 0, (size_t) M * sizeof(int), c->stream)) ? 0 : 1;
 	return launch_count_within(d_members, K, ndim, sqrt_threshold(maxdistance), d_cands, M, d_counts) ? 0 : 1;
 }
 

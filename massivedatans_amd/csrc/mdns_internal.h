@@ -21,6 +21,7 @@ struct Context {
 	// grow-only scratch: device workspace and pinned host staging
 	void *d_ws = nullptr;   size_t d_ws_bytes = 0;
 	void *h_pin = nullptr;  size_t h_pin_bytes = 0;
+	void *d_mask = nullptr; size_t d_mask_bytes = 0;
 };
 // nullptr (and mdns_last_error set) when no device can be initialised
 Context *ctx();
@@ -28,6 +29,7 @@ Context *ctx();
 // across a growing call.
 void *device_scratch(size_t bytes);
 void *pinned_scratch(size_t bytes);
+void *mask_scratch(size_t bytes);      // packed bootstrap masks (separate from device_scratch)
 
 // ---- resident spectra -------------------------------------------------------------------
 }  // namespace mdns
@@ -36,7 +38,9 @@ struct mdns_spectra {
 	int ndata = 0;      // number of spectra (rows)
 	int nx = 0;         // channels per spectrum
 	int ld = 0;         // row stride in doubles (nx rounded up to even => 16-byte aligned rows)
-	double *d_y = nullptr;   // [ndata, ld]
+	double *d_y = nullptr;   // [ndata, ld]   one spectrum per row
+	double *d_yT = nullptr;  // [nx, ldT]     channel-major replica (K1 dense scoring), or nullptr
+	int ldT = 0;             // ndata rounded up to a multiple of 64 (zero padded)
 	double *d_w = nullptr;   // [ndata, ld] inverse variances 1/v (K2), or nullptr
 	double *d_x = nullptr;   // [nx] wavelength grid, or nullptr
 	// per-handle grow-only device buffers for the host-pointer batch API
@@ -52,17 +56,31 @@ namespace mdns {
 // lane / thread of the row kernels can load its channel pair without a bounds test
 inline int model_ld(int nx) { return nx <= 0 ? 512 : ((nx + 511) / 512) * 512; }
 
+// channel count of the channel-major replica / transposed templates: padded (with zeros) to
+// the software-pipeline depth of k_gauss_cols
+inline int cols_nx(int nx) { return ((nx + 7) / 8) * 8; }
+// candidate stride of the transposed templates: multiple of 16 so every candidate tile is whole
+inline int model_ldb(int B) { return B <= 0 ? 16 : ((B + 15) / 16) * 16; }
+
 // launchers implemented in mdns_like.hip (all asynchronous on ctx()->stream)
 bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B,
                         double *d_model, int ldm);
+// candidates per wave of k_gauss_cols for M selected spectra and B candidates (1..16)
+int gauss_cols_tile(int M, int B);
+// tiled templates MT[ceil(B/bt)][cols_nx(nx)][bt], zero for b >= B and j >= nx
+bool launch_gauss_model_t(const double *d_x, int nx, const double *d_params, int B, int bt,
+                          double *d_model_t);
+bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, int B,
+                       double scale, const int *d_rows, int M, double *d_out);
 bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B,
                         double *d_model, int ldm);
 bool launch_gauss_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
                        double scale, const int *d_rows, int M, double *d_out);
 bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
                       const int *d_rows, int M, double *d_out);
+// src [nx][lds] -> dst [ndata][ld] (only the nx x ndata corner is touched)
 bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld,
-                      bool invert);
+                      bool invert, int lds);
 bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int ld,
                       bool invert);
 bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm);

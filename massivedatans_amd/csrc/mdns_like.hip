@@ -15,6 +15,7 @@
 //   y and 1/v stay in registers over both passes of cmuselike.c:50-61 (scale, then chi), so
 //   the reference's two strided passes become one HBM pass.
 #include "mdns_internal.h"
+#include <cstdlib>
 
 namespace mdns {
 
@@ -45,6 +46,26 @@ __global__ void k_gauss_model(const double *__restrict__ x, int nx, const double
 		m = A * exp(-0.5 * (t * t));
 	}
 	model[(size_t) b * ldm + j] = m;
+}
+
+// the same line in candidate tiles: MT[tile][j][BT] with tile = b / BT, zero for b >= B and
+// for the padding channels j >= nx (one thread per element).  A wave of k_gauss_cols walks one
+// tile front to back, so its template stream is contiguous.
+__global__ void k_gauss_model_t(const double *__restrict__ x, int nx, int nxp, const double *__restrict__ params,
+                                int B, int bt_size, int ntile, double *__restrict__ model_t)
+{
+	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	if (e >= ntile * nxp * bt_size) return;
+	const int bin = e % bt_size;
+	const int j = (e / bt_size) % nxp;
+	const int b = (e / (bt_size * nxp)) * bt_size + bin;
+	double m = 0.0;
+	if (b < B && j < nx) {
+		const double A = params[3 * b], mu = params[3 * b + 1], sig = params[3 * b + 2];
+		const double t = (mu - x[j]) / sig;
+		m = A * exp(-0.5 * (t * t));
+	}
+	model_t[e] = m;
 }
 
 // three lines on a flat continuum (config C5; massivedatans_amd/gen.py muse_template)
@@ -88,14 +109,14 @@ __global__ void k_pad_model(const double *__restrict__ src, int nx, double *__re
 
 // src [nx][ndata] (reference layout, sample.py:31 / clike.c:72) -> dst [ndata][ld]
 __global__ void k_transpose(const double *__restrict__ src, int nx, int ndata, double *__restrict__ dst,
-                            int ld, int invert)
+                            int ld, int invert, int lds)
 {
 	__shared__ double tile[32][33];
 	const int i0 = blockIdx.x * 32, j0 = blockIdx.y * 32;
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8
 	for (int jj = ty; jj < 32; jj += 8) {
 		const int j = j0 + jj, i = i0 + tx;
-		if (j < nx && i < ndata) tile[jj][tx] = src[(size_t) j * ndata + i];
+		if (j < nx && i < ndata) tile[jj][tx] = src[(size_t) j * lds + i];
 	}
 	__syncthreads();
 	for (int ii = ty; ii < 32; ii += 8) {
@@ -199,6 +220,84 @@ __global__ __launch_bounds__(kBlock) void k_gauss_rows(
 				if (b < B && k < M) out[(size_t) b * M + k] = mine * scale;
 			}
 		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------
+// K1, dense selections: one LANE per spectrum on the channel-major replica
+// ---------------------------------------------------------------------------------------
+// YT[nx][ldT]: lane i of a wave reads YT[j][tile*64 + i] -- 512 contiguous bytes per load and
+// no cross-lane reduction at all: every lane sums its own spectrum over the channels in
+// ascending order (the order of clike.c:64-76).  A wave scores BT candidates; their template
+// values MT[j][bt*BT .. +BT) are wave-uniform and arrive through the scalar cache as SGPR
+// operands, so the inner loop is exactly one v_add_f64 + one v_fma_f64 per (candidate,
+// channel, spectrum).  Work items are (spectrum tile, candidate tile) pairs, one per wave.
+template <int BT>
+__global__ __launch_bounds__(kBlock) void k_gauss_cols(
+    const double *__restrict__ YT, int ldT, int nxp, const double *__restrict__ model_t, int B,
+    double scale, const int *__restrict__ rows, int M, int ntiles, int nq_xcd, double *__restrict__ out)
+{
+	constexpr int CH = 8;                     // channels per software-pipeline stage (nxp % CH == 0)
+	const int lane = threadIdx.x & 63;
+	// Work item of a wave = (spectrum tile, candidate tile).  A workgroup takes 4 adjacent
+	// spectrum tiles (a "quad") of ONE candidate tile, so its waves pull the same template
+	// values through the scalar cache.  Workgroups are dealt round-robin over the 8 XCDs
+	// (blockIdx % 8 shares an XCD): quad q is always given to XCD q % 8, for every candidate
+	// tile, so each XCD re-reads only its own eighth of the spectra from its own L2.  This
+	// is a speed-only mapping; any placement gives the same results.
+	const int xcd = blockIdx.x & 7;
+	const int local = blockIdx.x >> 3;
+	const int bt = local / nq_xcd;
+	const int quad = (local % nq_xcd) * 8 + xcd;
+	const int tile = quad * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	if (tile >= ntiles) return;
+	const int k = tile * 64 + lane;           // position in the (compacted) output
+	int col = k;                              // column of YT (padded to ldT, so k >= M is readable)
+	if (rows) col = rows[k < M ? k : M - 1];
+	const double *ycol = YT + col;
+	const double *mt = model_t + (size_t) bt * nxp * BT;     // this wave's template tile [nxp][BT]
+
+	double acc[BT];
+#pragma unroll
+	for (int b = 0; b < BT; b++) acc[b] = 0.0;
+	// software pipeline over stages of CH channels: the next stage's spectra values are in
+	// flight while this one computes.  Both streams advance by pointer bumps so that the
+	// template loads keep small positive immediate offsets (no scalar address arithmetic).
+	double ycur[CH], ynext[CH];
+	const double *yp = ycol;                  // per lane
+	const double *mp = mt;                    // wave-uniform: CH*BT contiguous doubles per stage
+	const size_t ystep = (size_t) CH * ldT;
+#pragma unroll
+	for (int c = 0; c < CH; c++) ycur[c] = yp[(size_t) c * ldT];
+#pragma unroll 1
+	for (int st = nxp / CH - 1; st > 0; st--) {
+		yp += ystep;
+#pragma unroll
+		for (int c = 0; c < CH; c++) ynext[c] = yp[(size_t) c * ldT];
+#pragma unroll
+		for (int c = 0; c < CH; c++) {
+#pragma unroll
+			for (int b = 0; b < BT; b++) {
+				const double d = mp[c * BT + b] - ycur[c];
+				acc[b] = fma(d, d, acc[b]);
+			}
+		}
+		mp += CH * BT;
+#pragma unroll
+		for (int c = 0; c < CH; c++) ycur[c] = ynext[c];
+	}
+#pragma unroll
+	for (int c = 0; c < CH; c++) {
+#pragma unroll
+		for (int b = 0; b < BT; b++) {
+			const double d = mp[c * BT + b] - ycur[c];
+			acc[b] = fma(d, d, acc[b]);
+		}
+	}
+	if (k < M) {
+#pragma unroll
+		for (int b = 0; b < BT; b++)
+			if (bt * BT + b < B) out[(size_t) (bt * BT + b) * M + k] = acc[b] * scale;
 	}
 }
 
@@ -354,6 +453,54 @@ bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B
 	return launched("k_gauss_model");
 }
 
+int gauss_cols_tile(int M, int B)
+{
+	Context *c = ctx();
+	const int ntiles = (M + 63) / 64;
+	// candidates per wave: the largest tile that still leaves about five waves per SIMD
+	// (measured on MI355X, 10 000 spectra: B=64 -> 4, B=256 -> 8, B=1024 -> 16), at least 4
+	int bt = 16;
+	while (bt > 4 && (long long) ntiles * ((B + bt - 1) / bt) < 20LL * c->num_cus) bt >>= 1;
+	while (bt > B && bt > 1) bt >>= 1;
+	static const char *forced_bt = getenv("MDNS_K1_BT");      // experiments only
+	if (forced_bt) { const int f = atoi(forced_bt); if (f == 1 || f == 2 || f == 4 || f == 8 || f == 16) bt = f; }
+	return bt;
+}
+
+bool launch_gauss_model_t(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t)
+{
+	Context *c = ctx();
+	const int nxp = cols_nx(nx);
+	const int ntile = (B + bt - 1) / bt;
+	const int n = ntile * nxp * bt;
+	hipLaunchKernelGGL(k_gauss_model_t, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+	                   d_x, nx, nxp, d_params, B, bt, ntile, d_model_t);
+	return launched("k_gauss_model_t");
+}
+
+bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, int B, double scale,
+                       const int *d_rows, int M, double *d_out)
+{
+	Context *c = ctx();
+	const int ntiles = (M + 63) / 64;
+	const int nbt = (B + bt - 1) / bt;
+	const int nquads = (ntiles + 3) / 4;
+	const int nq_xcd = (nquads + 7) / 8;                      // quads per XCD (some may be empty)
+	const int blocks = 8 * nq_xcd * nbt;
+	ProfileScope prof(0);
+#define COLS_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols<BT>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+	s->d_yT, s->ldT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, d_out)
+	switch (bt) {
+	case 16: COLS_LAUNCH(16); break;
+	case 8: COLS_LAUNCH(8); break;
+	case 4: COLS_LAUNCH(4); break;
+	case 2: COLS_LAUNCH(2); break;
+	default: COLS_LAUNCH(1); break;
+	}
+#undef COLS_LAUNCH
+	return launched("k_gauss_cols");
+}
+
 bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B, double *d_model, int ldm)
 {
 	Context *c = ctx();
@@ -370,12 +517,12 @@ bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm
 	return launched("k_pad_model");
 }
 
-bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld, bool invert)
+bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld, bool invert, int lds)
 {
 	Context *c = ctx();
 	if (nx == 0 || ndata == 0) return true;
 	dim3 grid((ndata + 31) / 32, (nx + 31) / 32);
-	hipLaunchKernelGGL(k_transpose, grid, dim3(kBlock), 0, c->stream, d_src, nx, ndata, d_dst, ld, invert ? 1 : 0);
+	hipLaunchKernelGGL(k_transpose, grid, dim3(kBlock), 0, c->stream, d_src, nx, ndata, d_dst, ld, invert ? 1 : 0, lds);
 	return launched("k_transpose");
 }
 
