@@ -1,0 +1,223 @@
+"""MLFriends constrained draws: RadFriends region in a learned axis-scaling metric.
+
+Host-side mirror of the reference's ``hiermetriclearn.py:27-211``
+(``MetricLearningFriendsConstrainer``): same constructor arguments, rebuild policy, RNG call
+order and ``draw_constrained(Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kw)
+-> (u, x, L, n_evals)`` contract.  Differences, none of which change the sequence of results:
+
+* Candidates are handed out from an explicit buffer instead of a nested Python generator, so
+  that the candidates ALREADY proposed (and only those -- no RNG is consumed early) can be
+  scored on the GPU in one batch (``loglikelihood_batch`` keyword).  Likelihood values of
+  look-ahead candidates are cached until the candidates are consumed.
+* ``float > None`` (hiermetriclearn.py:53 on the first build) follows Python 2, where the
+  reference was written: the comparison is true, so the first build computes the radius twice
+  (SURVEY.md appendix A#1).
+"""
+import logging
+
+import numpy
+
+from .clustering.radfriendsregion import RadFriendsRegion
+from .clustering.sdml import IdentityMetric, SimpleScaling, TruncatedScaling
+
+log = logging.getLogger("massivedatans_amd")
+
+
+class MetricLearningFriendsConstrainer(object):
+    #: proposals requested from the region per refill (hiermetriclearn.py:106)
+    REGION_BATCH = 10000
+    #: probability of an extra unit-cube proposal round after each region refill (:126)
+    CUBE_PROBABILITY = 0.1
+    #: most candidates scored ahead of need in one likelihood launch
+    MAX_LOOKAHEAD = 64
+
+    def __init__(self, metriclearner, rebuild_every=50, metric_rebuild_every=50, verbose=False,
+                 keep_phantom_points=False, optimize_phantom_points=False, force_shrink=False):
+        self.metriclearner = metriclearner
+        self.rebuild_every = int(rebuild_every)
+        self.metric_rebuild_every = int(metric_rebuild_every)
+        self.verbose = verbose
+        self.force_shrink = force_shrink
+        self.metric = IdentityMetric()
+        self.region = None
+        self.prev_maxdistance = None
+        self.last_cluster_points = None
+        self.iter_since_metric_rebuild = 0
+        self.ndraws_since_rebuild = 0
+        self.direct_draws_efficient = True
+        self.clusters = None
+        self.generator = None
+        self._reset_buffer()
+        #: number of (candidate, data set) likelihood evaluations requested, incl. look-ahead
+        self.nevals_requested = 0
+
+    # ---- region construction ------------------------------------------------------------
+    def _fit_metric(self, u):
+        """New metric from the live points shifted to their mean (hiermetriclearn.py:63-80);
+        returns (metric, whether it differs from the current one)."""
+        shifted = u - numpy.mean(u, axis=0)
+        if self.metriclearner == 'none':
+            return self.metric, False
+        if self.metriclearner == 'simplescaling':
+            metric = SimpleScaling()
+            metric.fit(shifted)
+            return metric, True
+        if self.metriclearner == 'truncatedscaling':
+            metric = TruncatedScaling()
+            metric.fit(shifted)
+            changed = self.metric == IdentityMetric() or not numpy.all(self.metric.scale == metric.scale)
+            return metric, changed
+        raise AssertionError(self.metriclearner)
+
+    def cluster(self, u, ndim, keepMetric=False):
+        w = self.metric.transform(u)
+        if keepMetric:
+            self.region = RadFriendsRegion(members=w)
+            # Python-2 ordering: any float compares greater than None
+            grew = self.prev_maxdistance is None or self.region.maxdistance > self.prev_maxdistance
+            if self.force_shrink and grew:
+                self.region = RadFriendsRegion(members=w, maxdistance=self.prev_maxdistance)
+            self.prev_maxdistance = self.region.maxdistance
+            return
+        metric, metric_updated = self._fit_metric(u)
+        self.metric = metric
+        wnew = self.metric.transform(u)
+        self.region = RadFriendsRegion(members=wnew)
+        if not metric_updated and self.force_shrink and self.prev_maxdistance is not None:
+            if self.region.maxdistance > self.prev_maxdistance:
+                # same metric as before (w == wnew): never let the radius grow back
+                self.region = RadFriendsRegion(members=w, maxdistance=self.prev_maxdistance)
+        self.prev_maxdistance = self.region.maxdistance
+
+    def are_inside_cluster(self, points):
+        return self.region.are_inside(self.metric.transform(points))
+
+    def is_inside(self, point):
+        if not ((point >= 0).all() and (point <= 1).all()):
+            return False
+        return self.region.is_inside(self.metric.transform(point))
+
+    def rebuild(self, u, ndim, keepMetric=False):
+        same = (self.last_cluster_points is not None and len(self.last_cluster_points) == len(u)
+                and numpy.all(self.last_cluster_points == u))
+        if same:
+            return                                  # identical live points: keep region AND generator
+        self.cluster(u=u, ndim=ndim, keepMetric=keepMetric)
+        self.last_cluster_points = u
+        log.debug('maxdistance: %s', self.region.maxdistance)
+        self.generator = self.generate(ndim)
+        self._reset_buffer()
+
+    # ---- candidate stream ---------------------------------------------------------------
+    def generate(self, ndim):
+        """Yield ``(us, ntotal)``: arrays of unit-cube candidates inside the region and the
+        number of raw proposals behind the FIRST of them (hiermetriclearn.py:104-137)."""
+        ntotal = 0
+        N = self.REGION_BATCH
+        while True:
+            if ndim < 40:
+                for ws, n in self.region.generate(N):
+                    us = self.metric.untransform(ws)
+                    assert us.shape[1] == ndim, us.shape
+                    ntotal = ntotal + n
+                    inside_cube = numpy.logical_and(us < 1, us > 0).all(axis=1)
+                    if inside_cube.any():
+                        yield us[inside_cube, :], ntotal
+                        ntotal = 0
+            if numpy.random.uniform() < self.CUBE_PROBABILITY:
+                # occasionally propose from the whole unit cube (efficient while the region is big)
+                ntotal = ntotal + N
+                us = numpy.random.uniform(size=(N, ndim))
+                inside = self.region.are_inside(self.metric.transform(us))
+                if inside.any():
+                    yield us[inside, :], ntotal
+                    ntotal = 0
+
+    def _reset_buffer(self):
+        self._buf = None          # candidates already proposed, not yet consumed
+        self._buf_pos = 0
+        self._buf_ntotal = 0
+        self._ahead_L = None      # likelihoods of _buf[_ahead_lo : _ahead_lo + len(_ahead_L)]
+        self._ahead_lo = 0
+        self._ahead_key = None
+
+    def _next_candidate(self):
+        """Next candidate and the proposal count the reference's generator would report with it
+        (the batch total for the first candidate of a batch, 0 for the others)."""
+        if self._buf is None or self._buf_pos >= len(self._buf):
+            self._buf, self._buf_ntotal = next(self.generator)      # consumes RNG, exactly on demand
+            self._buf_pos = 0
+            self._ahead_L = None
+        u = self._buf[self._buf_pos]
+        ntotal = self._buf_ntotal if self._buf_pos == 0 else 0
+        self._buf_pos += 1
+        return u, ntotal
+
+    def _score(self, u, priortransform, loglikelihood, loglikelihood_batch, mask_key, lookahead):
+        """Likelihood vector of candidate ``u`` (= ``_buf[_buf_pos - 1]``), scoring up to
+        ``lookahead`` further buffered candidates in the same launch when a batch scorer is
+        available."""
+        pos = self._buf_pos - 1
+        if self._ahead_L is not None and self._ahead_key == mask_key and \
+                self._ahead_lo <= pos < self._ahead_lo + len(self._ahead_L):
+            return priortransform(u), self._ahead_L[pos - self._ahead_lo]
+        x = priortransform(u)
+        if loglikelihood_batch is None or lookahead <= 1 or pos + 1 >= len(self._buf):
+            self._ahead_L = None
+            L = loglikelihood(x)
+            self.nevals_requested += len(L)
+            return x, L
+        stop = min(len(self._buf), pos + lookahead)
+        xs = numpy.array([priortransform(v) for v in self._buf[pos:stop]])
+        Ls = loglikelihood_batch(xs)
+        self.nevals_requested += Ls.size
+        self._ahead_L, self._ahead_lo, self._ahead_key = Ls, pos, mask_key
+        return x, Ls[0]
+
+    # ---- the draw -----------------------------------------------------------------------
+    def _draw_constrained_prepare(self, Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs):
+        rebuild = self.ndraws_since_rebuild > self.rebuild_every or self.region is None
+        rebuild_metric = self.iter_since_metric_rebuild > self.metric_rebuild_every
+        if rebuild:
+            self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=not rebuild_metric)
+            self.ndraws_since_rebuild = 0
+            if rebuild_metric:
+                self.iter_since_metric_rebuild = 0
+        else:
+            rebuild_metric = False
+        assert self.generator is not None
+        return rebuild, rebuild_metric
+
+    def draw_constrained(self, Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs):
+        """Propose until a candidate beats the threshold of at least one data set
+        (hiermetriclearn.py:173-211).  Returns ``(u, x, L, n_likelihood_calls)``."""
+        loglikelihood_batch = kwargs.get('loglikelihood_batch')
+        mask_key = kwargs.get('mask_key')
+        ntoaccept = 0
+        self.iter_since_metric_rebuild += 1
+        rebuild, rebuild_metric = self._draw_constrained_prepare(
+            Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs)
+        lookahead = min(self.MAX_LOOKAHEAD, max(1, getattr(self, '_last_ntoaccept', 1)))
+        while True:
+            u, ntotal = self._next_candidate()
+            assert (u >= 0).all() and (u <= 1).all(), u
+            x, L = self._score(u, priortransform, loglikelihood, loglikelihood_batch, mask_key, lookahead)
+            ntoaccept += 1
+            self.ndraws_since_rebuild += 1
+            if ntotal > 100000:
+                self.direct_draws_efficient = False
+            if numpy.any(L > Lmins):
+                self._last_ntoaccept = ntoaccept
+                return u, x, L, ntoaccept
+            lookahead = min(self.MAX_LOOKAHEAD, max(lookahead, 2 * ntoaccept))
+            # a long unsuccessful streak: tighten the region (at most once per draw, each)
+            if not rebuild and self.ndraws_since_rebuild > self.rebuild_every:
+                rebuild = True
+                self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=True)
+                self.ndraws_since_rebuild = 0
+                continue
+            if not rebuild_metric and ntoaccept > 200:
+                rebuild_metric = True
+                self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=False)
+                self.iter_since_metric_rebuild = 0
+                continue

@@ -1,0 +1,147 @@
+"""The toy problem of the reference's ``sample.py`` -- one Gaussian emission line fitted to N
+spectra at once -- wired to the MI355X hot path.
+
+Problem definition surface kept from the reference (sample.py:44-108):
+``params``, ``nparams``, ``noise_level``, ``priortransform(cube)``,
+``multi_loglikelihood(params, data_mask)``; then the same wiring of constrainers, sampler and
+integrator (sample.py:131-197) and the same outputs (sample.py:200-217; ``.npz`` instead of
+HDF5 because h5py is not available here -- dataset names are kept).
+
+    python -m massivedatans_amd.sample data_widths_100.npz 100
+
+Environment knobs as in the reference: NLIVE_POINTS (400), SUPERSET_DRAWS (10), USE_GRAPH (1),
+MAXSAMPLES, MINSAMPLES.  CONSTRAINER must be MLFRIENDS (the other two draw methods live in
+third-party ``nestle`` and are outside the accelerated path).
+"""
+import json
+import logging
+import os
+import sys
+import time
+
+import numpy
+
+from . import cachedconstrainer
+from .cachedconstrainer import CachedConstrainer, generate_individual_constrainer
+from .multi_nested_integrator import multi_nested_integrator
+from .multi_nested_sampler import MultiNestedSampler
+
+noise_level = 0.01                    # sample.py:45
+params = ['A', 'mu', 'sig']           # sample.py:46
+nparams = len(params)
+
+
+def priortransform(cube):
+    """Unit cube -> (A, mu, log10 sig): A log-uniform in [0.01, 1], mu in [400, 800],
+    log10 sig in [0, 2] (sample.py:52-58)."""
+    cube = cube.copy()
+    cube[0] = 10 ** (cube[0] * 2 - 2)
+    cube[1] = cube[1] * 400 + 400
+    cube[2] = cube[2] * 2
+    return cube
+
+
+class GaussLineProblem(object):
+    """``multi_loglikelihood`` of sample.py:101-108 on the GPU.  ``x`` f64[nx], ``y`` f64[nx, ndata]
+    (the reference's layout).  ``backend`` may be any object with
+    ``loglike_batch(params[B,3], data_mask) -> L[B, M]`` (tests inject the CPU oracle there);
+    by default it is :class:`massivedatans_amd.like.GaussLineSpectra`."""
+
+    def __init__(self, x, y, backend=None):
+        self.x = numpy.ascontiguousarray(x, dtype=float)
+        self.y = numpy.ascontiguousarray(y, dtype=float)
+        self.nx, self.ndata = self.y.shape
+        if backend is None:
+            from .like import GaussLineSpectra
+            backend = GaussLineSpectra(self.x, self.y, noise_level=noise_level)
+        self.backend = backend
+        self.ncalls = 0
+        self.nevals = 0
+
+    def multi_loglikelihood(self, params, data_mask):
+        A, mu, log_sig_kms = params
+        sig = 10 ** log_sig_kms
+        L = self.backend.loglike_batch(numpy.array([[A, mu, sig]]), data_mask)[0]
+        self.ncalls += 1
+        self.nevals += len(L)
+        return L
+
+    def multi_loglikelihood_batch(self, params, data_mask):
+        """Rows of ``params`` are (A, mu, log10 sig) after priortransform."""
+        p = numpy.array(params, dtype=float)
+        # scalar pow per row: numpy's vectorised power may differ from the scalar one (which
+        # sample.py:103 uses) in the last bit
+        p[:, 2] = [10 ** v for v in p[:, 2]]
+        L = self.backend.loglike_batch(p, data_mask)
+        self.ncalls += 1
+        self.nevals += L.size
+        return L
+
+
+def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False, seed=1, batched=True):
+    """Constrainers + sampler wired as sample.py:131-194 (CONSTRAINER=MLFRIENDS)."""
+    cachedconstrainer.generate_fresh_constrainer = cachedconstrainer.generate_fresh_constrainer_mlfriends
+    superset_constrainer = cachedconstrainer.generate_fresh_constrainer_mlfriends()
+    cc = CachedConstrainer()
+    _, _, individual_draw_constrained = generate_individual_constrainer()
+    numpy.random.seed(seed)                                      # sample.py:162
+    sampler = MultiNestedSampler(
+        nlive_points=nlive_points, priortransform=priortransform,
+        multi_loglikelihood=problem.multi_loglikelihood, ndim=nparams, ndata=problem.ndata,
+        superset_draw_constrained=superset_constrainer.draw_constrained,
+        individual_draw_constrained=individual_draw_constrained,
+        draw_constrained=cc.get, nsuperset_draws=nsuperset_draws, use_graph=use_graph,
+        multi_loglikelihood_batch=problem.multi_loglikelihood_batch if batched else None)
+    superset_constrainer.sampler = sampler
+    cc.sampler = sampler
+    return sampler
+
+
+def run(x, y, nlive_points=400, nsuperset_draws=10, use_graph=False, max_samples=0, min_samples=0,
+        tolerance=0.5, seed=1, backend=None, batched=True):
+    """The whole analysis; returns ``(results, sampler, problem, duration)``."""
+    problem = GaussLineProblem(x, y, backend=backend)
+    start = time.time()
+    sampler = build_sampler(problem, nlive_points, nsuperset_draws, use_graph, seed, batched)
+    results = multi_nested_integrator(tolerance=tolerance, multi_sampler=sampler,
+                                      min_samples=min_samples, max_samples=max_samples)
+    return results, sampler, problem, time.time() - start
+
+
+def save_results(prefix, results, sampler, duration, ndata):
+    """Outputs of sample.py:200-217 (same dataset names; .npz container)."""
+    u, x, L, w, mask = list(zip(*results['weights']))
+    numpy.savez_compressed(prefix + '.npz', logZ=results['logZ'], logZerr=results['logZerr'],
+                           u=numpy.array(u), x=numpy.array(x), L=numpy.array(L), w=numpy.array(w),
+                           mask=numpy.array(mask), ndraws=sampler.ndraws)
+    with open(prefix + '.stats.json', 'w') as f:
+        json.dump(dict(ndraws=int(sampler.ndraws), duration=duration, ndata=int(ndata), niter=len(w),
+                       nevals=int(sampler.nevals)), f, indent=4)
+
+
+def main(argv=None):
+    argv = sys.argv if argv is None else argv
+    if len(argv) < 3:
+        sys.exit("usage: python -m massivedatans_amd.sample <data.npz> <ndata>")
+    logging.basicConfig(level=os.environ.get('MDNS_LOG', 'WARNING'))
+    from . import gen
+    ndata = int(argv[2])
+    data = gen.load(argv[1], ndata)
+    constrainer_type = os.environ.get('CONSTRAINER', 'MLFRIENDS')
+    if constrainer_type != 'MLFRIENDS':
+        sys.exit("CONSTRAINER=%s is not available: only MLFRIENDS runs on the accelerated path" % constrainer_type)
+    nlive_points = int(os.environ.get('NLIVE_POINTS', '400'))
+    results, sampler, problem, duration = run(
+        data['x'], data['y'], nlive_points=nlive_points,
+        nsuperset_draws=int(os.environ.get('SUPERSET_DRAWS', '10')),
+        use_graph=os.environ.get('USE_GRAPH', '1') == '1',
+        max_samples=int(os.environ.get('MAXSAMPLES', 0)), min_samples=int(os.environ.get('MINSAMPLES', 0)))
+    prefix = '%s_%s_nlive%d_%d.out8' % (argv[1], constrainer_type, nlive_points, ndata)
+    save_results(prefix, results, sampler, duration, ndata)
+    print('logZ = %.1f +- %.1f' % (results['logZ'][0], results['logZerr'][0]))
+    print('ndraws:', sampler.ndraws, 'niter:', len(results['weights']), 'likelihood evals:', sampler.nevals,
+          'in %.1f s' % duration)
+
+
+if __name__ == '__main__':
+    main()

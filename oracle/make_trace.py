@@ -1,0 +1,191 @@
+"""Golden ORCHESTRATION traces from the reference's own Python + C.  TEST INFRASTRUCTURE.
+
+Imports the reference from /root/reference (build container only) and runs its full pipeline
+-- MultiNestedSampler + multi_nested_integrator + MLFriends constrainers + compiled
+clike.so / cneighbors.so -- on gensimple_horns inputs, recording what every iteration returns.
+Only DATA is written (tests/golden/trace_*.npz); nothing of the reference is copied.
+
+How the reference is made importable without touching it:
+  * a staging directory in /tmp holds SYMLINKS to the reference's .py files, with the compiled
+    cneighbors.so (from oracle/_ref) beside clustering/neighbors.py, where that module looks
+    for it (neighbors.py:98);
+  * three import stubs in /tmp stand in for packages absent from this image and unused on
+    this path: progressbar (UI), igraph (only with use_graph=True), nestle (other draw methods);
+  * sample.py itself cannot be imported (h5py, runs at import): its wiring (sample.py:44-58,
+    101-108, 131-197) is restated below;
+  * Python-2 semantics of ``float > None`` (hiermetriclearn.py:53) are
+    supplied by a subclass, not by editing the reference.
+
+    python oracle/make_trace.py
+"""
+import contextlib
+import io
+import os
+import shutil
+import sys
+import time
+
+import numpy
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+REF = os.environ.get("MDNS_REFERENCE", "/root/reference")
+STAGE = "/tmp/mdns_ref_stage"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+os.environ.setdefault("MPLBACKEND", "Agg")
+
+from massivedatans_amd import gen  # noqa: E402
+from oracle.oracle import Oracle, have_reference  # noqa: E402
+
+STUBS = {
+    "progressbar.py": "class _W(object):\n    def __init__(self, *a, **k):\n        pass\n"
+                      "    def update(self, *a, **k):\n        pass\n    def start(self):\n        return self\n"
+                      "    def finish(self):\n        pass\n"
+                      "Timer = Bar = Percentage = ETA = Widget = ProgressBar = _W\n",
+    "igraph.py": "class Graph(object):\n    def __init__(self, *a, **k):\n        raise RuntimeError('igraph stub')\n",
+    "nestle.py": "def bounding_ellipsoid(*a, **k):\n    raise RuntimeError('nestle stub')\n"
+                 "bounding_ellipsoids = sample_ellipsoids = bounding_ellipsoid\n",
+}
+
+
+def stage_reference():
+    if os.path.isdir(STAGE):
+        shutil.rmtree(STAGE)
+    os.makedirs(os.path.join(STAGE, "pkg", "clustering"))
+    os.makedirs(os.path.join(STAGE, "stubs"))
+    for name in ("hiermetriclearn.py", "cachedconstrainer.py", "multi_nested_sampler.py",
+                 "multi_nested_integrator.py", "adaptive_progress.py", "elldrawer.py"):
+        os.symlink(os.path.join(REF, name), os.path.join(STAGE, "pkg", name))
+    for name in ("__init__.py", "neighbors.py", "radfriendsregion.py", "sdml.py"):
+        os.symlink(os.path.join(REF, "clustering", name), os.path.join(STAGE, "pkg", "clustering", name))
+    shutil.copy(os.path.join(HERE, "_ref", "cneighbors.so"), os.path.join(STAGE, "pkg", "clustering"))
+    for name, text in STUBS.items():
+        with open(os.path.join(STAGE, "stubs", name), "w") as f:
+            f.write(text)
+    sys.path.insert(0, os.path.join(STAGE, "stubs"))
+    sys.path.insert(0, os.path.join(STAGE, "pkg"))
+
+
+class Recorder(object):
+    """Iterator proxy: forwards everything to the sampler and keeps what next() returned."""
+
+    def __init__(self, sampler):
+        self.__dict__["_s"] = sampler
+        self.__dict__["Ls"] = []
+        self.__dict__["us"] = []
+        self.__dict__["ndraws_after"] = []
+
+    def __getattr__(self, name):
+        return getattr(self._s, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._s, name, value)
+
+    def __next__(self):
+        u, x, L = next(self._s)
+        self.Ls.append(numpy.array(L))
+        self.us.append(numpy.array(u))
+        self.ndraws_after.append(int(self._s.ndraws))
+        return u, x, L
+
+    next = __next__
+
+
+def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horns"):
+    import cachedconstrainer
+    import hiermetriclearn
+    from clustering.radfriendsregion import RadFriendsRegion
+    from multi_nested_integrator import multi_nested_integrator
+    from multi_nested_sampler import MultiNestedSampler
+
+    class Py2Constrainer(hiermetriclearn.MetricLearningFriendsConstrainer):
+        """hiermetriclearn.py:53 compares a float with None on the first build; under Python 2
+        (the reference's language) that is True, so the region is built a second time with
+        maxdistance=None.  Python 3 raises TypeError there; this subclass supplies the
+        Python-2 outcome for exactly that case and defers to the reference otherwise."""
+
+        def cluster(self, u, ndim, keepMetric=False):
+            if keepMetric and self.prev_maxdistance is None:
+                w = self.metric.transform(u)
+                self.region = RadFriendsRegion(members=w)
+                if self.force_shrink:
+                    self.region = RadFriendsRegion(members=w, maxdistance=None)
+                self.prev_maxdistance = self.region.maxdistance
+                return
+            return hiermetriclearn.MetricLearningFriendsConstrainer.cluster(self, u, ndim, keepMetric=keepMetric)
+
+    def fresh():                                       # sample.py:133-137
+        return Py2Constrainer(metriclearner='truncatedscaling', force_shrink=True, rebuild_every=1000,
+                              metric_rebuild_every=20, verbose=False)
+
+    data = (gen.horns if generator == "horns" else gen.nothing)(ndata)
+    x, y = data["x"], data["y"]
+    ref = Oracle("reference")
+    noise_level = 0.01
+
+    def priortransform(cube):                          # sample.py:52-58
+        cube = cube.copy()
+        cube[0] = 10 ** (cube[0] * 2 - 2)
+        cube[1] = cube[1] * 400 + 400
+        cube[2] = cube[2] * 2
+        return cube
+
+    def multi_loglikelihood(params, data_mask):        # sample.py:101-108
+        A, mu, log_sig_kms = params
+        sig = 10 ** log_sig_kms
+        Lout = numpy.zeros(data_mask.sum())
+        ref.gauss_like(x, y, A, mu, sig, noise_level, data_mask, Lout=Lout)
+        return -0.5 * Lout
+
+    cachedconstrainer.generate_fresh_constrainer = fresh            # sample.py:157
+    superset_constrainer = fresh()
+    cc = cachedconstrainer.CachedConstrainer()
+    _, _, individual_draw_constrained = cachedconstrainer.generate_individual_constrainer()
+    numpy.random.seed(1)                                            # sample.py:162
+    sampler = MultiNestedSampler(
+        nlive_points=nlive, priortransform=priortransform, multi_loglikelihood=multi_loglikelihood,
+        ndim=3, ndata=ndata, superset_draw_constrained=superset_constrainer.draw_constrained,
+        individual_draw_constrained=individual_draw_constrained, draw_constrained=cc.get,
+        nsuperset_draws=nsuperset_draws, use_graph=False)
+    superset_constrainer.sampler = sampler
+    cc.sampler = sampler
+    rec = Recorder(sampler)
+    results = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0, max_samples=max_samples)
+    rng_probe = numpy.random.uniform()
+    return dict(
+        ndata=ndata, nlive=nlive, max_samples=max_samples, nsuperset_draws=nsuperset_draws,
+        logZ=results["logZ"], logZerr=results["logZerr"], information=results["information"],
+        ndraws=sampler.ndraws, nweights=len(results["weights"]),
+        iter_nrunning=numpy.array([len(L) for L in rec.Ls]),
+        iter_L=numpy.concatenate(rec.Ls), iter_u=numpy.concatenate(rec.us),
+        iter_ndraws=numpy.array(rec.ndraws_after),
+        final_live_pointsp=sampler.live_pointsp, final_live_pointsL=sampler.live_pointsL,
+        npoints=len(sampler.pointpile), rng_probe=rng_probe)
+
+
+CASES = {
+    # name: (ndata, nlive, max_samples, nsuperset_draws, generator)
+    "nothing4": (4, 40, 1500, 3, "nothing"),      # terminates by tolerance (no signal: broad posterior)
+    "horns3": (3, 30, 1500, 10, "horns"),         # terminates by tolerance
+    "horns6": (6, 20, 300, 10, "horns"),          # capped; acceptance falls to ~1e-3 (242k draws)
+    "horns12": (12, 24, 260, 10, "horns"),        # capped; focussed draws on many groups
+}
+
+
+def main():
+    assert have_reference(), "oracle/_ref missing"
+    stage_reference()
+    for name, (ndata, nlive, max_samples, nsd, generator) in CASES.items():
+        t0 = time.time()
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = run_reference(ndata, nlive, max_samples, nsd, generator)
+        path = os.path.join(ROOT, "tests", "golden", "trace_%s.npz" % name)
+        numpy.savez_compressed(path, **out)
+        print("%s: %d iterations, running %s, ndraws %d, logZ[0] %.6f, %.1f s, %d bytes"
+              % (name, len(out["iter_nrunning"]), sorted(set(out["iter_nrunning"].tolist())), out["ndraws"],
+                 out["logZ"][0], time.time() - t0, os.path.getsize(path)))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,47 @@
+"""Test helper: the CPU oracle dressed as the product's backends, so that the HOST
+orchestration can be exercised (and pinned against reference traces) without a GPU.
+Tests only -- the product never imports this."""
+import numpy as np
+
+from massivedatans_amd.clustering import neighbors
+
+
+class OracleSpectra(object):
+    """Same ``loglike_batch(params[B,3], data_mask) -> L[B, M]`` as like.GaussLineSpectra."""
+
+    def __init__(self, oracle, x, y, noise_level=0.01):
+        self.o, self.x, self.y, self.noise = oracle, np.ascontiguousarray(x), np.ascontiguousarray(y), noise_level
+        self.ndata = self.y.shape[1]
+
+    def loglike_batch(self, params, data_mask=None):
+        params = np.atleast_2d(params)
+        if data_mask is None:
+            data_mask = np.ones(self.ndata, dtype=bool)
+        data_mask = np.ascontiguousarray(data_mask, dtype=np.bool_)
+        return np.array([-0.5 * self.o.gauss_like(self.x, self.y, p[0], p[1], p[2], self.noise, data_mask)
+                         for p in params]).reshape(len(params), int(data_mask.sum()))
+
+
+def patch_neighbors(monkeypatch, oracle):
+    """Route massivedatans_amd.clustering.neighbors to the oracle (keeps the module's own RNG
+    handling: draw_bootstrap_choice / bootstrapped_maxdistance / find_rdistance)."""
+    def count(xx, r, yy):
+        return oracle.count_within_distance_of(np.ascontiguousarray(xx), float(r), np.ascontiguousarray(yy)).astype(int)
+
+    def anyw(xx, r, yy):
+        return oracle.count_within_distance_of(np.ascontiguousarray(xx), float(r), np.ascontiguousarray(yy), countmax=1) > 0
+
+    def within(xx, r, y):
+        return oracle.is_within_distance_of(np.ascontiguousarray(xx), float(r), np.ascontiguousarray(y))
+
+    def boot(xx, chosen):
+        return oracle.bootstrapped_maxdistance(np.ascontiguousarray(xx), np.ascontiguousarray(chosen))
+
+    def nn(xx):
+        return oracle.most_distant_nearest_neighbor(np.ascontiguousarray(xx))
+
+    monkeypatch.setattr(neighbors, "count_within_distance_of", count)
+    monkeypatch.setattr(neighbors, "any_within_distance_of", anyw)
+    monkeypatch.setattr(neighbors, "is_within_distance_of", within)
+    monkeypatch.setattr(neighbors, "bootstrapped_maxdistance_chosen", boot)
+    monkeypatch.setattr(neighbors, "most_distant_nearest_neighbor", nn)

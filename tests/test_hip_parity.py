@@ -266,3 +266,33 @@ def test_geometry_full_size_properties(nb):
     assert r6 == nb.bootstrapped_maxdistance_chosen(pts, np.ascontiguousarray(chosen[:, ::-1]))
     assert nb.bootstrapped_maxdistance_chosen(pts, np.ones((10000, 3))) == 0.0
     assert 0 < r6 < 1
+
+
+# ---------------------------------------------------------------- end to end ---------------
+@pytest.mark.parametrize("case", ["nothing4", "horns3", "horns12"])
+def test_end_to_end_against_reference_trace(case):
+    """The whole analysis on the GPU (HIP likelihood + HIP geometry + host orchestration) against
+    the trace recorded from the reference's Python + C.  Geometry is bit-exact and likelihoods
+    agree to ~1e-15, so the integer bookkeeping is expected to coincide (a last-bit tie in an
+    accept test could fork a run; none occurs in these cases) and the evidences must agree within
+    the 1e-6 relative bar of BASELINE.json."""
+    import os
+    from massivedatans_amd import sample
+    from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with np.load(os.path.join(root, "tests", "golden", "trace_%s.npz" % case)) as f:
+        g = {k: f[k] for k in f.files}
+    ndata, nlive = int(g["ndata"]), int(g["nlive"])
+    data = (gen.horns if "horns" in case else gen.nothing)(ndata)
+    problem = sample.GaussLineProblem(data["x"], data["y"])          # HIP backend
+    sampler = sample.build_sampler(problem, nlive_points=nlive, nsuperset_draws=int(g["nsuperset_draws"]),
+                                   use_graph=False, seed=1, batched=True)
+    with np.errstate(all="ignore"):
+        results = multi_nested_integrator(tolerance=0.5, multi_sampler=sampler, min_samples=0,
+                                          max_samples=int(g["max_samples"]))
+    assert sampler.ndraws == int(g["ndraws"])
+    assert np.array_equal(sampler.live_pointsp, g["final_live_pointsp"])
+    assert rel_err(sampler.live_pointsL, g["final_live_pointsL"]) < 1e-12
+    assert rel_err(results["logZ"], g["logZ"]) < 1e-6
+    assert np.max(np.abs(results["logZ"] - g["logZ"])) < 1e-9
+    assert np.allclose(results["logZerr"], g["logZerr"], rtol=1e-6, atol=1e-9)

@@ -1,0 +1,77 @@
+"""Host orchestration (sampler, integrator, MLFriends constrainer, region, cache) against
+golden traces recorded from the REFERENCE's own Python + C (oracle/make_trace.py).
+
+The likelihood / geometry backends here are the CPU oracle (bit-identical to the reference C),
+so everything must agree BIT-EXACTLY: per-iteration dead-point likelihoods and coordinates,
+draw counts, final live-point id matrix, evidences, and the position of the global RNG stream.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from massivedatans_amd import gen, sample
+from oracle_backend import OracleSpectra, patch_neighbors
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CASES = ["nothing4", "horns3", "horns12", "horns6"]
+
+
+class Recorder(object):
+    def __init__(self, sampler):
+        self.__dict__.update(_s=sampler, Ls=[], us=[], ndraws_after=[])
+
+    def __getattr__(self, name):
+        return getattr(self._s, name)
+
+    def __next__(self):
+        u, x, L = next(self._s)
+        self.Ls.append(np.array(L))
+        self.us.append(np.array(u))
+        self.ndraws_after.append(int(self._s.ndraws))
+        return u, x, L
+
+
+def run_case(g, oracle, batched):
+    from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
+    ndata, nlive = int(g["ndata"]), int(g["nlive"])
+    name = "horns" if "horns" in g["_name"] else "nothing"
+    data = (gen.horns if name == "horns" else gen.nothing)(ndata)
+    problem = sample.GaussLineProblem(data["x"], data["y"], backend=OracleSpectra(oracle, data["x"], data["y"]))
+    sampler = sample.build_sampler(problem, nlive_points=nlive, nsuperset_draws=int(g["nsuperset_draws"]),
+                                   use_graph=False, seed=1, batched=batched)
+    rec = Recorder(sampler)
+    results = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0,
+                                      max_samples=int(g["max_samples"]))
+    return results, sampler, rec, np.random.uniform()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("batched", [False, True])
+def test_trace_bit_exact(case, batched, oracle, monkeypatch):
+    with np.load(os.path.join(ROOT, "tests", "golden", "trace_%s.npz" % case)) as f:
+        g = {k: f[k] for k in f.files}
+    g["_name"] = case
+    if case == "horns6" and batched:
+        pytest.skip("242k draws: run once, unbatched")
+    patch_neighbors(monkeypatch, oracle)
+    with np.errstate(all="ignore"):
+        results, sampler, rec, rng_probe = run_case(g, oracle, batched)
+    # integer bookkeeping
+    assert np.array_equal(np.array([len(L) for L in rec.Ls]), g["iter_nrunning"])
+    assert np.array_equal(np.array(rec.ndraws_after), g["iter_ndraws"])
+    assert sampler.ndraws == int(g["ndraws"])
+    assert len(sampler.pointpile) == int(g["npoints"])
+    assert np.array_equal(sampler.live_pointsp, g["final_live_pointsp"])
+    assert len(results["weights"]) == int(g["nweights"])
+    # floating point, bit for bit
+    assert np.array_equal(np.concatenate(rec.Ls), g["iter_L"])
+    assert np.array_equal(np.concatenate(rec.us), g["iter_u"])
+    assert np.array_equal(sampler.live_pointsL, g["final_live_pointsL"])
+    assert np.array_equal(results["logZ"], g["logZ"])
+    assert np.array_equal(results["logZerr"], g["logZerr"])
+    assert np.array_equal(results["information"], g["information"])
+    # the global legacy RNG stream was consumed call for call
+    assert rng_probe == float(g["rng_probe"])
+    # our own counter: every (candidate, data set) pair the sampler asked for
+    assert sampler.nevals >= sampler.ndraws

@@ -1,0 +1,19 @@
+#!/usr/bin/env python3
+"""End-to-end analysis on the GPU: python tools/e2e_run.py <horns|nothing> <ndata> <nlive> <max_samples>"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from massivedatans_amd import gen, sample
+
+kind, ndata, nlive, cap = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+data = (gen.horns if kind == "horns" else gen.nothing)(ndata)
+t0 = time.time()
+with np.errstate(all="ignore"):
+    results, sampler, problem, duration = sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap,
+                                                     use_graph=False)
+print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nlive, cap), "wall_s": duration,
+                  "setup_s": time.time() - t0 - duration, "iterations": int(results["nsamples"]),
+                  "ndraws": int(sampler.ndraws), "evals_useful": int(sampler.nevals),
+                  "evals_scored": int(problem.nevals), "launches": int(problem.ncalls),
+                  "useful_evals_per_s": sampler.nevals / duration, "scored_evals_per_s": problem.nevals / duration,
+                  "logZ_first3": results["logZ"][:3].tolist()}))
