@@ -457,10 +457,10 @@ int gauss_cols_tile(int M, int B)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
-	// candidates per wave: the largest tile that still leaves about five waves per SIMD
+	// candidates per wave: the largest tile that still leaves about four waves per SIMD
 	// (measured on MI355X, 10 000 spectra: B=64 -> 4, B=256 -> 8, B=1024 -> 16), at least 4
 	int bt = 16;
-	while (bt > 4 && (long long) ntiles * ((B + bt - 1) / bt) < 20LL * c->num_cus) bt >>= 1;
+	while (bt > 4 && (long long) ntiles * ((B + bt - 1) / bt) < 16LL * c->num_cus) bt >>= 1;
 	while (bt > B && bt > 1) bt >>= 1;
 	static const char *forced_bt = getenv("MDNS_K1_BT");      // experiments only
 	if (forced_bt) { const int f = atoi(forced_bt); if (f == 1 || f == 2 || f == 4 || f == 8 || f == 16) bt = f; }

@@ -1,0 +1,66 @@
+"""The N > 1 path on CPU: two processes, gloo backend, the oracle as per-rank scorer."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from massivedatans_amd import gen, parallel
+    from oracle.oracle import Oracle
+    from oracle_backend import OracleSpectra
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        orc = Oracle("port")
+        d = gen.horns(37)                                   # ragged split: 19 + 18
+        sharded = parallel.ShardedGaussLine(d["x"], d["y"], lambda x, y: OracleSpectra(orc, x, y))
+        whole = OracleSpectra(orc, d["x"], d["y"])
+        rng = np.random.RandomState(4)
+        params = np.column_stack([rng.uniform(0.01, 1, 5), rng.uniform(400, 800, 5), 10 ** rng.uniform(0, 2, 5)])
+        ok = True
+        for mask in (np.ones(37, bool), rng.uniform(size=37) < 0.4, np.arange(37) < 3, np.arange(37) == 30):
+            got = sharded.loglike_batch(params, mask)
+            ok &= np.array_equal(got, whole.loglike_batch(params, mask))
+        # live-point pool: ranks hold overlapping id sets of different sizes, twice (capacity reuse / growth)
+        pile = rng.uniform(size=(500, 3))
+        for k in (40, 300):
+            ids = np.unique(rng.randint(0, 500, size=k + 7 * rank))
+            uniq, pts = parallel.allgather_pool(ids, pile[ids])
+            allids = [None] * world
+            dist.all_gather_object(allids, ids)
+            want = np.unique(np.concatenate(allids))
+            ok &= np.array_equal(uniq, want) and np.array_equal(pts, pile[want])
+        lo, hi = parallel.shard_range(37, rank, world)
+        q.put((rank, bool(ok), lo, hi))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+    res = sorted(q.get(timeout=5) for _ in range(2))
+    assert [p.exitcode for p in procs] == [0, 0]
+    assert res == [(0, True, 0, 19), (1, True, 19, 37)]
+
+
+def test_shard_bounds():
+    from massivedatans_amd import parallel
+    assert parallel.shard_bounds(10, 3).tolist() == [0, 4, 7, 10]
+    assert parallel.shard_bounds(100000, 8).tolist() == [12500 * k for k in range(9)]
+    assert parallel.shard_bounds(3, 8).tolist() == [0, 1, 2, 3, 3, 3, 3, 3, 3]
+    m = np.arange(10) % 2 == 0
+    assert parallel.local_mask(m, 1, 3).tolist() == m[4:7].tolist()
