@@ -647,8 +647,8 @@ extern "C" int mdns_bootstrap_round_maxsq_dev(const double *d_members, int K, in
 	if (!c) return 1;
 	if (K < 0 || nbootstraps < 0 || ndim <= 0) { set_error("mdns_bootstrap_round_maxsq_dev: bad sizes"); return 1; }
 	if (nbootstraps == 0) return 0;
-	if (!MDNS_HIP(hipMemsetAsync(d_round_sq, 0, (size_t) nbootstraps * sizeof(double), c->stream))) return 1;
-	if (K == 0) return 0;
+	// k_pack_chosen clears d_round_sq itself; an empty pool still has to report zeros
+	if (K == 0) return MDNS_HIP(hipMemsetAsync(d_round_sq, 0, (size_t) nbootstraps * sizeof(double), c->stream)) ? 0 : 1;
 	return launch_bootstrap(d_members, K, ndim, d_chosen, nbootstraps, d_round_sq) ? 0 : 1;
 }
 

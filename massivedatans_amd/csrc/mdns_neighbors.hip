@@ -16,11 +16,21 @@
 
 namespace mdns {
 
-static constexpr int kBlock = 256;          // 64 points (one per lane) x 4 waves splitting the members
+static constexpr int kBlock = 256;          // 4 waves
 static constexpr int kMaxTile = 512;        // members per LDS tile (fewer when ndim is large)
 static constexpr int kMaxRegDim = 8;        // dimensions kept in registers
 static constexpr int kRounds = 16;          // bootstrap rounds per pass (cneighbors uses 10)
 static constexpr size_t kLdsBudget = 60 * 1024;
+
+// Lane geometry shared by the kernels below.  A wave is PTS points x SL member-slices
+// (PTS * SL = 64): lane = point + PTS * slice.  With the 4 waves of a workgroup that makes
+// 4*SL slices; slice q scans members q, q + 4*SL, q + 8*SL, ... of every LDS tile.  SL = 1 is
+// the throughput shape (64 points per workgroup, LDS reads are pure broadcasts); SL = 4 is the
+// latency shape for small problems (4x the workgroups, a quarter of the trip count per lane).
+template <int SL> struct Geo {
+	static constexpr int PTS = 64 / SL;
+	static constexpr int NSLICE = 4 * SL;
+};
 
 __device__ __forceinline__ double sq_distance(const double *a, const double *b, int ndim)
 {
@@ -47,22 +57,24 @@ __device__ __forceinline__ double sq_distance_fixed(const double *a, const doubl
 // ---------------------------------------------------------------------------------------
 // K3 / K4: how many members lie strictly within the radius of each candidate
 // ---------------------------------------------------------------------------------------
-// A workgroup owns 64 candidates (one per lane); its four waves each scan a quarter of every
-// member tile and meet in LDS.  grid.x tiles the candidates, grid.y splits the members between
+// grid.x tiles the candidates (PTS per workgroup), grid.y splits the members between
 // workgroups when the pool is large (partial counts then combine with integer atomics into a
 // zeroed buffer -- exact whatever the order).  D == 0: runtime ndim (generic path).
-template <int D>
+template <int D, int SL>
 __global__ __launch_bounds__(kBlock) void k_count_within(
     const double *__restrict__ members, int K, int ndim, double thresh_sq,
     const double *__restrict__ cands, int M, int *__restrict__ counts, int kchunk, int tile_n,
     int accumulate)
 {
+	constexpr int PTS = Geo<SL>::PTS, NSLICE = Geo<SL>::NSLICE;
 	extern __shared__ double smem[];
 	double *tile = smem;                                                  // [tile_n][ndim]
-	int *part = reinterpret_cast<int *>(smem + (size_t) tile_n * ndim);   // [4][64]
+	int *part = reinterpret_cast<int *>(smem + (size_t) tile_n * ndim);   // [4][PTS]
 	const int lane = threadIdx.x & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int j = blockIdx.x * 64 + lane;
+	const int wv = threadIdx.x >> 6;
+	const int pt = lane % PTS;
+	const int slice = wv * SL + lane / PTS;
+	const int j = blockIdx.x * PTS + pt;
 	const int jj = j < M ? j : M - 1;
 	const int kbeg = blockIdx.y * kchunk;
 	const int kend = min(K, kbeg + kchunk);
@@ -78,21 +90,23 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 		__syncthreads();
 		for (int e = threadIdx.x; e < n * ndim; e += kBlock) tile[e] = members[(size_t) t0 * ndim + e];
 		__syncthreads();
-		const int q = (n + 3) / 4;
-		const int ibeg = wv * q, iend = min(n, ibeg + q);
 		if (D > 0) {
-			for (int i = ibeg; i < iend; i++)
+#pragma unroll 4
+			for (int i = slice; i < n; i += NSLICE)
 				hits += sq_distance_fixed<(D > 0 ? D : 1)>(tile + i * D, c) < thresh_sq ? 1 : 0;
 		} else {
 			const double *cj = cands + (size_t) jj * ndim;
-			for (int i = ibeg; i < iend; i++)
+			for (int i = slice; i < n; i += NSLICE)
 				hits += sq_distance(tile + i * ndim, cj, ndim) < thresh_sq ? 1 : 0;
 		}
 	}
-	part[wv * 64 + lane] = hits;
+	// sum over the slices of this wave (lanes pt, pt + PTS, ...), then over the waves
+#pragma unroll
+	for (int off = PTS; off < 64; off <<= 1) hits += __shfl_xor(hits, off, 64);
+	if (lane < PTS) part[wv * PTS + pt] = hits;
 	__syncthreads();
-	if (wv == 0 && j < M) {
-		const int total = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+	if (wv == 0 && lane < PTS && j < M) {
+		const int total = (part[pt] + part[PTS + pt]) + (part[2 * PTS + pt] + part[3 * PTS + pt]);
 		if (accumulate) { if (total) atomicAdd(counts + j, total); }
 		else counts[j] = total;
 	}
@@ -108,6 +122,16 @@ __device__ __forceinline__ double wave_max(double v)
 	return v;
 }
 
+// min(a, b) where b may be a QUIET NaN meaning "not a candidate": v_min_f64 returns the other
+// operand for a quiet NaN.  Written as asm so that the compiler does not put a canonicalising
+// v_max_f64 in front of every use (it cannot know the operand is already quiet).
+__device__ __forceinline__ double min_or_skip(double a, double b)
+{
+	double r;
+	asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+	return r;
+}
+
 // non-negative doubles order like their bit patterns
 __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
 {
@@ -115,11 +139,13 @@ __device__ __forceinline__ void atomic_max_nonneg(double *addr, double v)
 }
 
 // chosen f64[K][nboot] (cneighbors.c:146 tests != 0) -> one bit per round of the window
-// [b0, b0+nb) for every pool point
+// [b0, b0+nb) for every pool point; also clears the window's slots of round_sq, which
+// k_nearest_chosen then raises with atomic max
 __global__ void k_pack_chosen(const double *__restrict__ chosen, int K, int nboot, int b0, int nb,
-                              unsigned *__restrict__ mask)
+                              unsigned *__restrict__ mask, double *__restrict__ round_sq)
 {
 	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nb) round_sq[b0 + i] = 0.0;
 	if (i >= K) return;
 	const double *row = chosen + (size_t) i * nboot + b0;
 	unsigned m = 0;
@@ -134,22 +160,27 @@ __global__ void k_pack_chosen(const double *__restrict__ chosen, int K, int nboo
 //   at 1, :162).
 // NN == true  (K5, cneighbors.c:47-71): one round, everybody chosen, self excluded, every
 //   point contributes.
-// A workgroup owns 64 pool points (one per lane); its four waves each scan a quarter of every
-// member tile, so a pool of K points runs on 4*ceil(K/64) waves.  The per-round minima of the
-// four waves meet in LDS (min is exact, so the split cannot change the result).
-template <int D, bool NN>
+// The distance of a pair is computed once and offered to all rounds without branches: for a
+// round in which member j is NOT chosen the exponent and quiet bits of the distance are forced
+// to ones (-> quiet NaN), which v_min_f64 discards.  Partial minima of slices and waves meet by
+// shuffles and LDS (min is exact, the split cannot change the result).
+template <int D, bool NN, int SL>
 __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
     const double *__restrict__ members, int K, int ndim, const unsigned *__restrict__ mask,
     int nb, double *__restrict__ round_sq, int tile_n)
 {
+	constexpr int PTS = Geo<SL>::PTS, NSLICE = Geo<SL>::NSLICE;
+	constexpr int NR = NN ? 1 : kRounds;
 	extern __shared__ double smem[];
 	double *tile = smem;                                          // [tile_n][ndim]
-	double *part = smem + (size_t) tile_n * ndim;                 // [4][kRounds][64]
-	unsigned *tmask = reinterpret_cast<unsigned *>(part + 4 * kRounds * 64);   // [tile_n]
+	double *part = smem + (size_t) tile_n * ndim;                 // [4][NR][PTS]
+	unsigned *tmask = reinterpret_cast<unsigned *>(part + 4 * NR * PTS);   // [tile_n]
 
 	const int lane = threadIdx.x & 63;
-	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int i = blockIdx.x * 64 + lane;
+	const int wv = threadIdx.x >> 6;
+	const int pt = lane % PTS;
+	const int slice = wv * SL + lane / PTS;
+	const int i = blockIdx.x * PTS + pt;
 	const int ii = i < K ? i : K - 1;
 	double c[D > 0 ? D : 1];
 	if (D > 0) {
@@ -158,43 +189,56 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 	}
 	const unsigned mymask = NN ? 0u : mask[ii];
 
-	double nearest[kRounds];
+	double nearest[NR];
 #pragma unroll
-	for (int b = 0; b < kRounds; b++) nearest[b] = 1e300;         // cneighbors.c:51,148
+	for (int b = 0; b < NR; b++) nearest[b] = 1e300;              // cneighbors.c:51,148
 
 	for (int t0 = 0; t0 < K; t0 += tile_n) {
 		const int n = min(tile_n, K - t0);
 		__syncthreads();
 		for (int e = threadIdx.x; e < n * ndim; e += kBlock) tile[e] = members[(size_t) t0 * ndim + e];
-		for (int e = threadIdx.x; e < n; e += kBlock) tmask[e] = NN ? 1u : mask[t0 + e];
+		if (!NN) for (int e = threadIdx.x; e < n; e += kBlock) tmask[e] = mask[t0 + e];
 		__syncthreads();
-		const int q = (n + 3) / 4;
-		const int jbeg = wv * q, jend = min(n, jbeg + q);
-		for (int jn = jbeg; jn < jend; jn++) {
-			const unsigned mk = __builtin_amdgcn_readfirstlane(tmask[jn]);   // same for the whole wave
-			if (mk == 0) continue;
+		for (int jn = slice; jn < n; jn += NSLICE) {
 			double d;
 			if (D > 0) d = sq_distance_fixed<(D > 0 ? D : 1)>(tile + jn * D, c);
 			else d = sq_distance(members + (size_t) ii * ndim, tile + jn * ndim, ndim);
 			if (NN) {
 				if (t0 + jn != ii) nearest[0] = fmin(nearest[0], d);
 			} else {
+				const int notchosen = (int) ~tmask[jn];
+				const unsigned lo = (unsigned) __double2loint(d);
+				const unsigned hi = (unsigned) __double2hiint(d);
 #pragma unroll
-				for (int b = 0; b < kRounds; b++)
-					if ((mk >> b) & 1u) nearest[b] = fmin(nearest[b], d);   // scalar branch per round
+				for (int b = 0; b < NR; b++) {
+					// 0 where chosen in round b, all ones where not (1-bit signed field extract);
+					// exponent all ones + quiet bit = quiet NaN whatever the mantissa
+					const unsigned kill = (unsigned) __builtin_amdgcn_sbfe(notchosen, b, 1);
+					const double cand = __hiloint2double((int) (hi | (kill & 0x7ff80000u)), (int) lo);
+					nearest[b] = min_or_skip(nearest[b], cand);
+				}
 			}
 		}
 	}
-	// meet the four partial minima, then max over the contributing points: one atomic per
-	// wave and round (each wave finishes a quarter of the rounds)
+	// min over the slices of this wave, then over the waves; finally the max over the
+	// contributing points: one atomic per wave and round
 #pragma unroll
-	for (int b = 0; b < kRounds; b++) part[(wv * kRounds + b) * 64 + lane] = nearest[b];
+	for (int b = 0; b < NR; b++) {
+		double v = nearest[b];
+#pragma unroll
+		for (int off = PTS; off < 64; off <<= 1) v = fmin(v, __shfl_xor(v, off, 64));
+		if (lane < PTS) part[(wv * NR + b) * PTS + pt] = v;
+	}
 	__syncthreads();
-	for (int b = wv; b < nb; b += 4) {
-		double v = fmin(fmin(part[(0 * kRounds + b) * 64 + lane], part[(1 * kRounds + b) * 64 + lane]),
-		                fmin(part[(2 * kRounds + b) * 64 + lane], part[(3 * kRounds + b) * 64 + lane]));
-		const bool contributes = i < K && (NN ? true : (i >= 1 && !((mymask >> b) & 1u)));
-		v = wave_max(contributes ? v : 0.0);
+	for (int b = wv; b < (NN ? 1 : nb); b += 4) {
+		double v = 0.0;
+		if (lane < PTS) {
+			v = fmin(fmin(part[(0 * NR + b) * PTS + pt], part[(1 * NR + b) * PTS + pt]),
+			         fmin(part[(2 * NR + b) * PTS + pt], part[(3 * NR + b) * PTS + pt]));
+			const bool contributes = i < K && (NN ? true : (i >= 1 && !((mymask >> b) & 1u)));
+			if (!contributes) v = 0.0;
+		}
+		v = wave_max(v);
 		if (lane == 0 && v > 0.0) atomic_max_nonneg(round_sq + b, v);
 	}
 }
@@ -210,15 +254,21 @@ static bool launched(const char *name)
 	return false;
 }
 
-// members per LDS tile: a multiple of 4, as many as fit beside `fixed_bytes`
+// members per LDS tile: a multiple of 16, as many as fit beside `fixed_bytes`
 static int pick_tile(int ndim, size_t per_member_extra, size_t fixed_bytes)
 {
 	const size_t per = (size_t) ndim * sizeof(double) + per_member_extra;
-	if (fixed_bytes + 4 * per > kLdsBudget) return 0;
+	if (fixed_bytes + 16 * per > kLdsBudget) return 0;
 	size_t n = (kLdsBudget - fixed_bytes) / per;
 	if (n > (size_t) kMaxTile) n = kMaxTile;
-	return (int) (n & ~(size_t) 3);
+	return (int) (n & ~(size_t) 15);
 }
+
+#define MDNS_DIM_SWITCH(ndim, LAUNCH) \
+	switch ((ndim) <= kMaxRegDim ? (ndim) : 0) { \
+	case 1: LAUNCH(1); break; case 2: LAUNCH(2); break; case 3: LAUNCH(3); break; \
+	case 4: LAUNCH(4); break; case 5: LAUNCH(5); break; case 6: LAUNCH(6); break; \
+	case 7: LAUNCH(7); break; case 8: LAUNCH(8); break; default: LAUNCH(0); break; }
 
 bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
                          const double *d_cands, int M, int *d_counts)
@@ -227,7 +277,10 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	const size_t fixed = 4 * 64 * sizeof(int);
 	const int tile_n = pick_tile(ndim, 0, fixed);
 	if (tile_n <= 0) { set_error("ndim=%d too large for the member tile", ndim); return false; }
-	const int gx = (M + 63) / 64;
+	// few candidates: 16 per workgroup and 16 member slices (latency shape)
+	const bool small = (M + 63) / 64 < 2 * c->num_cus;
+	const int pts = small ? 16 : 64;
+	const int gx = (M + pts - 1) / pts;
 	// split the members between workgroups until the grid covers the chip about twice
 	int want = (2 * c->num_cus + gx - 1) / gx;
 	int max_split = (K + tile_n - 1) / tile_n;
@@ -242,19 +295,11 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	const size_t lds = (size_t) tile_n * ndim * sizeof(double) + fixed;
 	dim3 grid(gx, gy);
 	ProfileScope prof(2);
-#define COUNT_LAUNCH(D) hipLaunchKernelGGL((k_count_within<D>), grid, dim3(kBlock), lds, c->stream, \
-	d_members, K, ndim, thresh_sq, d_cands, M, d_counts, kchunk, tile_n, accumulate)
-	switch (ndim <= kMaxRegDim ? ndim : 0) {
-	case 1: COUNT_LAUNCH(1); break;
-	case 2: COUNT_LAUNCH(2); break;
-	case 3: COUNT_LAUNCH(3); break;
-	case 4: COUNT_LAUNCH(4); break;
-	case 5: COUNT_LAUNCH(5); break;
-	case 6: COUNT_LAUNCH(6); break;
-	case 7: COUNT_LAUNCH(7); break;
-	case 8: COUNT_LAUNCH(8); break;
-	default: COUNT_LAUNCH(0); break;
-	}
+#define COUNT_LAUNCH(D) do { if (small) hipLaunchKernelGGL((k_count_within<D, 4>), grid, dim3(kBlock), lds, c->stream, \
+		d_members, K, ndim, thresh_sq, d_cands, M, d_counts, kchunk, tile_n, accumulate); \
+	else hipLaunchKernelGGL((k_count_within<D, 1>), grid, dim3(kBlock), lds, c->stream, \
+		d_members, K, ndim, thresh_sq, d_cands, M, d_counts, kchunk, tile_n, accumulate); } while (0)
+	MDNS_DIM_SWITCH(ndim, COUNT_LAUNCH)
 #undef COUNT_LAUNCH
 	return launched("k_count_within");
 }
@@ -273,28 +318,23 @@ static bool launch_nearest(const double *d_members, int K, int ndim, const doubl
 		d_mask = (unsigned *) mask_scratch((size_t) K * sizeof(unsigned));
 		if (!d_mask) return false;
 	}
-	dim3 grid((K + 63) / 64);
+	const bool small = (K + 63) / 64 < 2 * c->num_cus;          // latency shape below ~32k points
+	const int pts = small ? 16 : 64;
+	dim3 grid((K + pts - 1) / pts);
 	for (int b0 = 0; b0 < nboot; b0 += kRounds) {
 		const int nb = nboot - b0 < kRounds ? nboot - b0 : kRounds;
 		if (!NN) {
-			hipLaunchKernelGGL(k_pack_chosen, dim3((K + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-			                   d_chosen, K, nboot, b0, nb, d_mask);
+			const int nthreads = K > nb ? K : nb;
+			hipLaunchKernelGGL(k_pack_chosen, dim3((nthreads + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+			                   d_chosen, K, nboot, b0, nb, d_mask, d_round_sq);
 			if (!launched("k_pack_chosen")) return false;
 		}
 		ProfileScope prof(3);
-#define NEAR_LAUNCH(D) hipLaunchKernelGGL((k_nearest_chosen<D, NN>), grid, dim3(kBlock), lds, c->stream, \
-	d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n)
-		switch (ndim <= kMaxRegDim ? ndim : 0) {
-		case 1: NEAR_LAUNCH(1); break;
-		case 2: NEAR_LAUNCH(2); break;
-		case 3: NEAR_LAUNCH(3); break;
-		case 4: NEAR_LAUNCH(4); break;
-		case 5: NEAR_LAUNCH(5); break;
-		case 6: NEAR_LAUNCH(6); break;
-		case 7: NEAR_LAUNCH(7); break;
-		case 8: NEAR_LAUNCH(8); break;
-		default: NEAR_LAUNCH(0); break;
-		}
+#define NEAR_LAUNCH(D) do { if (small) hipLaunchKernelGGL((k_nearest_chosen<D, NN, 4>), grid, dim3(kBlock), lds, c->stream, \
+		d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n); \
+	else hipLaunchKernelGGL((k_nearest_chosen<D, NN, 1>), grid, dim3(kBlock), lds, c->stream, \
+		d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n); } while (0)
+		MDNS_DIM_SWITCH(ndim, NEAR_LAUNCH)
 #undef NEAR_LAUNCH
 		if (!launched("k_nearest_chosen")) return false;
 	}
