@@ -67,7 +67,12 @@ def multi_nested_integrator(multi_sampler, tolerance=0.01, max_samples=None, min
     wi = logwidth + Li
     logZ = wi
     H = Li - logZ
-    remainder_tails = [[] for _ in range(ndata)]
+    ndim = ui.shape[1]
+    # live points of each data set at its termination, in order of increasing likelihood
+    tail_u = numpy.zeros((nlive, ndata, ndim))
+    tail_x = numpy.zeros((nlive, ndata, ndim))
+    tail_L = numpy.zeros((nlive, ndata))
+    tail_w = numpy.zeros(ndata)
     while True:
         i = i + 1
         logwidth = log(1 - exp(-1. / nlive)) + logVolremaining
@@ -96,7 +101,8 @@ def multi_nested_integrator(multi_sampler, tolerance=0.01, max_samples=None, min
                 log_.debug('iteration %d: terminating %d data sets', i, terminating.sum())
                 for j, k in enumerate(numpy.where(running)[0]):
                     if terminating[j]:
-                        remainder_tails[k] = [[u, x, L, logwidth] for u, x, L in sampler.remainder(j)]
+                        tail_u[:, k], tail_x[:, k], tail_L[:, k] = sampler.remainder_arrays(j)
+                        tail_w[k] = logwidth
                 sampler.cut_down(~terminating)
                 running[running] = ~terminating
             if not running.any():
@@ -110,8 +116,7 @@ def multi_nested_integrator(multi_sampler, tolerance=0.01, max_samples=None, min
     # the live points at termination complete the posterior sample (not needed for logZ)
     all_tails = numpy.ones(ndata, dtype=bool)
     for k in range(nlive):
-        u, x, L, lw = list(zip(*[tail[k] for tail in remainder_tails]))
-        weights.append([u, x, L, lw, all_tails])
+        weights.append([tail_u[k], tail_x[k], tail_L[k], tail_w.copy(), all_tails])
     logZerr = logZerr + last_remainderZerr
     logZ = logaddexp(logZ, last_remainderZ)
 

@@ -11,13 +11,17 @@ State (names as in the reference):
   pointpile[npoints, ndim], pointpilex   every point ever accepted, unit-cube / physical
   live_pointsp[nlive, ndata] int         id (row of pointpile) of each live point of each data set
   live_pointsL[nlive, ndata] f64         its likelihood for that data set
-  shelves[d]                             FIFO of accepted (id, u, x, L) waiting to replace the
-                                         worst live point of data set d
+  shelves                                per data set a FIFO of accepted (id, L) pairs waiting to
+                                         replace its worst live point (array-backed, see _Shelves;
+                                         u and x of an entry are pointpile[id], pointpilex[id])
   superpoints                            ids still shared by ALL data sets
 
 What differs from the reference is mechanical: no printing (``logging`` at DEBUG), the initial
-``nlive`` likelihood vectors come from one batched launch, and the constrainers get an
-optional batch scorer (``loglikelihood_batch``) so that they can look ahead on the GPU.
+``nlive`` likelihood vectors come from one batched launch, the constrainers get an optional
+batch scorer (``loglikelihood_batch``) so that they can look ahead on the GPU, and the
+per-data-set Python loops of the reference (shelf lists, ``numpy.unique`` over the whole id
+matrix every iteration) are array operations: at 10 000 data sets they, not the likelihood,
+set the wall-clock.  None of this changes a single value (tests/test_orchestration.py).
 """
 import logging
 from collections import defaultdict
@@ -31,6 +35,67 @@ def find_nsmallest(n, arr1, arr2):
     """(n+1)-th smallest value of the two arrays together (multi_nested_sampler.py:44-47)."""
     merged = numpy.concatenate((arr1, arr2))
     return numpy.partition(merged, n)[n]
+
+
+class _Shelves(object):
+    """FIFO queues of (point id, L), one per data set, in two padded arrays.  Same behaviour
+    as the reference's ``self.shelves`` list of lists of ``(pj, uj, xj, Lj)`` tuples
+    (multi_nested_sampler.py:117,137-138,482-485,513): append at the tail, pop at the head,
+    purge keeps order."""
+
+    def __init__(self, ndata, cap=4):
+        self.n = numpy.zeros(ndata, dtype=int)
+        self.p = numpy.zeros((ndata, cap), dtype=int)
+        self.L = numpy.full((ndata, cap), numpy.inf)
+
+    def __len__(self):
+        return len(self.n)
+
+    def empty(self):
+        return self.n == 0
+
+    def purge(self, Lmins):
+        """Drop entries that no longer beat their data set's threshold, keeping the order."""
+        cap = self.p.shape[1]
+        valid = numpy.arange(cap)[None, :] < self.n[:, None]
+        keep = valid & (self.L > Lmins[:, None])
+        if keep.sum() == valid.sum():
+            return
+        order = numpy.argsort(~keep, axis=1, kind='stable')       # kept entries first, in order
+        self.p = numpy.take_along_axis(self.p, order, axis=1)
+        self.L = numpy.take_along_axis(self.L, order, axis=1)
+        self.n = keep.sum(axis=1)
+        self.L[numpy.arange(cap)[None, :] >= self.n[:, None]] = numpy.inf
+
+    def append(self, rows, pid, Ls):
+        if len(rows) == 0:
+            return
+        if (self.n[rows] >= self.p.shape[1]).any():
+            extra = self.p.shape[1]
+            self.p = numpy.hstack((self.p, numpy.zeros((len(self.n), extra), dtype=int)))
+            self.L = numpy.hstack((self.L, numpy.full((len(self.n), extra), numpy.inf)))
+        pos = self.n[rows]
+        self.p[rows, pos] = pid
+        self.L[rows, pos] = Ls
+        self.n[rows] += 1
+
+    def pop_heads(self):
+        """Head (id, L) of every queue; every queue must be non-empty."""
+        assert (self.n > 0).all()
+        pid, L = self.p[:, 0].copy(), self.L[:, 0].copy()
+        self.p[:, :-1] = self.p[:, 1:]
+        self.L[:, :-1] = self.L[:, 1:]
+        self.L[:, -1] = numpy.inf
+        self.n -= 1
+        return pid, L
+
+    def select(self, surviving):
+        self.n, self.p, self.L = self.n[surviving], self.p[surviving], self.L[surviving]
+
+    def as_lists(self, pointpile, pointpilex):
+        """The reference's representation (for inspection)."""
+        return [[(int(self.p[d, k]), pointpile[self.p[d, k]], pointpilex[self.p[d, k]], self.L[d, k])
+                 for k in range(self.n[d])] for d in range(len(self.n))]
 
 
 class MultiNestedSampler(object):
@@ -70,13 +135,20 @@ class MultiNestedSampler(object):
         self.pointpilex = numpy.array(xs)
         self.live_pointsp = numpy.array([[p] * ndata for p in range(nlive_points)])
         self.live_pointsL = numpy.array(Ls)
-        self.superpoints = list(range(nlive_points))
+        self.superpoints = set(range(nlive_points))
+        # how many (live slot, data set) cells hold each point id: the distinct live points of
+        # ALL data sets are the ids with a positive count (replaces numpy.unique over the matrix)
+        self._refcount = numpy.full(nlive_points, ndata, dtype=int)
         self.Lmax = self.live_pointsL.max(axis=0)
         assert self.Lmax.shape == (ndata,)
         self.data_mask_all = numpy.ones(self.ndata) == 1
         self.real_data_mask_all = numpy.ones(self.ndata) == 1
         self.ndraws = nlive_points
-        self.shelves = [[] for _ in range(ndata)]
+        self._shelves = _Shelves(ndata)
+
+    @property
+    def shelves(self):
+        return self._shelves.as_lists(self.pointpile, self.pointpilex)
 
     def draw_global_uniform(self):
         return numpy.random.uniform(0, 1, size=self.ndim)
@@ -92,16 +164,18 @@ class MultiNestedSampler(object):
         L = self.live_pointsL
         Lmins = L.min(axis=0)
         Lmini = L.argmin(axis=0)
-        for d in range(self.ndata):
-            self.shelves[d] = [entry for entry in self.shelves[d] if entry[3] > Lmins[d]]
-        allu, allp = self.get_unique_pointsp(self.live_pointsp)
-        return allu, allp, L.min(), Lmins, Lmini
+        self._shelves.purge(Lmins)
+        allp = numpy.flatnonzero(self._refcount[:len(self.pointpile)])
+        return self.pointpile[allp], allp, L.min(), Lmins, Lmini
 
     def cut_down(self, surviving):
         """Drop the data sets that finished (multi_nested_sampler.py:148-173)."""
+        dropped = self.live_pointsp[:, ~surviving]
+        if dropped.size:
+            self._refcount -= numpy.bincount(dropped.ravel(), minlength=len(self._refcount))
         self.live_pointsp = self.live_pointsp[:, surviving]
         self.live_pointsL = self.live_pointsL[:, surviving]
-        self.shelves = [shelf for keep, shelf in zip(surviving, self.shelves) if keep]
+        self._shelves.select(surviving)
         self.ndata = surviving.sum()
         self.Lmax = self.live_pointsL.max(axis=0)
         self.data_mask_all = numpy.ones(self.ndata) == 1
@@ -159,13 +233,18 @@ class MultiNestedSampler(object):
             members = [first]
             points = self.live_pointsp[:, first].tolist()
             i = 0
-            while i < len(points) and todo.any():
+            known = set(points)
+            ntodo = int(todo.sum())
+            while i < len(points) and ntodo > 0:
                 newmembers = [m for m in self.point_data_map[points[i]] if todo[m]]
-                members += newmembers
-                for newp in numpy.unique(self.live_pointsp[:, newmembers]):
-                    if newp not in points:
-                        points.append(newp)
-                todo[newmembers] = False
+                if newmembers:
+                    members += newmembers
+                    for newp in numpy.unique(self.live_pointsp[:, newmembers]):
+                        if newp not in known:
+                            known.add(newp)
+                            points.append(newp)
+                    todo[newmembers] = False
+                    ntodo -= len(newmembers)
                 i += 1
             member_mask = numpy.zeros(len(data_mask), dtype=bool)
             member_mask[members] = True
@@ -221,10 +300,13 @@ class MultiNestedSampler(object):
         """A data set that already has n accepted points waiting needs the (n+1)-th worst of
         (live points + shelf) as its threshold (multi_nested_sampler.py:438-447)."""
         higher = Lmins[joint_indices].copy()
-        for j, d in enumerate(joint_indices):
-            n = len(self.shelves[d])
-            if n:
-                higher[j] = find_nsmallest(n, self.live_pointsL[:, d], [entry[3] for entry in self.shelves[d]])
+        counts = self._shelves.n[joint_indices]
+        for n in numpy.unique(counts[counts > 0]):
+            sel = numpy.flatnonzero(counts == n)
+            d = joint_indices[sel]
+            # rows = live likelihoods + the n shelf entries (+inf padding sorts last)
+            merged = numpy.hstack((self.live_pointsL[:, d].T, self._shelves.L[d, :]))
+            higher[sel] = numpy.partition(merged, n, axis=1)[:, n]
         return higher
 
     def _fill_shelves(self, Lmins, allu, allp):
@@ -232,7 +314,7 @@ class MultiNestedSampler(object):
         passes = 0
         while True:
             passes += 1
-            empty = numpy.array([len(self.shelves[d]) == 0 for d in range(self.ndata)])
+            empty = self._shelves.empty()
             if not empty.any():
                 return
             focussed = passes > self.nsuperset_draws
@@ -257,8 +339,8 @@ class MultiNestedSampler(object):
                 joint_indices = numpy.where(joint_data_mask)[0]
                 njoints = len(joint_indices)
                 firstd = joint_indices[0]
-                max_draws = 100000 if (njoints == 1 and len(self.shelves[firstd]) == 0) else 1000
-                if len(groups) > 1 and not focussed and all(len(self.shelves[d]) > 0 for d in joint_indices):
+                max_draws = 100000 if (njoints == 1 and self._shelves.n[firstd] == 0) else 1000
+                if len(groups) > 1 and not focussed and (self._shelves.n[joint_indices] > 0).all():
                     continue                      # this group needs nothing
                 Lmins_higher = self._thresholds_with_shelves(joint_indices, Lmins)
                 real_indices = numpy.where(self.real_data_mask_all)[0]
@@ -287,13 +369,13 @@ class MultiNestedSampler(object):
                 ppi = len(self.pointpile)
                 self.pointpile = numpy.vstack((self.pointpile, [uj]))
                 self.pointpilex = numpy.vstack((self.pointpilex, [xj]))
-                nfilled = 0
-                for j, d in enumerate(joint_indices):
-                    if Lj[j] > Lmins_higher[j]:
-                        self.shelves[d].append((ppi, uj, xj, Lj[j]))
-                        nfilled += 1
+                beats = Lj > Lmins_higher
+                self._shelves.append(joint_indices[beats], ppi, Lj[beats])
+                nfilled = int(beats.sum())
+                if len(self._refcount) <= ppi:
+                    self._refcount = numpy.concatenate((self._refcount, numpy.zeros(max(1024, ppi), dtype=int)))
                 if nfilled == self.ndata:
-                    self.superpoints.append(ppi)
+                    self.superpoints.add(ppi)
                 log.debug('iteration %d: accepted after %d tries, filled %d shelves', self.global_iter, n, nfilled)
 
     def __next__(self):
@@ -311,14 +393,14 @@ class MultiNestedSampler(object):
             for d, pj in enumerate(dead):
                 self.point_data_map[pj].remove(d)
         if self.superpoints:
-            for pj in numpy.unique(dead):
-                if pj in self.superpoints:
-                    self.superpoints.remove(pj)
-        for d in range(self.ndata):
-            pj, _, _, Lj = self.shelves[d].pop(0)
-            self.live_pointsp[Lmini[d], d] = pj
-            self.live_pointsL[Lmini[d], d] = Lj
-            if self.point_data_map is not None:
+            self.superpoints.difference_update(numpy.unique(dead).tolist())
+        newp, newL = self._shelves.pop_heads()
+        self.live_pointsp[Lmini, every] = newp
+        self.live_pointsL[Lmini, every] = newL
+        self._refcount -= numpy.bincount(dead, minlength=len(self._refcount))
+        self._refcount += numpy.bincount(newp, minlength=len(self._refcount))
+        if self.point_data_map is not None:
+            for d, pj in enumerate(newp):
                 self.point_data_map[pj].add(d)
         self.Lmax = self.live_pointsL.max(axis=0)
         assert self.Lmax.shape == (self.ndata,)
@@ -330,16 +412,21 @@ class MultiNestedSampler(object):
         while True:
             yield self.__next__()
 
+    def remainder_arrays(self, d):
+        """``remainder(d)`` as arrays: (u[nlive, ndim], x[nlive, ndim], L[nlive]) in order of
+        increasing likelihood."""
+        order = numpy.argsort(self.live_pointsL[:, d])
+        p = self.live_pointsp[order, d]
+        return self.pointpile[p], self.pointpilex[p], self.live_pointsL[order, d]
+
     def remainder(self, d=None):
         """Live points in order of increasing likelihood: per data set ``d``, or for all data
         sets at once as (u[ndata,ndim], x, L[ndata]) triples (multi_nested_sampler.py:536-563)."""
         if d is None:
-            order = numpy.empty((self.ndata, self.nlive_points), dtype=int)
-            for k in range(self.ndata):
-                order[k, :] = numpy.argsort(self.live_pointsL[:, k])
+            order = numpy.argsort(self.live_pointsL, axis=0)       # column-wise, like the reference's loop
             every = numpy.arange(self.ndata)
             for i in range(self.nlive_points):
-                j = order[every, i]
+                j = order[i, every]
                 p = self.live_pointsp[j, every]
                 yield self.pointpile[p], self.pointpilex[p], self.live_pointsL[j, every]
         else:
