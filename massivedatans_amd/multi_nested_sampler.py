@@ -296,18 +296,18 @@ class MultiNestedSampler(object):
             yield member_mask, sorted(points)
 
     # ---- one nested-sampling iteration ---------------------------------------------------
-    def _thresholds_with_shelves(self, joint_indices, Lmins):
+    def _refresh_thresholds(self, rows):
         """A data set that already has n accepted points waiting needs the (n+1)-th worst of
-        (live points + shelf) as its threshold (multi_nested_sampler.py:438-447)."""
-        higher = Lmins[joint_indices].copy()
-        counts = self._shelves.n[joint_indices]
+        (live points + shelf) as its threshold (multi_nested_sampler.py:438-447).  The reference
+        recomputes this for every data set of every draw; live likelihoods do not change within
+        an iteration and a shelf only changes when it receives a point, so the thresholds are
+        kept in ``self._higher`` and refreshed for exactly the rows whose shelf grew."""
+        counts = self._shelves.n[rows]
         for n in numpy.unique(counts[counts > 0]):
-            sel = numpy.flatnonzero(counts == n)
-            d = joint_indices[sel]
-            # rows = live likelihoods + the n shelf entries (+inf padding sorts last)
+            d = rows[counts == n]
+            # live likelihoods + the shelf entries (+inf padding sorts last)
             merged = numpy.hstack((self.live_pointsL[:, d].T, self._shelves.L[d, :]))
-            higher[sel] = numpy.partition(merged, n, axis=1)[:, n]
-        return higher
+            self._higher[d] = numpy.partition(merged, n, axis=1)[:, n]
 
     def _fill_shelves(self, Lmins, allu, allp):
         superset_groups = None
@@ -342,7 +342,7 @@ class MultiNestedSampler(object):
                 max_draws = 100000 if (njoints == 1 and self._shelves.n[firstd] == 0) else 1000
                 if len(groups) > 1 and not focussed and (self._shelves.n[joint_indices] > 0).all():
                     continue                      # this group needs nothing
-                Lmins_higher = self._thresholds_with_shelves(joint_indices, Lmins)
+                Lmins_higher = self._higher[joint_indices].copy()
                 real_indices = numpy.where(self.real_data_mask_all)[0]
                 if njoints == 1:
                     draw = self.individual_draw_constrained(real_indices[firstd], self.global_iter, sampler=self)
@@ -371,6 +371,7 @@ class MultiNestedSampler(object):
                 self.pointpilex = numpy.vstack((self.pointpilex, [xj]))
                 beats = Lj > Lmins_higher
                 self._shelves.append(joint_indices[beats], ppi, Lj[beats])
+                self._refresh_thresholds(joint_indices[beats])
                 nfilled = int(beats.sum())
                 if len(self._refcount) <= ppi:
                     self._refcount = numpy.concatenate((self._refcount, numpy.zeros(max(1024, ppi), dtype=int)))
@@ -380,6 +381,8 @@ class MultiNestedSampler(object):
 
     def __next__(self):
         allu, allp, _, Lmins, Lmini = self.prepare()
+        self._higher = Lmins.copy()
+        self._refresh_thresholds(numpy.flatnonzero(self._shelves.n > 0))
         self._fill_shelves(Lmins, allu, allp)
 
         # every data set gives up its worst live point and takes the head of its shelf
