@@ -151,8 +151,6 @@ def main():
     d_params, d_chosen, d_cands = dev(params), dev(chosen), dev(cands)
     d_L = lib.mdns_dev_alloc(B * nd * 8)
     d_counts = lib.mdns_dev_alloc(NCAND * 4)
-    d_round = lib.mdns_dev_alloc(NBOOT * 8)
-    round_sq = np.zeros(NBOOT)
     if world > 1:
         assert K % world == 0, "pool size must divide over the ranks"
         t_pool = torch.empty((K, NDIM), dtype=torch.float64, device="cuda")
@@ -160,14 +158,17 @@ def main():
         d_pool = t_pool.data_ptr()
     else:
         d_pool = dev(pool)
+    region = lib.mdns_region_wrap_dev(d_pool, K, NDIM)     # the pool buffer is refilled in place
+    if not region:
+        raise _lib.MdnsError(_lib.last_error())
 
     def step():
         if world > 1:
             dist.all_gather_into_tensor(t_pool, t_mine)
-        _lib.check(lib.mdns_bootstrap_round_maxsq_dev(d_pool, K, NDIM, d_chosen, NBOOT, d_round), "K6")
-        _lib.check(lib.mdns_d2h(_lib.ptr(round_sq), d_round, NBOOT * 8), "radius d2h")
-        radius = float(np.sqrt(round_sq.max()))
-        _lib.check(lib.mdns_count_within_dev(d_pool, K, NDIM, radius, d_cands, NCAND, d_counts), "K3")
+        radius = lib.mdns_region_bootstrap_radius_dev(region, d_chosen, NBOOT)    # K6; the one host sync
+        if radius != radius:
+            raise _lib.MdnsError(_lib.last_error())
+        _lib.check(lib.mdns_region_count_dev(region, d_cands, NCAND, d_counts), "K3")
         _lib.check(lib.mdns_gauss_loglike_batch_dev(spectra, d_params, B, 0.01, None, nd, d_L), "K1")
 
     def fence():
@@ -255,6 +256,7 @@ def main():
             res["cpu_baseline"] = cpu_baseline(data, params)
         print(json.dumps(res))
 
+    lib.mdns_region_destroy(region)
     lib.mdns_spectra_destroy(spectra)
     if world > 1:
         dist.destroy_process_group()

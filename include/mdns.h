@@ -123,6 +123,28 @@ int mdns_muse_loglike_batch(mdns_spectra *s, const double *ypred, int B,
 int mdns_muse3_loglike_batch(mdns_spectra *s, const double *params, int B,
                              const int *row_ids, int M, double *Lout);
 
+/* Live-point pool resident on the device: the members of a RadFriends region
+ * (clustering/radfriendsregion.py:59-70 keeps `members` and `maxdistance`; every are_inside /
+ * count_nearby_members call of a region's life re-uses them, radfriendsregion.py:82-98). */
+typedef struct mdns_region mdns_region;
+
+/* members f64[K, ndim] on the host (copied to the device) ... */
+mdns_region *mdns_region_create(const double *members, int K, int ndim);
+/* ... or already on the device (borrowed, not copied: e.g. an all-gathered pool). */
+mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int ndim);
+void mdns_region_destroy(mdns_region *r);
+/* K6 on the resident members (cneighbors.c:125-179): chosen f64[K, nbootstraps] on the host /
+ * on the device.  Returns the radius and keeps it as the region's maxdistance; NaN on failure. */
+double mdns_region_bootstrap_radius(mdns_region *r, const double *chosen, int nbootstraps);
+double mdns_region_bootstrap_radius_dev(mdns_region *r, const double *d_chosen, int nbootstraps);
+/* RadFriendsRegion(members, maxdistance=...) with a given radius (hiermetriclearn.py:54,90). */
+int mdns_region_set_radius(mdns_region *r, double maxdistance);
+double mdns_region_radius(const mdns_region *r);
+/* K3 with the region's radius (cneighbors.c:95-119, no early stop): points f64[M, ndim],
+ * counts int32[M] overwritten.  Host pointers (synchronous) / device pointers (asynchronous). */
+int mdns_region_count(mdns_region *r, const double *points, int M, int *counts);
+int mdns_region_count_dev(mdns_region *r, const double *d_points, int M, int *d_counts);
+
 /* ------------------------------------------------------------------------------------ */
 /* Part 3: raw device entry points (all pointers are DEVICE pointers; asynchronous on the */
 /* library stream; no host synchronisation)                                             */

@@ -21,6 +21,9 @@ ABI_SYMBOLS = (
     "mdns_count_within_distance_of", "mdns_bootstrapped_maxdistance",
     "mdns_spectra_create", "mdns_spectra_destroy", "mdns_spectra_ndata", "mdns_spectra_nx",
     "mdns_gauss_loglike_batch", "mdns_muse_loglike_batch", "mdns_muse3_loglike_batch",
+    "mdns_region_create", "mdns_region_wrap_dev", "mdns_region_destroy",
+    "mdns_region_bootstrap_radius", "mdns_region_bootstrap_radius_dev", "mdns_region_set_radius",
+    "mdns_region_radius", "mdns_region_count", "mdns_region_count_dev",
     "mdns_dev_alloc", "mdns_dev_free", "mdns_h2d", "mdns_d2h", "mdns_sync", "mdns_set_stream",
     "mdns_event_create", "mdns_event_destroy", "mdns_event_record", "mdns_event_elapsed_ms",
     "mdns_profile", "mdns_profile_read",
@@ -60,6 +63,15 @@ def _declare(lib):
         "mdns_gauss_loglike_batch": (i, [vp, vp, i, d, vp, i, vp]),
         "mdns_muse_loglike_batch": (i, [vp, vp, i, vp, i, vp]),
         "mdns_muse3_loglike_batch": (i, [vp, vp, i, vp, i, vp]),
+        "mdns_region_create": (vp, [vp, i, i]),
+        "mdns_region_wrap_dev": (vp, [vp, i, i]),
+        "mdns_region_destroy": (None, [vp]),
+        "mdns_region_bootstrap_radius": (d, [vp, vp, i]),
+        "mdns_region_bootstrap_radius_dev": (d, [vp, vp, i]),
+        "mdns_region_set_radius": (i, [vp, d]),
+        "mdns_region_radius": (d, [vp]),
+        "mdns_region_count": (i, [vp, vp, i, vp]),
+        "mdns_region_count_dev": (i, [vp, vp, i, vp]),
         "mdns_dev_alloc": (vp, [sz]),
         "mdns_dev_free": (None, [vp]),
         "mdns_h2d": (i, [vp, vp, sz]),

@@ -104,3 +104,55 @@ def find_rdistance(u, verbose=False, nbootstraps=15, metric='euclidean'):
     """neighbors.py:229-231: dispatches to the bootstrapped radius."""
     assert metric == 'euclidean', metric
     return bootstrapped_maxdistance(u, nbootstraps)
+
+
+class MemberSet(object):
+    """The members of one RadFriends region, resident on the device for the region's life
+    (``mdns_region_*`` of include/mdns.h): the radius is computed and the many membership
+    tests of ``RadFriendsRegion.generate`` run against the same HBM copy."""
+
+    def __init__(self, members):
+        self._lib = _lib.require_device()
+        members = _pts(members, "members")
+        self.nmembers, self.ndim = members.shape
+        self._h = self._lib.mdns_region_create(_lib.ptr(members), self.nmembers, self.ndim)
+        if not self._h:
+            raise _lib.MdnsError("mdns_region_create failed: " + _lib.last_error())
+
+    def bootstrap_radius(self, chosen):
+        """K6 for a given chosen matrix; the result becomes the set's radius."""
+        chosen = _lib.as_f64(chosen)
+        if chosen.ndim != 2 or chosen.shape[0] != self.nmembers:
+            raise ValueError("chosen must be [nmembers, nbootstraps]")
+        r = self._lib.mdns_region_bootstrap_radius(self._h, _lib.ptr(chosen), chosen.shape[1])
+        if r != r:
+            raise _lib.MdnsError("mdns_region_bootstrap_radius failed: " + _lib.last_error())
+        return r
+
+    def set_radius(self, maxdistance):
+        _lib.check(self._lib.mdns_region_set_radius(self._h, float(maxdistance)), "mdns_region_set_radius")
+
+    def count(self, points):
+        """Number of members strictly within the radius of each point (int array)."""
+        points = _pts(points, "points")
+        if points.shape[1] != self.ndim:
+            raise ValueError("members and points differ in dimension")
+        counts = numpy.zeros(len(points), dtype=numpy.int32)
+        if len(points):
+            _lib.check(self._lib.mdns_region_count(self._h, _lib.ptr(points), len(points), _lib.ptr(counts)),
+                       "mdns_region_count")
+        return counts.astype(int)
+
+    def any(self, points):
+        return self.count(points) > 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mdns_region_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -23,10 +23,14 @@ class RadFriendsRegion(object):
         self.members = members
         self.metric = metric
         self.verbose = verbose
+        self._set = neighbors.MemberSet(members)         # members stay on the device
         if maxdistance is None:
-            # bootstrapped safe radius: 10 numpy.random.choice calls + K6 (radfriendsregion.py:62-64)
-            maxdistance = neighbors.find_rdistance(members, nbootstraps=nbootstraps, metric=metric,
-                                                   verbose=verbose)
+            # bootstrapped safe radius (radfriendsregion.py:62-64 -> neighbors.py:170-177):
+            # nbootstraps numpy.random.choice calls on the global stream, then K6
+            chosen = neighbors.draw_bootstrap_choice(len(members), nbootstraps)
+            maxdistance = self._set.bootstrap_radius(chosen)
+        else:
+            self._set.set_radius(maxdistance)
         self.maxdistance = maxdistance
         self._update_box()
 
@@ -36,19 +40,21 @@ class RadFriendsRegion(object):
 
     def add_members(self, us):
         self.members = numpy.vstack((self.members, us))
+        self._set = neighbors.MemberSet(self.members)
+        self._set.set_radius(self.maxdistance)
         self._update_box()
 
     # ---- membership ------------------------------------------------------------------
     def count_nearby_members(self, us):
-        return neighbors.count_within_distance_of(self.members, self.maxdistance, us)
+        return self._set.count(us)
 
     def are_inside(self, us):
-        return neighbors.any_within_distance_of(self.members, self.maxdistance, us)
+        return self._set.any(us)
 
     def is_inside(self, u):
         if not ((u >= self.lo).all() and (u <= self.hi).all()):
             return False
-        return neighbors.is_within_distance_of(self.members, self.maxdistance, u)
+        return bool(self._set.any(numpy.asarray(u, dtype=float).reshape((1, -1)))[0])
 
     def are_near_members(self, us):
         """Boolean [nmembers, npoints] proximity matrix (diagnostics; not on the hot path)."""

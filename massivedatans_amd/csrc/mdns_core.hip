@@ -752,3 +752,120 @@ extern "C" double mdns_most_distant_nearest_neighbor(const void *xx, int nsample
 	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return NAN;
 	return std::sqrt(sq);
 }
+
+// ---------------------------------------------------------------------------------------
+// resident RadFriends region (members + radius)
+// ---------------------------------------------------------------------------------------
+struct mdns_region {
+	const double *d_members = nullptr;
+	double *owned = nullptr;          // == d_members when this handle allocated them
+	int K = 0, ndim = 0;
+	double radius = NAN;              // maxdistance
+	double thresh_sq = NAN;           // sqrt_threshold(radius)
+	double *d_round = nullptr;        // per-round max of squared nearest-chosen distances
+	int round_cap = 0;
+	double *d_chosen = nullptr; size_t chosen_cap = 0;
+	double *d_points = nullptr; size_t points_cap = 0;
+	int *d_counts = nullptr; size_t counts_cap = 0;
+};
+
+static mdns_region *region_new(const double *d_members, double *owned, int K, int ndim)
+{
+	mdns_region *r = new mdns_region();
+	r->d_members = d_members; r->owned = owned; r->K = K; r->ndim = ndim;
+	return r;
+}
+
+extern "C" mdns_region *mdns_region_create(const double *members, int K, int ndim)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (!members || K <= 0 || ndim <= 0) { set_error("mdns_region_create: bad arguments (K=%d ndim=%d)", K, ndim); return nullptr; }
+	double *d = nullptr;
+	const size_t bytes = (size_t) K * ndim * sizeof(double);
+	if (!MDNS_HIP(hipMalloc((void **) &d, bytes))) return nullptr;
+	if (!MDNS_HIP(hipMemcpyAsync(d, members, bytes, hipMemcpyHostToDevice, c->stream)) ||
+	    !MDNS_HIP(hipStreamSynchronize(c->stream))) { (void) hipFree(d); return nullptr; }
+	return region_new(d, d, K, ndim);
+}
+
+extern "C" mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int ndim)
+{
+	if (!ctx()) return nullptr;
+	if (!d_members || K <= 0 || ndim <= 0) { set_error("mdns_region_wrap_dev: bad arguments"); return nullptr; }
+	return region_new(d_members, nullptr, K, ndim);
+}
+
+extern "C" void mdns_region_destroy(mdns_region *r)
+{
+	if (!r) return;
+	Context *c = ctx();
+	if (c) (void) hipStreamSynchronize(c->stream);
+	void *bufs[] = {r->owned, r->d_round, r->d_chosen, r->d_points, r->d_counts};
+	for (void *b : bufs) if (b) (void) hipFree(b);
+	delete r;
+}
+
+extern "C" int mdns_region_set_radius(mdns_region *r, double maxdistance)
+{
+	if (!r) { set_error("null region"); return 1; }
+	r->radius = maxdistance;
+	r->thresh_sq = sqrt_threshold(maxdistance);
+	return 0;
+}
+
+extern "C" double mdns_region_radius(const mdns_region *r) { return r ? r->radius : NAN; }
+
+extern "C" double mdns_region_bootstrap_radius_dev(mdns_region *r, const double *d_chosen, int nbootstraps)
+{
+	Context *c = ctx();
+	if (!c || !r) return NAN;
+	if (nbootstraps <= 0) { set_error("mdns_region_bootstrap_radius: nbootstraps=%d", nbootstraps); return NAN; }
+	if (r->round_cap < nbootstraps) {
+		if (r->d_round) { (void) hipStreamSynchronize(c->stream); (void) hipFree(r->d_round); r->d_round = nullptr; }
+		if (!MDNS_HIP(hipMalloc((void **) &r->d_round, (size_t) nbootstraps * sizeof(double)))) return NAN;
+		r->round_cap = nbootstraps;
+	}
+	if (!launch_bootstrap(r->d_members, r->K, r->ndim, d_chosen, nbootstraps, r->d_round)) return NAN;
+	double *pin = (double *) pinned_scratch((size_t) nbootstraps * sizeof(double));
+	if (!pin) return NAN;
+	if (!MDNS_HIP(hipMemcpyAsync(pin, r->d_round, (size_t) nbootstraps * sizeof(double), hipMemcpyDeviceToHost, c->stream))) return NAN;
+	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return NAN;
+	double best = 0;          // cneighbors.c:160-174; sqrt after the max (monotone)
+	for (int b = 0; b < nbootstraps; b++) { const double v = std::sqrt(pin[b]); if (v > best) best = v; }
+	mdns_region_set_radius(r, best);
+	return best;
+}
+
+extern "C" double mdns_region_bootstrap_radius(mdns_region *r, const double *chosen, int nbootstraps)
+{
+	Context *c = ctx();
+	if (!c || !r) return NAN;
+	const size_t n = (size_t) r->K * (nbootstraps > 0 ? nbootstraps : 0);
+	if (n == 0) { set_error("mdns_region_bootstrap_radius: nbootstraps=%d", nbootstraps); return NAN; }
+	if (!grow(&r->d_chosen, &r->chosen_cap, n)) return NAN;
+	if (!MDNS_HIP(hipMemcpyAsync(r->d_chosen, chosen, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return NAN;
+	return mdns_region_bootstrap_radius_dev(r, r->d_chosen, nbootstraps);
+}
+
+extern "C" int mdns_region_count_dev(mdns_region *r, const double *d_points, int M, int *d_counts)
+{
+	if (!ctx() || !r) return 1;
+	if (M < 0) { set_error("mdns_region_count: M=%d", M); return 1; }
+	if (M == 0) return 0;
+	if (r->radius != r->radius) { set_error("mdns_region_count: the region has no radius yet"); return 1; }
+	return launch_count_within(r->d_members, r->K, r->ndim, r->thresh_sq, d_points, M, d_counts) ? 0 : 1;
+}
+
+extern "C" int mdns_region_count(mdns_region *r, const double *points, int M, int *counts)
+{
+	Context *c = ctx();
+	if (!c || !r) return 1;
+	if (M <= 0) return M < 0;
+	const size_t n = (size_t) M * r->ndim;
+	if (!grow(&r->d_points, &r->points_cap, n) || !grow(&r->d_counts, &r->counts_cap, (size_t) M)) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(r->d_points, points, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
+	if (mdns_region_count_dev(r, r->d_points, M, r->d_counts) != 0) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(counts, r->d_counts, (size_t) M * sizeof(int), hipMemcpyDeviceToHost, c->stream))) return 1;
+	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
+}

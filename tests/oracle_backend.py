@@ -40,6 +40,28 @@ def patch_neighbors(monkeypatch, oracle):
     def nn(xx):
         return oracle.most_distant_nearest_neighbor(np.ascontiguousarray(xx))
 
+    class OracleMemberSet(object):
+        def __init__(self, members):
+            self.members = np.ascontiguousarray(members, dtype=float)
+            self.radius = None
+
+        def bootstrap_radius(self, chosen):
+            self.radius = boot(self.members, chosen)
+            return self.radius
+
+        def set_radius(self, r):
+            self.radius = float(r)
+
+        def count(self, points):
+            return count(self.members, self.radius, np.atleast_2d(points))
+
+        def any(self, points):
+            return anyw(self.members, self.radius, np.atleast_2d(points))
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(neighbors, "MemberSet", OracleMemberSet)
     monkeypatch.setattr(neighbors, "count_within_distance_of", count)
     monkeypatch.setattr(neighbors, "any_within_distance_of", anyw)
     monkeypatch.setattr(neighbors, "is_within_distance_of", within)

@@ -296,3 +296,29 @@ def test_end_to_end_against_reference_trace(case):
     assert rel_err(results["logZ"], g["logZ"]) < 1e-6
     assert np.max(np.abs(results["logZ"] - g["logZ"])) < 1e-9
     assert np.allclose(results["logZerr"], g["logZerr"], rtol=1e-6, atol=1e-9)
+
+
+def test_region_handle_bit_exact(hip, nb, oracle):
+    """Resident members (mdns_region_*): same numbers as the one-shot entry points."""
+    rng = np.random.RandomState(21)
+    for K, ndim in ((100, 3), (777, 5), (3000, 3)):
+        pts = rng.uniform(size=(K, ndim))
+        ms = nb.MemberSet(pts)
+        chosen = np.zeros((K, 10))
+        for b in range(10):
+            chosen[rng.choice(np.arange(K), size=K, replace=True), b] = 1.
+        r = ms.bootstrap_radius(chosen)
+        assert r == oracle.bootstrapped_maxdistance(pts, chosen)
+        for M in (1, 1000, 4097):
+            cand = rng.uniform(-0.1, 1.1, size=(M, ndim))
+            want = oracle.count_within_distance_of(pts, r, cand).astype(int)
+            assert np.array_equal(ms.count(cand), want)
+            assert np.array_equal(ms.any(cand), want > 0)
+        ms.set_radius(0.5 * r)
+        cand = rng.uniform(size=(500, ndim))
+        assert np.array_equal(ms.count(cand), oracle.count_within_distance_of(pts, 0.5 * r, cand).astype(int))
+        ms.close()
+    # a region without a radius refuses to count
+    ms = nb.MemberSet(rng.uniform(size=(10, 3)))
+    with pytest.raises(_lib.MdnsError):
+        ms.count(rng.uniform(size=(5, 3)))
