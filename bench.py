@@ -107,17 +107,22 @@ def main():
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
 
-    from massivedatans_amd import _lib, gen
-    os.environ.setdefault("MDNS_DEVICE", str(local_rank))
-    lib = _lib.require_device()
-
     dist = None
     torch = None
-    if world > 1:
+    # MDNS_BENCH_FORCE_DIST=1 exercises the collective path with a single rank (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("MDNS_BENCH_FORCE_DIST") == "1"
+    if use_dist:
+        # torch first: it brings its own copy of the HIP runtime (same soname); loaded first it
+        # becomes the one runtime of the process, which libmdns_hip.so then binds to as well
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from massivedatans_amd import _lib, gen
+    os.environ.setdefault("MDNS_DEVICE", str(local_rank))
+    lib = _lib.require_device()
+    if use_dist:
         # kernels and the collective share one stream, so no cross-stream events are needed
         lib.mdns_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
@@ -151,7 +156,7 @@ def main():
     d_params, d_chosen, d_cands = dev(params), dev(chosen), dev(cands)
     d_L = lib.mdns_dev_alloc(B * nd * 8)
     d_counts = lib.mdns_dev_alloc(NCAND * 4)
-    if world > 1:
+    if use_dist:
         assert K % world == 0, "pool size must divide over the ranks"
         t_pool = torch.empty((K, NDIM), dtype=torch.float64, device="cuda")
         t_mine = torch.from_numpy(pool[rank * (K // world):(rank + 1) * (K // world)].copy()).cuda()
@@ -163,7 +168,7 @@ def main():
         raise _lib.MdnsError(_lib.last_error())
 
     def step():
-        if world > 1:
+        if use_dist:
             dist.all_gather_into_tensor(t_pool, t_mine)
         radius = lib.mdns_region_bootstrap_radius_dev(region, d_chosen, NBOOT)    # K6; the one host sync
         if radius != radius:
@@ -173,7 +178,7 @@ def main():
 
     def fence():
         _lib.check(lib.mdns_sync(), "sync")
-        if world > 1:
+        if use_dist:
             torch.cuda.synchronize()
             dist.barrier()
             torch.cuda.synchronize()
@@ -186,13 +191,13 @@ def main():
     for _ in range(args.steps):
         step()
     _lib.check(lib.mdns_sync(), "sync")
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
     lib.mdns_profile(0)
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -258,7 +263,7 @@ def main():
 
     lib.mdns_region_destroy(region)
     lib.mdns_spectra_destroy(spectra)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
