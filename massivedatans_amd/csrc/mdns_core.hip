@@ -421,7 +421,10 @@ extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_par
 	//    spectrum row, reading exactly the selected rows once (k_gauss_rows).
 	// Measured crossover on MI355X, 10 000 x 200: rows 7/12/12/19 us at B = 1/2/4/8, cols ~17 us.
 	static const char *forced = getenv("MDNS_K1_PATH");      // "rows" | "cols": experiments only
-	bool use_cols = s->d_yT && B > 4 && (size_t) M * 8 >= (size_t) s->ndata;
+	// (sparse selections with 32+ candidates also go to the lane kernel, which then gathers
+	// columns: 59 us against 688 us at 10 % of 10 000 spectra and B = 1024)
+	const bool dense = (size_t) M * 8 >= (size_t) s->ndata;
+	bool use_cols = s->d_yT && B > 4 && (dense || B >= 32);
 	if (forced && !strcmp(forced, "rows")) use_cols = false;
 	if (forced && !strcmp(forced, "cols") && s->d_yT) use_cols = true;
 	if (use_cols) {
