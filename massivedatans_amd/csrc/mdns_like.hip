@@ -346,14 +346,32 @@ __device__ __forceinline__ double block_sum4(double v, double *slot /* [4] in LD
 	return (slot[0] + slot[1]) + (slot[2] + slot[3]);
 }
 
-// NP = channel pairs per thread (nx <= 512*NP); W holds 1/v
-template <int NP>
+// sums N values over the 256 threads with ONE barrier: wave shuffles, then 4 x N LDS words.
+// `slot` [4][N] must not be in use by a reduction that other waves may still be reading.
+template <int N>
+__device__ __forceinline__ void block_sums(double (&v)[N], double *slot)
+{
+	const int wv = threadIdx.x >> 6;
+#pragma unroll
+	for (int i = 0; i < N; i++) {
+		const double t = wave_sum(v[i]);
+		if ((threadIdx.x & 63) == 0) slot[wv * N + i] = t;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < N; i++) v[i] = (slot[i] + slot[N + i]) + (slot[2 * N + i] + slot[3 * N + i]);
+}
+
+// NP = channel pairs per thread (nx <= 512*NP); CB = candidates per barrier pair; W holds 1/v.
+// Per candidate and channel: s1 += (y w) m, s2 += (m m) w, then chi += (y - s m)^2 w -- six
+// VALU operations, with y, w and y w resident in registers for all candidates of the row.
+template <int NP, int CB>
 __global__ __launch_bounds__(kBlock) void k_muse_rows(
     const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
     const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M,
     double *__restrict__ out)
 {
-	__shared__ double red[3][4];
+	__shared__ double redA[4 * 2 * CB], redB[4 * CB];
 	const int ch = 2 * threadIdx.x;
 	bool valid[NP];
 #pragma unroll
@@ -362,39 +380,53 @@ __global__ __launch_bounds__(kBlock) void k_muse_rows(
 	for (int k = blockIdx.x; k < M; k += gridDim.x) {
 		const int row = rows ? rows[k] : k;
 		const size_t base = (size_t) row * ld + ch;
-		double2 y[NP], w[NP];
+		double2 y[NP], w[NP], yw[NP];
 #pragma unroll
 		for (int p = 0; p < NP; p++) {
+			// lanes past the last channel hold zeros; for odd nx the pad channel of the last
+			// pair has y = w = 0 too (the buffers are zero-filled before the upload)
 			y[p] = valid[p] ? *reinterpret_cast<const double2 *>(Y + base + p * 512) : make_double2(0.0, 0.0);
 			w[p] = valid[p] ? *reinterpret_cast<const double2 *>(W + base + p * 512) : make_double2(0.0, 0.0);
+			yw[p] = make_double2(y[p].x * w[p].x, y[p].y * w[p].y);
 		}
-		// nx odd: the pad channel of the last pair must not contribute (its 1/v is garbage-free
-		// zero because the W buffer is zero-filled before the upload)
-		for (int b = 0; b < B; b++) {
-			double2 m[NP];
-			double s1 = 0.0, s2 = 0.0;
+		for (int b0 = 0; b0 < B; b0 += CB) {
+			double2 m[CB][NP];
+			double sums[2 * CB];
 #pragma unroll
-			for (int p = 0; p < NP; p++) {
-				m[p] = *reinterpret_cast<const double2 *>(model + (size_t) b * ldm + p * 512 + ch);
-				s1 = fma(y[p].x * m[p].x, w[p].x, s1);
-				s1 = fma(y[p].y * m[p].y, w[p].y, s1);
-				s2 = fma(m[p].x * m[p].x, w[p].x, s2);
-				s2 = fma(m[p].y * m[p].y, w[p].y, s2);
-			}
-			const double t1 = block_sum4(s1, red[0]);
-			const double t2 = block_sum4(s2, red[1]);
-			const double s = t1 / (1e-10 + t2);           // cmuselike.c:52,57
-			double chi = 0.0;
+			for (int c = 0; c < CB; c++) {
+				const int b = (b0 + c < B) ? b0 + c : B - 1;
+				double s1 = 0.0, s2 = 0.0;
 #pragma unroll
-			for (int p = 0; p < NP; p++) {
-				const double r0 = y[p].x - s * m[p].x;
-				const double r1 = y[p].y - s * m[p].y;
-				chi = fma(r0 * r0, w[p].x, chi);
-				chi = fma(r1 * r1, w[p].y, chi);
+				for (int p = 0; p < NP; p++) {
+					m[c][p] = *reinterpret_cast<const double2 *>(model + (size_t) b * ldm + p * 512 + ch);
+					s1 = fma(yw[p].x, m[c][p].x, s1);
+					s1 = fma(yw[p].y, m[c][p].y, s1);
+					s2 = fma(m[c][p].x * m[c][p].x, w[p].x, s2);
+					s2 = fma(m[c][p].y * m[c][p].y, w[p].y, s2);
+				}
+				sums[2 * c] = s1;
+				sums[2 * c + 1] = s2;
 			}
-			const double tot = block_sum4(chi, red[2]);
-			if (threadIdx.x == 0) out[(size_t) b * M + k] = -0.5 * tot;
-			// red[0] is rewritten only after every wave passed the two later barriers
+			block_sums<2 * CB>(sums, redA);
+			double chi[CB];
+#pragma unroll
+			for (int c = 0; c < CB; c++) {
+				const double s = sums[2 * c] / (1e-10 + sums[2 * c + 1]);      // cmuselike.c:52,57
+				double acc = 0.0;
+#pragma unroll
+				for (int p = 0; p < NP; p++) {
+					const double r0 = fma(-s, m[c][p].x, y[p].x);
+					const double r1 = fma(-s, m[c][p].y, y[p].y);
+					acc = fma(r0 * r0, w[p].x, acc);
+					acc = fma(r1 * r1, w[p].y, acc);
+				}
+				chi[c] = acc;
+			}
+			// redA may be rewritten by the next round only after everybody read it: they all
+			// did before arriving at the barrier inside this call
+			block_sums<CB>(chi, redB);
+			if (threadIdx.x < CB && b0 + threadIdx.x < B)
+				out[(size_t) (b0 + threadIdx.x) * M + k] = -0.5 * (threadIdx.x == 0 ? chi[0] : chi[CB - 1]);
 		}
 	}
 }
@@ -581,8 +613,10 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 	int blocks = M < c->num_cus * 8 ? M : c->num_cus * 8;
 	if (blocks < 1) blocks = 1;
 	ProfileScope prof(1);
-#define MUSE_LAUNCH(NP) hipLaunchKernelGGL((k_muse_rows<NP>), dim3(blocks), dim3(kBlock), 0, c->stream, \
-	s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out)
+#define MUSE_LAUNCH(NP) do { if (B >= 2) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
+	else hipLaunchKernelGGL((k_muse_rows<NP, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); } while (0)
 	if (nx <= 512) MUSE_LAUNCH(1);
 	else if (nx <= 1024) MUSE_LAUNCH(2);
 	else if (nx <= 2048) MUSE_LAUNCH(4);

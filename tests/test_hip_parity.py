@@ -322,3 +322,80 @@ def test_region_handle_bit_exact(hip, nb, oracle):
     ms = nb.MemberSet(rng.uniform(size=(10, 3)))
     with pytest.raises(_lib.MdnsError):
         ms.count(rng.uniform(size=(5, 3)))
+
+
+def test_dropin_cmuselike_and_cneighbors_shims(golden, oracle):
+    """The other two shim libraries, bound exactly as musefuse.py:509-517 and
+    clustering/neighbors.py:100-166 bind the reference's."""
+    nd_ = np.ctypeslib.ndpointer
+    f2 = nd_(dtype=np.float64, ndim=2, flags='C_CONTIGUOUS')
+    f1 = nd_(dtype=np.float64, ndim=1, flags='C_CONTIGUOUS')
+    lm = C.CDLL(os.path.join(_lib.DROPIN_DIR, "cmuselike.so"))
+    lm.like.argtypes = [f2, f2, f1, nd_(dtype=np.bool_, ndim=1, flags='C_CONTIGUOUS'), C.c_int, C.c_int, f1]
+    yy, vv = golden["k2_y"], golden["k2_v"]
+    nx, nd = yy.shape
+    m = np.ascontiguousarray(golden["k2_masks"][1])
+    Lout = np.zeros(nd)
+    assert lm.like(yy, vv, np.ascontiguousarray(golden["k2_ypred"][0]), m, nd, nx, Lout) == 0
+    assert rel_err(Lout[m], golden["k2_out1"][0][m]) < 1e-11 and np.all(Lout[~m] == 0)
+
+    ln = C.CDLL(os.path.join(_lib.DROPIN_DIR, "cneighbors.so"))
+    ln.most_distant_nearest_neighbor.argtypes = [f2, C.c_int, C.c_int]
+    ln.most_distant_nearest_neighbor.restype = C.c_double
+    ln.is_within_distance_of.argtypes = [f2, C.c_int, C.c_int, C.c_double, f1]
+    ln.is_within_distance_of.restype = C.c_int
+    ln.count_within_distance_of.argtypes = [f2, C.c_int, C.c_int, C.c_double, f2, C.c_int, f1, C.c_int]
+    ln.bootstrapped_maxdistance.argtypes = [f2, C.c_int, C.c_int, f2, C.c_int]
+    ln.bootstrapped_maxdistance.restype = C.c_double
+    pts = golden["k6_d3_pts"]
+    assert ln.most_distant_nearest_neighbor(pts, len(pts), 3) == float(golden["k6_d3_nn"])
+    chosen = np.ascontiguousarray(golden["k6_d3_chosen"][0])
+    assert ln.bootstrapped_maxdistance(pts, len(pts), 3, chosen, 10) == golden["k6_d3_radius"][0]
+    mem, cand, r = golden["k3_d3_members"], golden["k3_d3_cands"], float(golden["k3_d3_r"])
+    counts = np.zeros(len(cand))
+    assert ln.count_within_distance_of(mem, len(mem), 3, r, cand, len(cand), counts, 0) == 0
+    assert np.array_equal(counts, golden["k3_d3_count0"])
+    assert ln.is_within_distance_of(mem, len(mem), 3, r, np.ascontiguousarray(cand[0])) == int(golden["k3_d3_any"][0])
+
+
+def test_registered_spectra_are_reused(hip, golden):
+    """mdns_register_spectra: later drop-in like() calls with the same pointer use the resident
+    copy (and follow the x passed with each call, as clike.c:35 takes it per call)."""
+    x, y = golden["k1_horns_x"], golden["k1_horns_y"]
+    nx, nd = y.shape
+    m = np.ones(nd, dtype=np.bool_)
+    p = golden["k1_horns_params"][2]
+    assert hip.mdns_register_spectra(_lib.ptr(y), None, nd, nx) == 0
+    try:
+        for xs in (x, x + 3.0):
+            out = np.zeros(nd)
+            assert hip.mdns_gauss_like(_lib.ptr(xs), _lib.ptr(y), nd, nx, p[0], p[1], 10 ** p[2], 0.01,
+                                       _lib.ptr(m), _lib.ptr(out)) == 0
+            ypred = p[0] * np.exp(-0.5 * ((p[1] - xs) / 10 ** p[2]) ** 2)
+            want = (((ypred.reshape((-1, 1)) - y) / 0.01) ** 2).sum(axis=0)
+            assert rel_err(out, want) < 1e-12
+    finally:
+        assert hip.mdns_unregister_spectra(_lib.ptr(y)) == 0
+    assert hip.mdns_unregister_spectra(_lib.ptr(y)) != 0
+
+
+def test_c4_size_single_gpu():
+    """100 000 spectra (config C4's total) on one GPU: sizes, indexing and the XCD tiling at a
+    grid 10x larger than the bench's; checked by properties (no oracle at this size)."""
+    from massivedatans_amd.like import GaussLineSpectra
+    d = gen.nothing(100000)
+    sp = GaussLineSpectra(d["x"], d["y"])
+    rng = np.random.RandomState(8)
+    params = np.column_stack([rng.uniform(0.01, 1, 40), rng.uniform(400, 800, 40), 10 ** rng.uniform(0, 2, 40)])
+    full = sp.loglike_batch(params)                                  # lane kernel
+    assert full.shape == (40, 100000) and np.all(np.isfinite(full))
+    one = sp.loglike_batch(params[3:4])[0]                           # row kernel
+    assert rel_err(one, full[3]) < 1e-13
+    cols = rng.choice(100000, size=257, replace=False)
+    ypred = params[3, 0] * np.exp(-0.5 * ((params[3, 1] - d["x"]) / params[3, 2]) ** 2)
+    want = -0.5 * (((ypred.reshape((-1, 1)) - d["y"][:, cols]) / 0.01) ** 2).sum(axis=0)
+    assert rel_err(full[3, cols], want) < 1e-12
+    m = np.zeros(100000, bool)
+    m[cols] = True
+    assert np.array_equal(sp.loglike_batch(params, m), full[:, m])   # 40 candidates, sparse: lane kernel + gather
+    sp.close()
