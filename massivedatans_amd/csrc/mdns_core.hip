@@ -414,17 +414,17 @@ extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_par
 	if (B == 0 || M == 0) return 0;
 	const double scale = -0.5 / (noise_level * noise_level);
 	// Two kernels, chosen by shape only (never by data), so a run is reproducible:
-	//  * batches of 5+ candidates on dense selections (at least one spectrum in eight) are
-	//    arithmetic-bound: one LANE per spectrum on the channel-major replica, templates as
-	//    scalar operands (k_gauss_cols);
-	//  * 1-4 candidates, or sparse selections, are bandwidth/latency-bound: one WAVE per
+	//  * batches of 12+ candidates on dense selections (at least one spectrum in eight), and
+	//    batches of 32+ on any selection, are arithmetic-bound: one LANE per spectrum on the
+	//    channel-major replica, templates as scalar operands (k_gauss_cols);
+	//  * few candidates, or sparse selections, are bandwidth/latency-bound: one WAVE per
 	//    spectrum row, reading exactly the selected rows once (k_gauss_rows).
-	// Measured crossover on MI355X, 10 000 x 200: rows 7/12/12/19 us at B = 1/2/4/8, cols ~17 us.
+	// Measured on MI355X, 10 000 x 200, all spectra: rows 6.8 / 8.7 / 12.3 / 18.9 us at
+	// B = 1 / 4 / 8 / 16, cols 16.9 / 17.3 / 19.2 us at B = 8 / 16 / 32; at 10 % of the spectra
+	// and B = 1024: cols 59 us, rows 688 us.
 	static const char *forced = getenv("MDNS_K1_PATH");      // "rows" | "cols": experiments only
-	// (sparse selections with 32+ candidates also go to the lane kernel, which then gathers
-	// columns: 59 us against 688 us at 10 % of 10 000 spectra and B = 1024)
 	const bool dense = (size_t) M * 8 >= (size_t) s->ndata;
-	bool use_cols = s->d_yT && B > 4 && (dense || B >= 32);
+	bool use_cols = s->d_yT && ((dense && B >= 12) || B >= 32);
 	if (forced && !strcmp(forced, "rows")) use_cols = false;
 	if (forced && !strcmp(forced, "cols") && s->d_yT) use_cols = true;
 	if (use_cols) {

@@ -21,11 +21,31 @@ namespace mdns {
 
 static constexpr int kBlock = 256;
 
+// Sum over the 64 lanes of a wavefront, returned in every lane (wave-uniform).
+// Data-parallel primitives (DPP) move the partial sums inside the VALU -- no LDS crossbar
+// round trips as with ds_bpermute shuffles, which made reductions the longest part of the row
+// kernels.  Steps: the two quad permutations, row_shr:4, row_shr:8 (each 16-lane row now has its
+// sum in lanes 12-15), row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lane 63
+// holds the total.  Lanes without a source receive 0 (bound_ctrl), the identity of the sum.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v)
+{
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+	return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-	for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-	return v;
+	v += dpp_move<0xb1, 0xf>(v);      // quad_perm:[1,0,3,2]
+	v += dpp_move<0x4e, 0xf>(v);      // quad_perm:[2,3,0,1]
+	v += dpp_move<0x114, 0xf>(v);     // row_shr:4
+	v += dpp_move<0x118, 0xf>(v);     // row_shr:8
+	v += dpp_move<0x142, 0xa>(v);     // row_bcast:15 -> rows 1, 3
+	v += dpp_move<0x143, 0xc>(v);     // row_bcast:31 -> rows 2, 3
+	const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+	const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+	return __hiloint2double(hi, lo);
 }
 
 // ---------------------------------------------------------------------------------------

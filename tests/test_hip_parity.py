@@ -109,22 +109,24 @@ def test_k1_full_size_properties():
     d = gen.horns(10000)
     sp = GaussLineSpectra(d["x"], d["y"])
     rng = np.random.RandomState(5)
-    params = np.column_stack([rng.uniform(0.01, 1, 16), rng.uniform(400, 800, 16), 10 ** rng.uniform(0, 2, 16)])
+    params = np.column_stack([rng.uniform(0.01, 1, 32), rng.uniform(400, 800, 32), 10 ** rng.uniform(0, 2, 32)])
     full = sp.loglike_batch(params)
-    assert full.shape == (16, 10000) and np.all(np.isfinite(full)) and np.all(full <= 0)
-    # (1) batching is transparent: any split into batches of 5+ candidates runs the same
-    # per-spectrum summation and is bitwise identical; single candidates take the row kernel
+    assert full.shape == (32, 10000) and np.all(np.isfinite(full)) and np.all(full <= 0)
+    # (1) batching is transparent: any split into batches of 12+ candidates runs the same
+    # per-spectrum summation and is bitwise identical; small batches take the row kernel
     # (tree sum) and agree to rounding
-    assert np.array_equal(sp.loglike_batch(params[:8]), full[:8])
-    assert np.array_equal(sp.loglike_batch(params[5:16]), full[5:16])
-    for b in (0, 7, 15):
+    assert np.array_equal(sp.loglike_batch(params[:16]), full[:16])
+    assert np.array_equal(sp.loglike_batch(params[12:32]), full[12:32])
+    assert rel_err(sp.loglike_batch(params[3:9]), full[3:9]) < 1e-13
+    for b in (0, 7, 31):
         assert rel_err(sp.loglike_batch(params[b:b + 1])[0], full[b]) < 1e-13
     # (2) masking is a gather of the full result: bitwise for dense selections (same kernel,
     # same per-spectrum summation order), to rounding for sparse ones (row kernel, tree sum)
     m = rng.uniform(size=10000) < 0.5
     assert np.array_equal(sp.loglike_batch(params, m), full[:, m])
     m = rng.uniform(size=10000) < 0.01
-    assert rel_err(sp.loglike_batch(params, m), full[:, m]) < 1e-13
+    assert np.array_equal(sp.loglike_batch(params, m), full[:, m])          # 32 candidates: lane kernel + gather
+    assert rel_err(sp.loglike_batch(params[:20], m), full[:20, m]) < 1e-13  # sparse, < 32: row kernel
     # (3) A -> 0 reproduces the closed-form null evidence of plotevidences.py:17
     null = sp.loglike_batch(np.array([[0.0, 600., 5.0]]))[0]
     want = (-0.5 * (d["y"] / 0.01) ** 2).sum(axis=0)
