@@ -87,6 +87,42 @@ def cpu_baseline(data, params, budget_s=12.0):
     return res
 
 
+def hbm_regime_leg(lib, _lib, ndata=1000000, nx=200, reps=20):
+    """The one-pass (B = 1) row kernel on spectra that do NOT fit the 256 MiB Infinity Cache:
+    1 000 000 x 200 doubles = 1.6 GB streamed from HBM per launch.  This is the HBM-bound
+    regime of K1 (1608 algorithmic bytes per eval = the bytes physically moved)."""
+    rng = np.random.RandomState(ndata)
+    x = np.linspace(400, 800, nx)
+    y = np.ascontiguousarray(rng.normal(0, 0.01, size=(ndata, nx)))
+    sp = lib.mdns_spectra_create(_lib.ptr(x), _lib.ptr(y), None, ndata, nx, 1)
+    if not sp:
+        return {"error": _lib.last_error()}
+    del y
+    p = np.array([[0.3, 640.0, 5.0]])
+    d_p = lib.mdns_dev_alloc(p.nbytes)
+    lib.mdns_h2d(d_p, _lib.ptr(p), p.nbytes)
+    d_L = lib.mdns_dev_alloc(ndata * 8)
+    for _ in range(3):
+        lib.mdns_gauss_loglike_batch_dev(sp, d_p, 1, 0.01, None, ndata, d_L)
+    lib.mdns_sync()
+    lib.mdns_profile(1)
+    for _ in range(reps):
+        lib.mdns_gauss_loglike_batch_dev(sp, d_p, 1, 0.01, None, ndata, d_L)
+    lib.mdns_sync()
+    n, ms = C.c_longlong(0), C.c_double(0)
+    lib.mdns_profile_read(0, C.byref(n), C.byref(ms))
+    lib.mdns_profile(0)
+    us = 1e3 * ms.value / max(1, n.value)
+    lib.mdns_dev_free(d_p)
+    lib.mdns_dev_free(d_L)
+    lib.mdns_spectra_destroy(sp)
+    gbs = ndata * (8 * nx + 8) / (us * 1e-6) / 1e9
+    return {"kernel": "k_gauss_rows", "workload": "%d spectra x %d channels (%.1f GB > 256 MiB Infinity Cache), "
+                                                  "1 candidate per pass" % (ndata, nx, ndata * nx * 8 / 1e9),
+            "bound": "hbm", "launch_us": us, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": gbs / HBM_PEAK_GBS, "evals_per_s": ndata / (us * 1e-6)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +132,7 @@ def main():
     ap.add_argument("--ndata", type=int, default=10000, help="spectra per GPU")
     ap.add_argument("--pool", type=int, default=4 * NLIVE, help="unique live points in the pool (K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1.6 GB one-pass HBM-regime measurement")
     ap.add_argument("--workload", default="horns", choices=["horns", "nothing"])
     args = ap.parse_args()
 
@@ -257,6 +294,8 @@ def main():
                                  "(effective, not physical, bandwidth); frac_physical counts bytes actually moved"},
         }
         res.update(other)
+        if not args.no_hbm_leg and world == 1:
+            res["roofline_hbm_regime"] = hbm_regime_leg(lib, _lib)
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(data, params)
         print(json.dumps(res))

@@ -3,7 +3,7 @@
 of each hot-path kernel over sweeps of batch size, mask density and pool size, measured with
 HIP events on the launch stream (mdns_profile).  One JSON line per case.
 
-    python bench_kernels.py [k1] [k2] [k3] [k6]      (default: all)
+    python bench_kernels.py [k1] [k1big] [k2] [k3] [k6]      (default: k1 k2 k3 k6)
 """
 import ctypes as C
 import json
@@ -65,6 +65,33 @@ def k1(lib, ndata=10000):
     lib.mdns_spectra_destroy(sp)
 
 
+def k1big(lib, ndata=1000000):
+    """K1 on a spectra set far larger than the 256 MiB Infinity Cache (1.6 GB): the
+    HBM-bound regime of the row kernel (one pass, B = 1..4) and of the lane kernel."""
+    nx = 200
+    rng = np.random.RandomState(ndata)
+    x = gen.wavelength_grid()
+    y = np.ascontiguousarray(rng.normal(0, 0.01, size=(ndata, nx)))      # [ndata, nx]: no transpose needed
+    sp = lib.mdns_spectra_create(_lib.ptr(x), _lib.ptr(y), None, ndata, nx, 1)
+    if not sp:
+        raise _lib.MdnsError(_lib.last_error())
+    for B in (1, 2, 4, 16, 64, 256):
+        cube = rng.uniform(size=(B, 3))
+        params = np.column_stack([10 ** (cube[:, 0] * 2 - 2), cube[:, 1] * 400 + 400, 10 ** (cube[:, 2] * 2)])
+        d_p = dev(lib, params)
+        d_L = lib.mdns_dev_alloc(B * ndata * 8)
+        us = timed(lib, 0, lambda: lib.mdns_gauss_loglike_batch_dev(sp, d_p, B, 0.01, None, ndata, d_L), reps=10)
+        evals = B * ndata
+        print(json.dumps({"kernel": "K1", "ndata": ndata, "nx": nx, "mask": 1.0, "M": ndata, "B": B, "us": us,
+                          "evals_per_s": evals / (us * 1e-6),
+                          "alg_GBps": evals * (8 * nx + 8) / (us * 1e-6) / 1e9,
+                          "phys_GBps": (ndata * nx * 8 + evals * 8) / (us * 1e-6) / 1e9,
+                          "fp64_valu_frac": 3.0 * nx * evals / (us * 1e-6) / 78.6e12}), flush=True)
+        lib.mdns_dev_free(d_p)
+        lib.mdns_dev_free(d_L)
+    lib.mdns_spectra_destroy(sp)
+
+
 def k2(lib, ndata=4096, nx=4096):
     cube = gen.muse_like(ndata, nx=nx)
     sp = lib.mdns_spectra_create(_lib.ptr(cube["x"]), _lib.ptr(cube["y"]), _lib.ptr(cube["v"]), ndata, nx, 0)
@@ -119,6 +146,8 @@ def main():
     lib = _lib.require_device()
     if "k1" in which:
         k1(lib)
+    if "k1big" in which:
+        k1big(lib)
     if "k2" in which:
         k2(lib)
     if "k3" in which or "k6" in which:

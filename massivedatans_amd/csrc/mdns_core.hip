@@ -424,7 +424,9 @@ extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_par
 	// and B = 1024: cols 59 us, rows 688 us.
 	static const char *forced = getenv("MDNS_K1_PATH");      // "rows" | "cols": experiments only
 	const bool dense = (size_t) M * 8 >= (size_t) s->ndata;
-	bool use_cols = s->d_yT && ((dense && B >= 12) || B >= 32);
+	// dense: the lane kernel pays a ~17 us pipeline fill, the row kernel ~6.5 us plus more per
+	// eval; they cross near 1.5e5 evals (B = 12 at 10 000 spectra, B = 2 at 100 000: 27 vs 38 us)
+	bool use_cols = s->d_yT && ((dense && B >= 2 && (long long) M * B >= 150000) || B >= 32);
 	if (forced && !strcmp(forced, "rows")) use_cols = false;
 	if (forced && !strcmp(forced, "cols") && s->d_yT) use_cols = true;
 	if (use_cols) {

@@ -401,3 +401,25 @@ def test_c4_size_single_gpu():
     m[cols] = True
     assert np.array_equal(sp.loglike_batch(params, m), full[:, m])   # 40 candidates, sparse: lane kernel + gather
     sp.close()
+
+
+@pytest.mark.parametrize("nd,nx,B", [(5000, 37, 40), (4100, 200, 50), (2500, 9, 80)])
+def test_k1_lane_kernel_vs_oracle(oracle, nd, nx, B):
+    """Shapes that dispatch to the lane-per-spectrum kernel (M*B >= 150 000), including channel
+    counts that are not multiples of the pipeline depth and spectra counts that are not multiples
+    of 64, full and gathered (dense mask) selections."""
+    from massivedatans_amd.like import GaussLineSpectra
+    rng = np.random.RandomState(nd + nx)
+    x = np.sort(rng.uniform(400, 800, nx))
+    y = np.ascontiguousarray(rng.normal(0, 0.05, size=(nx, nd)))
+    sp = GaussLineSpectra(x, y, noise_level=0.01)
+    params = np.column_stack([rng.uniform(0.01, 1, B), rng.uniform(400, 800, B), 10 ** rng.uniform(0, 2, B)])
+    full_mask = np.ones(nd, bool)
+    dense = rng.uniform(size=nd) < 0.8
+    for mask in (full_mask, dense):
+        assert mask.sum() * B >= 150000
+        got = sp.loglike_batch(params, mask)
+        for b in (0, B // 2, B - 1):
+            want = -0.5 * oracle.gauss_like(x, y, params[b, 0], params[b, 1], params[b, 2], 0.01, mask)
+            assert rel_err(got[b], want) < RTOL_L
+    sp.close()
