@@ -566,6 +566,15 @@ extern "C" int mdns_unregister_spectra(const void *yy)
 	return 1;
 }
 
+// MDNS_ASSUME_STATIC_SPECTRA=1: the drop-in like() calls register every spectra array they
+// see (by pointer and shape) instead of uploading it on each call -- for hosts such as the
+// reference's sample.py / musefuse.py, which load their data once and never modify it
+static bool assume_static_spectra()
+{
+	static const char *e = getenv("MDNS_ASSUME_STATIC_SPECTRA");
+	return e && *e && *e != '0';
+}
+
 // mask (C bool per data set) -> ascending row ids; returns the count
 static int mask_to_rows(const void *data_mask, int ndata, std::vector<int> &rows)
 {
@@ -584,6 +593,8 @@ extern "C" int mdns_gauss_like(const void *xp, const void *yyp, int ndata, int n
 	const int M = mask_to_rows(data_maskp, ndata, rows);
 	if (M == 0 || nx <= 0) return 0;
 	mdns_spectra *s = find_registered(yyp, nullptr, ndata, nx);
+	if (!s && assume_static_spectra() && mdns_register_spectra(yyp, nullptr, ndata, nx) == 0)
+		s = find_registered(yyp, nullptr, ndata, nx);
 	const bool temporary = (s == nullptr);
 	if (temporary) {
 		s = mdns_spectra_create((const double *) xp, (const double *) yyp, nullptr, ndata, nx,
@@ -615,6 +626,8 @@ extern "C" int mdns_muse_like(const void *yyp, const void *vvp, const void *ypre
 	const int M = mask_to_rows(data_maskp, ndata, rows);
 	if (M == 0) return 0;
 	mdns_spectra *s = find_registered(yyp, vvp, ndata, nx);
+	if (!s && assume_static_spectra() && mdns_register_spectra(yyp, vvp, ndata, nx) == 0)
+		s = find_registered(yyp, vvp, ndata, nx);
 	const bool temporary = (s == nullptr);
 	if (temporary) {
 		s = mdns_spectra_create(nullptr, (const double *) yyp, (const double *) vvp, ndata, nx,
