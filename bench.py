@@ -207,11 +207,14 @@ def main():
     def step():
         if use_dist:
             dist.all_gather_into_tensor(t_pool, t_mine)
-        radius = lib.mdns_region_bootstrap_radius_dev(region, d_chosen, NBOOT)    # K6; the one host sync
-        if radius != radius:
-            raise _lib.MdnsError(_lib.last_error())
+        # K6, then radius + membership threshold finished on the device: K3 follows in stream order
+        _lib.check(lib.mdns_region_bootstrap_radius_async(region, d_chosen, NBOOT), "K6")
         _lib.check(lib.mdns_region_count_dev(region, d_cands, NCAND, d_counts), "K3")
         _lib.check(lib.mdns_gauss_loglike_batch_dev(spectra, d_params, B, 0.01, None, nd, d_L), "K1")
+        # the host needs the radius (bounding box of the next proposals): fetched while K1 runs
+        radius = lib.mdns_region_radius(region)
+        if radius != radius:
+            raise _lib.MdnsError(_lib.last_error())
 
     def fence():
         _lib.check(lib.mdns_sync(), "sync")

@@ -137,9 +137,14 @@ void mdns_region_destroy(mdns_region *r);
  * on the device.  Returns the radius and keeps it as the region's maxdistance; NaN on failure. */
 double mdns_region_bootstrap_radius(mdns_region *r, const double *chosen, int nbootstraps);
 double mdns_region_bootstrap_radius_dev(mdns_region *r, const double *d_chosen, int nbootstraps);
+/* The same without waiting: radius and membership threshold are finished ON the device, so a
+ * following mdns_region_count_dev needs no host round trip; mdns_region_radius() then waits
+ * for and returns the value (the host needs it for the bounding box, radfriendsregion.py:69).
+ * Returns 0 when enqueued. */
+int mdns_region_bootstrap_radius_async(mdns_region *r, const double *d_chosen, int nbootstraps);
 /* RadFriendsRegion(members, maxdistance=...) with a given radius (hiermetriclearn.py:54,90). */
 int mdns_region_set_radius(mdns_region *r, double maxdistance);
-double mdns_region_radius(const mdns_region *r);
+double mdns_region_radius(mdns_region *r);
 /* K3 with the region's radius (cneighbors.c:95-119, no early stop): points f64[M, ndim],
  * counts int32[M] overwritten.  Host pointers (synchronous) / device pointers (asynchronous). */
 int mdns_region_count(mdns_region *r, const double *points, int M, int *counts);

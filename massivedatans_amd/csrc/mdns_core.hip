@@ -654,7 +654,7 @@ extern "C" int mdns_count_within_dev(const double *d_members, int K, int ndim, d
 	if (K < 0 || M < 0 || ndim <= 0) { set_error("mdns_count_within_dev: bad sizes"); return 1; }
 	if (M == 0) return 0;
 	if (K == 0) return MDNS_HIP(hipMemsetAsync(d_counts, 0, (size_t) M * sizeof(int), c->stream)) ? 0 : 1;
-	return launch_count_within(d_members, K, ndim, sqrt_threshold(maxdistance), d_cands, M, d_counts) ? 0 : 1;
+	return launch_count_within(d_members, K, ndim, sqrt_threshold(maxdistance), nullptr, d_cands, M, d_counts) ? 0 : 1;
 }
 
 extern "C" int mdns_bootstrap_round_maxsq_dev(const double *d_members, int K, int ndim,
@@ -778,8 +778,15 @@ struct mdns_region {
 	const double *d_members = nullptr;
 	double *owned = nullptr;          // == d_members when this handle allocated them
 	int K = 0, ndim = 0;
-	double radius = NAN;              // maxdistance
-	double thresh_sq = NAN;           // sqrt_threshold(radius)
+	double radius = NAN;              // maxdistance, host copy
+	double thresh_sq = NAN;           // membership threshold on squared distances, host copy
+	// device copy {radius, threshold}: written by k_radius_threshold, so that the membership
+	// kernel can follow the radius kernel on the stream without a host round trip
+	double *d_state = nullptr;
+	bool on_device = false;           // d_state is what the membership kernel must read
+	bool pending = false;             // the host copies still have to be fetched (async path)
+	double *h_state = nullptr;        // pinned, 2 doubles
+	hipEvent_t ready = nullptr;
 	double *d_round = nullptr;        // per-round max of squared nearest-chosen distances
 	int round_cap = 0;
 	double *d_chosen = nullptr; size_t chosen_cap = 0;
@@ -791,6 +798,10 @@ static mdns_region *region_new(const double *d_members, double *owned, int K, in
 {
 	mdns_region *r = new mdns_region();
 	r->d_members = d_members; r->owned = owned; r->K = K; r->ndim = ndim;
+	bool ok = MDNS_HIP(hipMalloc((void **) &r->d_state, 2 * sizeof(double)));
+	ok = ok && MDNS_HIP(hipHostMalloc((void **) &r->h_state, 2 * sizeof(double), hipHostMallocDefault));
+	ok = ok && MDNS_HIP(hipEventCreateWithFlags(&r->ready, hipEventDisableTiming));
+	if (!ok) { mdns_region_destroy(r); return nullptr; }
 	return r;
 }
 
@@ -819,8 +830,10 @@ extern "C" void mdns_region_destroy(mdns_region *r)
 	if (!r) return;
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
-	void *bufs[] = {r->owned, r->d_round, r->d_chosen, r->d_points, r->d_counts};
+	void *bufs[] = {r->owned, r->d_state, r->d_round, r->d_chosen, r->d_points, r->d_counts};
 	for (void *b : bufs) if (b) (void) hipFree(b);
+	if (r->h_state) (void) hipHostFree(r->h_state);
+	if (r->ready) (void) hipEventDestroy(r->ready);
 	delete r;
 }
 
@@ -829,30 +842,51 @@ extern "C" int mdns_region_set_radius(mdns_region *r, double maxdistance)
 	if (!r) { set_error("null region"); return 1; }
 	r->radius = maxdistance;
 	r->thresh_sq = sqrt_threshold(maxdistance);
+	r->on_device = false;
+	r->pending = false;
 	return 0;
 }
 
-extern "C" double mdns_region_radius(const mdns_region *r) { return r ? r->radius : NAN; }
+// host copies of {radius, threshold}; waits for the device when they are still in flight
+static bool region_fetch(mdns_region *r)
+{
+	if (!r->pending) return true;
+	if (!MDNS_HIP(hipEventSynchronize(r->ready))) return false;
+	r->radius = r->h_state[0];
+	r->thresh_sq = r->h_state[1];
+	r->pending = false;
+	return true;
+}
+
+extern "C" double mdns_region_radius(mdns_region *r)
+{
+	if (!r || !ctx() || !region_fetch(r)) return NAN;
+	return r->radius;
+}
+
+extern "C" int mdns_region_bootstrap_radius_async(mdns_region *r, const double *d_chosen, int nbootstraps)
+{
+	Context *c = ctx();
+	if (!c || !r) return 1;
+	if (nbootstraps <= 0) { set_error("mdns_region_bootstrap_radius: nbootstraps=%d", nbootstraps); return 1; }
+	if (r->round_cap < nbootstraps) {
+		if (r->d_round) { (void) hipStreamSynchronize(c->stream); (void) hipFree(r->d_round); r->d_round = nullptr; }
+		if (!MDNS_HIP(hipMalloc((void **) &r->d_round, (size_t) nbootstraps * sizeof(double)))) return 1;
+		r->round_cap = nbootstraps;
+	}
+	if (!launch_bootstrap(r->d_members, r->K, r->ndim, d_chosen, nbootstraps, r->d_round)) return 1;
+	if (!launch_radius_threshold(r->d_round, nbootstraps, r->d_state)) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(r->h_state, r->d_state, 2 * sizeof(double), hipMemcpyDeviceToHost, c->stream))) return 1;
+	if (!MDNS_HIP(hipEventRecord(r->ready, c->stream))) return 1;
+	r->on_device = true;
+	r->pending = true;
+	return 0;
+}
 
 extern "C" double mdns_region_bootstrap_radius_dev(mdns_region *r, const double *d_chosen, int nbootstraps)
 {
-	Context *c = ctx();
-	if (!c || !r) return NAN;
-	if (nbootstraps <= 0) { set_error("mdns_region_bootstrap_radius: nbootstraps=%d", nbootstraps); return NAN; }
-	if (r->round_cap < nbootstraps) {
-		if (r->d_round) { (void) hipStreamSynchronize(c->stream); (void) hipFree(r->d_round); r->d_round = nullptr; }
-		if (!MDNS_HIP(hipMalloc((void **) &r->d_round, (size_t) nbootstraps * sizeof(double)))) return NAN;
-		r->round_cap = nbootstraps;
-	}
-	if (!launch_bootstrap(r->d_members, r->K, r->ndim, d_chosen, nbootstraps, r->d_round)) return NAN;
-	double *pin = (double *) pinned_scratch((size_t) nbootstraps * sizeof(double));
-	if (!pin) return NAN;
-	if (!MDNS_HIP(hipMemcpyAsync(pin, r->d_round, (size_t) nbootstraps * sizeof(double), hipMemcpyDeviceToHost, c->stream))) return NAN;
-	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return NAN;
-	double best = 0;          // cneighbors.c:160-174; sqrt after the max (monotone)
-	for (int b = 0; b < nbootstraps; b++) { const double v = std::sqrt(pin[b]); if (v > best) best = v; }
-	mdns_region_set_radius(r, best);
-	return best;
+	if (mdns_region_bootstrap_radius_async(r, d_chosen, nbootstraps) != 0) return NAN;
+	return mdns_region_radius(r);
 }
 
 extern "C" double mdns_region_bootstrap_radius(mdns_region *r, const double *chosen, int nbootstraps)
@@ -871,8 +905,10 @@ extern "C" int mdns_region_count_dev(mdns_region *r, const double *d_points, int
 	if (!ctx() || !r) return 1;
 	if (M < 0) { set_error("mdns_region_count: M=%d", M); return 1; }
 	if (M == 0) return 0;
-	if (r->radius != r->radius) { set_error("mdns_region_count: the region has no radius yet"); return 1; }
-	return launch_count_within(r->d_members, r->K, r->ndim, r->thresh_sq, d_points, M, d_counts) ? 0 : 1;
+	if (!r->on_device && r->radius != r->radius) { set_error("mdns_region_count: the region has no radius yet"); return 1; }
+	// right after a radius computation the threshold is read from device memory (stream order)
+	return launch_count_within(r->d_members, r->K, r->ndim, r->thresh_sq, r->on_device ? r->d_state + 1 : nullptr,
+	                           d_points, M, d_counts) ? 0 : 1;
 }
 
 extern "C" int mdns_region_count(mdns_region *r, const double *points, int M, int *counts)

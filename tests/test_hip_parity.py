@@ -423,3 +423,27 @@ def test_k1_lane_kernel_vs_oracle(oracle, nd, nx, B):
             want = -0.5 * oracle.gauss_like(x, y, params[b, 0], params[b, 1], params[b, 2], 0.01, mask)
             assert rel_err(got[b], want) < RTOL_L
     sp.close()
+
+
+def test_device_side_threshold_matches_host(nb, oracle):
+    """After mdns_region_bootstrap_radius* the membership threshold lives on the device
+    (k_radius_threshold); it must select exactly the points the reference's sqrt(d) < r selects,
+    including candidates placed AT distance r from a member."""
+    rng = np.random.RandomState(77)
+    for trial in range(60):
+        K, ndim = int(rng.randint(5, 40)), int(rng.randint(1, 4))
+        pts = rng.uniform(size=(K, ndim)) * 10 ** rng.uniform(-3, 3)
+        chosen = np.zeros((K, 10))
+        for b in range(10):
+            chosen[rng.choice(np.arange(K), size=K, replace=True), b] = 1.
+        ms = nb.MemberSet(pts)
+        r = ms.bootstrap_radius(chosen)                     # device radius + device threshold
+        assert r == oracle.bootstrapped_maxdistance(pts, chosen)
+        cand = [pts[i] + r * np.eye(ndim)[k] * s for i in range(min(K, 6)) for k in range(ndim) for s in (1, -1)]
+        cand += [pts[0] + np.nextafter(r, 0) * np.eye(ndim)[0], pts[0] + np.nextafter(r, np.inf) * np.eye(ndim)[0]]
+        cand = np.array(cand + list(rng.uniform(pts.min(), pts.max(), size=(50, ndim))))
+        want = oracle.count_within_distance_of(pts, r, cand).astype(int)
+        assert np.array_equal(ms.count(cand), want)         # threshold read from device memory
+        ms.set_radius(r)
+        assert np.array_equal(ms.count(cand), want)         # threshold computed on the host
+        ms.close()
