@@ -227,16 +227,19 @@ class MultiNestedSampler(object):
             return
         self.rebuild_map()
         todo = data_mask.copy()
-        while todo.any():
+        todo_set = set(numpy.flatnonzero(todo).tolist())     # same content as `todo`, for set algebra
+        while todo_set:
             first = numpy.where(todo)[0][0]
             todo[first] = False
+            todo_set.discard(int(first))
             members = [first]
             points = self.live_pointsp[:, first].tolist()
             i = 0
             known = set(points)
-            ntodo = int(todo.sum())
-            while i < len(points) and ntodo > 0:
-                newmembers = [m for m in self.point_data_map[points[i]] if todo[m]]
+            while i < len(points) and todo_set:
+                # data sets still to place that hold this point (their order is immaterial:
+                # they only enter a mask and a numpy.unique)
+                newmembers = list(self.point_data_map[points[i]] & todo_set)
                 if newmembers:
                     members += newmembers
                     for newp in numpy.unique(self.live_pointsp[:, newmembers]):
@@ -244,7 +247,7 @@ class MultiNestedSampler(object):
                             known.add(newp)
                             points.append(newp)
                     todo[newmembers] = False
-                    ntodo -= len(newmembers)
+                    todo_set.difference_update(newmembers)
                 i += 1
             member_mask = numpy.zeros(len(data_mask), dtype=bool)
             member_mask[members] = True
@@ -317,6 +320,10 @@ class MultiNestedSampler(object):
             empty = self._shelves.empty()
             if not empty.any():
                 return
+            if passes == 1:
+                # thresholds of this iteration (only needed when something has to be drawn)
+                self._higher = Lmins.copy()
+                self._refresh_thresholds(numpy.flatnonzero(self._shelves.n > 0))
             focussed = passes > self.nsuperset_draws
             if focussed:
                 data_mask = empty
@@ -381,8 +388,6 @@ class MultiNestedSampler(object):
 
     def __next__(self):
         allu, allp, _, Lmins, Lmini = self.prepare()
-        self._higher = Lmins.copy()
-        self._refresh_thresholds(numpy.flatnonzero(self._shelves.n > 0))
         self._fill_shelves(Lmins, allu, allp)
 
         # every data set gives up its worst live point and takes the head of its shelf
