@@ -242,10 +242,12 @@ class MultiNestedSampler(object):
                 newmembers = list(self.point_data_map[points[i]] & todo_set)
                 if newmembers:
                     members += newmembers
-                    for newp in numpy.unique(self.live_pointsp[:, newmembers]):
-                        if newp not in known:
-                            known.add(newp)
-                            points.append(newp)
+                    # the reference appends numpy.unique(...) of the new members' live points
+                    # that are not yet listed: ascending ids, each once
+                    fresh = set(self.live_pointsp[:, newmembers].ravel().tolist()) - known
+                    if fresh:
+                        known |= fresh
+                        points.extend(sorted(fresh))
                     todo[newmembers] = False
                     todo_set.difference_update(newmembers)
                 i += 1
