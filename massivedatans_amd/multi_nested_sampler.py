@@ -244,10 +244,12 @@ class MultiNestedSampler(object):
                     members += newmembers
                     # the reference appends numpy.unique(...) of the new members' live points
                     # that are not yet listed: ascending ids, each once
-                    fresh = set(self.live_pointsp[:, newmembers].ravel().tolist()) - known
+                    cols = self.live_pointsp[:, newmembers]
+                    uniq = numpy.unique(cols) if cols.size > 256 else sorted(set(cols.ravel().tolist()))
+                    fresh = [p for p in (uniq.tolist() if cols.size > 256 else uniq) if p not in known]
                     if fresh:
-                        known |= fresh
-                        points.extend(sorted(fresh))
+                        known.update(fresh)
+                        points.extend(fresh)
                     todo[newmembers] = False
                     todo_set.difference_update(newmembers)
                 i += 1
