@@ -10,6 +10,11 @@
  * selected device and reports failure (return code / NaN, message via mdns_last_error())
  * when no device is usable.
  *
+ * Threading: like the reference (one Python thread; its OpenMP lives inside the .so files),
+ * the entry points are meant to be called from one thread at a time.  One process drives one
+ * GPU; all work is issued on one HIP stream (the library's own, or the caller's through
+ * mdns_set_stream).
+ *
  * Part 1  drop-in entry points with the reference's argument lists (host pointers);
  *         the three shim libraries clike.so / cmuselike.so / cneighbors.so re-export them
  *         under the reference's symbol names.

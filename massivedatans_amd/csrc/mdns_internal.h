@@ -59,9 +59,6 @@ inline int model_ld(int nx) { return nx <= 0 ? 512 : ((nx + 511) / 512) * 512; }
 // channel count of the channel-major replica / transposed templates: padded (with zeros) to
 // the software-pipeline depth of k_gauss_cols
 inline int cols_nx(int nx) { return ((nx + 7) / 8) * 8; }
-// candidate stride of the transposed templates: multiple of 16 so every candidate tile is whole
-inline int model_ldb(int B) { return B <= 0 ? 16 : ((B + 15) / 16) * 16; }
-
 // launchers implemented in mdns_like.hip (all asynchronous on ctx()->stream)
 bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B,
                         double *d_model, int ldm);
