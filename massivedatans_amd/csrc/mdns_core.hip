@@ -357,13 +357,12 @@ extern "C" mdns_spectra *mdns_spectra_create(const double *x, const double *y, c
 	ok = ok && MDNS_HIP(hipMemsetAsync(s->d_y, 0, elems * sizeof(double), c->stream));
 	ok = ok && upload_rows(y, ndata, nx, layout, s->d_y, s->ld, false);
 	if (ok && !v && nx > 0 && ndata > 0) {
-		// K1 also keeps a channel-major replica [nx][ldT] for dense candidate batches
+		// K1 also keeps a channel-major replica, in tiles of 64 spectra, for candidate batches
+		// (the tiling kernel writes every element, padding included)
 		s->ldT = ((ndata + 63) / 64) * 64;
 		const size_t telems = (size_t) cols_nx(nx) * s->ldT;
 		ok = MDNS_HIP(hipMalloc((void **) &s->d_yT, telems * sizeof(double)));
-		ok = ok && MDNS_HIP(hipMemsetAsync(s->d_yT, 0, telems * sizeof(double), c->stream));
-		// rows [ndata][ld] -> [nx][ldT] is the same re-lay with the roles of the axes swapped
-		ok = ok && launch_transpose(s->d_y, ndata, nx, s->d_yT, s->ldT, false, s->ld);
+		ok = ok && launch_tile_columns(s->d_y, s->ld, ndata, nx, s->d_yT);
 		ok = ok && MDNS_HIP(hipStreamSynchronize(c->stream));
 	}
 	if (ok && v) {

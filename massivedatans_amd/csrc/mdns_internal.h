@@ -39,7 +39,8 @@ struct mdns_spectra {
 	int nx = 0;         // channels per spectrum
 	int ld = 0;         // row stride in doubles (nx rounded up to even => 16-byte aligned rows)
 	double *d_y = nullptr;   // [ndata, ld]   one spectrum per row
-	double *d_yT = nullptr;  // [nx, ldT]     channel-major replica (K1 dense scoring), or nullptr
+	double *d_yT = nullptr;  // [ldT/64][cols_nx(nx)][64] channel-major replica in tiles of 64 spectra
+	                         // (K1 lane kernel), or nullptr
 	int ldT = 0;             // ndata rounded up to a multiple of 64 (zero padded)
 	double *d_w = nullptr;   // [ndata, ld] inverse variances 1/v (K2), or nullptr
 	double *d_x = nullptr;   // [nx] wavelength grid, or nullptr
@@ -78,6 +79,8 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 // src [nx][lds] -> dst [ndata][ld] (only the nx x ndata corner is touched)
 bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld,
                       bool invert, int lds);
+// rows [ndata][ld] -> tiled channel-major replica [ceil(ndata/64)][cols_nx(nx)][64]
+bool launch_tile_columns(const double *d_y, int ld, int ndata, int nx, double *d_yt);
 bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int ld,
                       bool invert);
 bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm);

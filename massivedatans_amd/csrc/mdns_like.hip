@@ -148,6 +148,26 @@ __global__ void k_transpose(const double *__restrict__ src, int nx, int ndata, d
 	}
 }
 
+// spectra rows Y[ndata][ld] -> the tiled channel-major replica of k_gauss_cols:
+// element (channel j, spectrum i) at ((i / 64) * nxp + j) * 64 + i % 64, zeros in the padding
+// (spectra >= ndata of the last tile, channels nx..nxp-1).  One workgroup = 64 spectra x 32
+// channels through an LDS tile: reads run along channels, writes along spectra.
+__global__ __launch_bounds__(kBlock) void k_tile_columns(const double *__restrict__ Y, int ld, int ndata, int nx,
+                                                         int nxp, double *__restrict__ YT)
+{
+	__shared__ double tile[64][33];
+	const int t = blockIdx.x, j0 = blockIdx.y * 32;
+	for (int r = threadIdx.x >> 5; r < 64; r += 8) {
+		const int i = t * 64 + r, j = j0 + (threadIdx.x & 31);
+		tile[r][threadIdx.x & 31] = (i < ndata && j < nx) ? Y[(size_t) i * ld + j] : 0.0;
+	}
+	__syncthreads();
+	for (int jj = threadIdx.x >> 6; jj < 32; jj += 4) {
+		const int j = j0 + jj;
+		if (j < nxp) YT[((size_t) t * nxp + j) * 64 + (threadIdx.x & 63)] = tile[threadIdx.x & 63][jj];
+	}
+}
+
 __global__ void k_copy_rows(const double *__restrict__ src, int nx, int ndata, double *__restrict__ dst,
                             int ld, int invert)
 {
@@ -252,68 +272,95 @@ __global__ __launch_bounds__(kBlock) void k_gauss_rows(
 // values MT[j][bt*BT .. +BT) are wave-uniform and arrive through the scalar cache as SGPR
 // operands, so the inner loop is exactly one v_add_f64 + one v_fma_f64 per (candidate,
 // channel, spectrum).  Work items are (spectrum tile, candidate tile) pairs, one per wave.
-template <int BT>
+// SP = spectra per lane (1 or 2): with 2 every template value read through the scalar cache
+// feeds two v_add/v_fmac pairs.
+template <int BT, int SP>
 __global__ __launch_bounds__(kBlock) void k_gauss_cols(
-    const double *__restrict__ YT, int ldT, int nxp, const double *__restrict__ model_t, int B,
+    const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
     double scale, const int *__restrict__ rows, int M, int ntiles, int nq_xcd, double *__restrict__ out)
 {
 	constexpr int CH = 8;                     // channels per software-pipeline stage (nxp % CH == 0)
 	const int lane = threadIdx.x & 63;
-	// Work item of a wave = (spectrum tile, candidate tile).  A workgroup takes 4 adjacent
-	// spectrum tiles (a "quad") of ONE candidate tile, so its waves pull the same template
-	// values through the scalar cache.  Workgroups are dealt round-robin over the 8 XCDs
-	// (blockIdx % 8 shares an XCD): quad q is always given to XCD q % 8, for every candidate
-	// tile, so each XCD re-reads only its own eighth of the spectra from its own L2.  This
-	// is a speed-only mapping; any placement gives the same results.
+	// Work item of a wave = (spectrum tile, candidate tile), a spectrum tile being 64*SP
+	// spectra.  A workgroup takes 4 adjacent spectrum tiles (a "quad") of ONE candidate tile,
+	// so its waves pull the same template values through the scalar cache.  Workgroups are
+	// dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD): quad q is always given
+	// to XCD q % 8, for every candidate tile, so each XCD re-reads only its own eighth of the
+	// spectra from its own L2.  This is a speed-only mapping; any placement gives the same
+	// results.
 	const int xcd = blockIdx.x & 7;
 	const int local = blockIdx.x >> 3;
 	const int bt = local / nq_xcd;
 	const int quad = (local % nq_xcd) * 8 + xcd;
 	const int tile = quad * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (tile >= ntiles) return;
-	const int k = tile * 64 + lane;           // position in the (compacted) output
-	int col = k;                              // column of YT (padded to ldT, so k >= M is readable)
-	if (rows) col = rows[k < M ? k : M - 1];
-	const double *ycol = YT + col;
-	const double *mt = model_t + (size_t) bt * nxp * BT;     // this wave's template tile [nxp][BT]
+	// YT is stored in tiles of 64 spectra: element (channel j, spectrum i) at
+	// ((i / 64) * nxp + j) * 64 + i % 64.  Whatever column a lane owns (its own tile when all
+	// spectra are selected, a gathered one otherwise), consecutive channels are exactly 512
+	// bytes apart, so the eight loads of a stage are immediate offsets of one pointer.
+	int k[SP];                                // positions in the (compacted) output
+	const double *yp[SP];
+#pragma unroll
+	for (int s = 0; s < SP; s++) {
+		k[s] = (tile * SP + s) * 64 + lane;
+		int col = k[s];                       // the replica is padded: positions >= M stay readable
+		if (rows) col = rows[k[s] < M ? k[s] : M - 1];
+		else if (col >= ((M + 63) & ~63)) col = M - 1;
+		yp[s] = YT + ((size_t) (col >> 6) * nxp << 6) + (col & 63);
+	}
+	const double *mp = model_t + (size_t) bt * nxp * BT;     // wave-uniform: CH*BT contiguous doubles per stage
 
-	double acc[BT];
+	double acc[SP][BT];
 #pragma unroll
-	for (int b = 0; b < BT; b++) acc[b] = 0.0;
-	// software pipeline over stages of CH channels: the next stage's spectra values are in
-	// flight while this one computes.  Both streams advance by pointer bumps so that the
-	// template loads keep small positive immediate offsets (no scalar address arithmetic).
-	double ycur[CH], ynext[CH];
-	const double *yp = ycol;                  // per lane
-	const double *mp = mt;                    // wave-uniform: CH*BT contiguous doubles per stage
-	const size_t ystep = (size_t) CH * ldT;
+	for (int s = 0; s < SP; s++)
 #pragma unroll
-	for (int c = 0; c < CH; c++) ycur[c] = yp[(size_t) c * ldT];
-#pragma unroll 1
-	for (int st = nxp / CH; st > 0; st--) {
-		// the last stage prefetches its own channels again (in bounds, unused): one loop body,
-		// no peeled copy for the compiler to tangle with the stores below
-		yp += (st > 1) ? ystep : 0;
+		for (int b = 0; b < BT; b++) acc[s][b] = 0.0;
+	// Software pipeline over stages of CH channels with two register buffers that swap roles
+	// (no copies): while `cur` is consumed the next stage's spectra values land in `nxt`.
+	// The last stage prefetches its own channels again (in bounds, unused) so that every
+	// stage is the same straight-line code.
+	double ya[SP][CH], yb[SP][CH];
 #pragma unroll
-		for (int c = 0; c < CH; c++) ynext[c] = yp[(size_t) c * ldT];
+	for (int s = 0; s < SP; s++)
+#pragma unroll
+		for (int c = 0; c < CH; c++) ya[s][c] = yp[s][c * 64];
+	auto stage = [&](const double (&cur)[SP][CH], double (&nxt)[SP][CH], bool last) {
+#pragma unroll
+		for (int s = 0; s < SP; s++) {
+			yp[s] += last ? 0 : CH * 64;
+#pragma unroll
+			for (int c = 0; c < CH; c++) nxt[s][c] = yp[s][c * 64];
+		}
 #pragma unroll
 		for (int c = 0; c < CH; c++) {
 			// (forcing all differences of a channel ahead of the squares was measured 9 % slower:
-			// it costs 34 VGPRs = three waves per SIMD, and occupancy is what hides the loads)
+			// it costs 34 VGPRs = three waves per SIMD)
 #pragma unroll
 			for (int b = 0; b < BT; b++) {
-				const double d = mp[c * BT + b] - ycur[c];
-				acc[b] = fma(d, d, acc[b]);
+				const double mv = mp[c * BT + b];
+#pragma unroll
+				for (int s = 0; s < SP; s++) {
+					const double d = mv - cur[s][c];
+					acc[s][b] = fma(d, d, acc[s][b]);
+				}
 			}
 		}
 		mp += CH * BT;
-#pragma unroll
-		for (int c = 0; c < CH; c++) ycur[c] = ynext[c];
+	};
+	int st = nxp / CH;
+#pragma unroll 1
+	for (; st >= 2; st -= 2) {
+		stage(ya, yb, false);
+		stage(yb, ya, st == 2);
 	}
-	if (k < M) {
+	if (st == 1) stage(ya, yb, true);
 #pragma unroll
-		for (int b = 0; b < BT; b++)
-			if (bt * BT + b < B) out[(size_t) (bt * BT + b) * M + k] = acc[b] * scale;
+	for (int s = 0; s < SP; s++) {
+		if (k[s] < M) {
+#pragma unroll
+			for (int b = 0; b < BT; b++)
+				if (bt * BT + b < B) out[(size_t) (bt * BT + b) * M + k[s]] = acc[s][b] * scale;
+		}
 	}
 }
 
@@ -530,14 +577,17 @@ bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, i
                        const int *d_rows, int M, double *d_out)
 {
 	Context *c = ctx();
-	const int ntiles = (M + 63) / 64;
+	// one spectrum per lane: two per lane (template values reused twice) measured 18 % slower
+	// (207 vs 176 us at B = 1024) -- half the waves, and the scalar path is not the limit
+	constexpr int sp = 1;
+	const int ntiles = (M + 64 * sp - 1) / (64 * sp);
 	const int nbt = (B + bt - 1) / bt;
 	const int nquads = (ntiles + 3) / 4;
 	const int nq_xcd = (nquads + 7) / 8;                      // quads per XCD (some may be empty)
 	const int blocks = 8 * nq_xcd * nbt;
 	ProfileScope prof(0);
-#define COLS_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols<BT>), dim3(blocks), dim3(kBlock), 0, c->stream, \
-	s->d_yT, s->ldT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, d_out)
+#define COLS_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols<BT, sp>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+	s->d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, d_out)
 	switch (bt) {
 	case 16: COLS_LAUNCH(16); break;
 	case 8: COLS_LAUNCH(8); break;
@@ -572,6 +622,16 @@ bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int
 	dim3 grid((ndata + 31) / 32, (nx + 31) / 32);
 	hipLaunchKernelGGL(k_transpose, grid, dim3(kBlock), 0, c->stream, d_src, nx, ndata, d_dst, ld, invert ? 1 : 0, lds);
 	return launched("k_transpose");
+}
+
+bool launch_tile_columns(const double *d_y, int ld, int ndata, int nx, double *d_yt)
+{
+	Context *c = ctx();
+	if (nx == 0 || ndata == 0) return true;
+	const int nxp = cols_nx(nx);
+	dim3 grid((ndata + 63) / 64, (nxp + 31) / 32);
+	hipLaunchKernelGGL(k_tile_columns, grid, dim3(kBlock), 0, c->stream, d_y, ld, ndata, nx, nxp, d_yt);
+	return launched("k_tile_columns");
 }
 
 bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int ld, bool invert)
