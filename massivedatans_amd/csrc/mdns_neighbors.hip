@@ -163,7 +163,7 @@ __global__ void k_pack_chosen(const double *__restrict__ chosen, int K, int nboo
 // with sqrt(T) >= radius, so that  sqrt(d) < radius  <=>  d < T  (cneighbors.c:88,109).  Same
 // bisection over bit patterns as mdns::sqrt_threshold on the host; hipcc's sqrt(double) is
 // correctly rounded (verified bit for bit against the host on 1.6e7 inputs, and the parity
-// tests compare both paths), so the two agree exactly.  One thread: 64 dependent steps.
+// tests compare both paths), so the two agree exactly.  One thread; normally ~5 square roots.
 __global__ void k_radius_threshold(const double *__restrict__ round_sq, int nb, double *__restrict__ state)
 {
 	if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -177,12 +177,27 @@ __global__ void k_radius_threshold(const double *__restrict__ round_sq, int nb, 
 	if (!(r > 0.0)) T = 0.0;                       // nothing is strictly within a zero radius
 	else if (r == __longlong_as_double(0x7ff0000000000000LL)) T = r;
 	else {
-		unsigned long long lo = 0, hi = 0x7ff0000000000000ULL;
-		while (hi - lo > 1) {
-			const unsigned long long mid = lo + (hi - lo) / 2;
-			if (sqrt(__longlong_as_double((long long) mid)) >= r) hi = mid; else lo = mid;
+		// T lies within a few ulps of r*r: walk there, and keep the full bisection for the
+		// cases where r*r leaves the normal range or the walk does not settle
+		const double t0 = r * r;
+		unsigned long long u = (unsigned long long) __double_as_longlong(t0);
+		bool settled = false;
+		if (t0 > 1e-300 && t0 < 1e300) {
+			int guard = 0;
+			while (sqrt(__longlong_as_double((long long) u)) < r && guard < 8) { u++; guard++; }
+			while (guard < 16 && sqrt(__longlong_as_double((long long) (u - 1))) >= r) { u--; guard++; }
+			settled = guard < 16 && sqrt(__longlong_as_double((long long) u)) >= r &&
+			          sqrt(__longlong_as_double((long long) (u - 1))) < r;
 		}
-		T = __longlong_as_double((long long) hi);
+		if (!settled) {
+			unsigned long long lo = 0, hi = 0x7ff0000000000000ULL;
+			while (hi - lo > 1) {
+				const unsigned long long mid = lo + (hi - lo) / 2;
+				if (sqrt(__longlong_as_double((long long) mid)) >= r) hi = mid; else lo = mid;
+			}
+			u = hi;
+		}
+		T = __longlong_as_double((long long) u);
 	}
 	state[0] = r;
 	state[1] = T;
