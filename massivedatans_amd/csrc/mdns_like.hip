@@ -498,6 +498,74 @@ __global__ __launch_bounds__(kBlock) void k_muse_rows(
 	}
 }
 
+// Many candidates: the limit of k_muse_rows is the 32 KiB template that every (candidate,
+// row) pair pulls from L2 (15.5 TB/s at B = 64).  Here a workgroup keeps RB = 2 spectra in
+// registers and applies each template to both, halving that traffic; y w is formed on the fly
+// to make room (8 VALU operations per candidate and channel instead of 6 -- the VALU was idle).
+template <int NP>
+__global__ __launch_bounds__(kBlock) void k_muse_rows2(
+    const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
+    const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M,
+    double *__restrict__ out)
+{
+	constexpr int RB = 2;
+	__shared__ double redA[4 * 2 * RB], redB[4 * RB];
+	const int ch = 2 * threadIdx.x;
+	bool valid[NP];
+#pragma unroll
+	for (int p = 0; p < NP; p++) valid[p] = (p * 512 + ch) < nx;
+
+	for (int k0 = blockIdx.x * RB; k0 < M; k0 += gridDim.x * RB) {
+		double2 y[RB][NP], w[RB][NP];
+#pragma unroll
+		for (int r = 0; r < RB; r++) {
+			const int k = (k0 + r < M) ? k0 + r : M - 1;
+			const size_t base = (size_t) (rows ? rows[k] : k) * ld + ch;
+#pragma unroll
+			for (int p = 0; p < NP; p++) {
+				y[r][p] = valid[p] ? *reinterpret_cast<const double2 *>(Y + base + p * 512) : make_double2(0.0, 0.0);
+				w[r][p] = valid[p] ? *reinterpret_cast<const double2 *>(W + base + p * 512) : make_double2(0.0, 0.0);
+			}
+		}
+		for (int b = 0; b < B; b++) {
+			double2 m[NP];
+			double sums[2 * RB];
+#pragma unroll
+			for (int i = 0; i < 2 * RB; i++) sums[i] = 0.0;
+#pragma unroll
+			for (int p = 0; p < NP; p++) {
+				m[p] = *reinterpret_cast<const double2 *>(model + (size_t) b * ldm + p * 512 + ch);
+				const double mmx = m[p].x * m[p].x, mmy = m[p].y * m[p].y;
+#pragma unroll
+				for (int r = 0; r < RB; r++) {
+					sums[2 * r] = fma(y[r][p].x * w[r][p].x, m[p].x, sums[2 * r]);
+					sums[2 * r] = fma(y[r][p].y * w[r][p].y, m[p].y, sums[2 * r]);
+					sums[2 * r + 1] = fma(mmx, w[r][p].x, sums[2 * r + 1]);
+					sums[2 * r + 1] = fma(mmy, w[r][p].y, sums[2 * r + 1]);
+				}
+			}
+			block_sums<2 * RB>(sums, redA);
+			double chi[RB];
+#pragma unroll
+			for (int r = 0; r < RB; r++) {
+				const double s = sums[2 * r] / (1e-10 + sums[2 * r + 1]);      // cmuselike.c:52,57
+				double acc = 0.0;
+#pragma unroll
+				for (int p = 0; p < NP; p++) {
+					const double r0 = fma(-s, m[p].x, y[r][p].x);
+					const double r1 = fma(-s, m[p].y, y[r][p].y);
+					acc = fma(r0 * r0, w[r][p].x, acc);
+					acc = fma(r1 * r1, w[r][p].y, acc);
+				}
+				chi[r] = acc;
+			}
+			block_sums<RB>(chi, redB);
+			if (threadIdx.x < RB && k0 + threadIdx.x < M)
+				out[(size_t) b * M + k0 + threadIdx.x] = -0.5 * (threadIdx.x == 0 ? chi[0] : chi[RB - 1]);
+		}
+	}
+}
+
 // any nx: two passes over the row from memory (the row is L2-hot for the second pass)
 __global__ __launch_bounds__(kBlock) void k_muse_rows_generic(
     const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
@@ -693,7 +761,11 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 	int blocks = M < c->num_cus * 8 ? M : c->num_cus * 8;
 	if (blocks < 1) blocks = 1;
 	ProfileScope prof(1);
-#define MUSE_LAUNCH(NP) do { if (B >= 2) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+	static const char *k2v = getenv("MDNS_K2_ROWS2");         // experiments only: "0" disables
+	const bool two_rows = B >= 4 && M >= 2 * c->num_cus && !(k2v && k2v[0] == '0');
+#define MUSE_LAUNCH(NP) do { if (two_rows) hipLaunchKernelGGL((k_muse_rows2<NP>), dim3((blocks + 1) / 2), dim3(kBlock), 0, c->stream, \
+		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
+	else if (B >= 2) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
 	else hipLaunchKernelGGL((k_muse_rows<NP, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); } while (0)
