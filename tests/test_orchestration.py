@@ -75,3 +75,32 @@ def test_trace_bit_exact(case, batched, oracle, monkeypatch):
     assert rng_probe == float(g["rng_probe"])
     # our own counter: every (candidate, data set) pair the sampler asked for
     assert sampler.nevals >= sampler.ndraws
+
+
+def test_graph_grouping_is_the_same_partition(oracle, monkeypatch):
+    """``generate_subsets_graph`` (connected components; igraph ordering restated, not pinned)
+    must at least produce the same PARTITION of data sets and live points as the pinned
+    ``generate_subsets_nograph`` walk, on real sampler states where the data sets have split."""
+    from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
+    patch_neighbors(monkeypatch, oracle)
+    data = gen.horns(12)
+    problem = sample.GaussLineProblem(data["x"], data["y"], backend=OracleSpectra(oracle, data["x"], data["y"]))
+    sampler = sample.build_sampler(problem, nlive_points=24, nsuperset_draws=10, use_graph=False, seed=1, batched=False)
+    checked = 0
+    with np.errstate(all="ignore"):
+        for it in range(120):
+            next(sampler)
+            if sampler.superpoints or it % 10:
+                continue
+            rng = np.random.RandomState(it)
+            for mask in (np.ones(sampler.ndata, bool), rng.uniform(size=sampler.ndata) < 0.6):
+                if mask.sum() < 2:
+                    continue
+                allp = np.unique(sampler.live_pointsp[:, mask])
+                a = {(frozenset(np.flatnonzero(m).tolist()), frozenset(int(p) for p in pts))
+                     for m, pts in sampler.generate_subsets_nograph(mask, allp)}
+                b = {(frozenset(np.flatnonzero(m).tolist()), frozenset(int(p) for p in pts))
+                     for m, pts in sampler.generate_subsets_graph(mask, allp)}
+                assert a == b
+                checked += len(a) > 1
+    assert checked > 0, "no split state was reached: the test would be vacuous"
