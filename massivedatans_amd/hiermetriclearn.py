@@ -69,24 +69,29 @@ class MetricLearningFriendsConstrainer(object):
             return metric, changed
         raise AssertionError(self.metriclearner)
 
+    def _never_grow(self, region, members_old_metric):
+        """``force_shrink``: a rebuilt region may not have a larger radius than the one it
+        replaces (hiermetriclearn.py:53-54,88-90).  ``prev_maxdistance is None`` counts as
+        "smaller than anything", the Python-2 ordering the reference was written under."""
+        previous = self.prev_maxdistance
+        if self.force_shrink and (previous is None or region.maxdistance > previous):
+            return RadFriendsRegion(members=members_old_metric, maxdistance=previous)
+        return region
+
     def cluster(self, u, ndim, keepMetric=False):
-        w = self.metric.transform(u)
+        """(Re)build the region around the live points ``u``; with ``keepMetric`` the axis
+        scaling stays as it is, otherwise it is re-learned first (hiermetriclearn.py:48-92)."""
+        w_old = self.metric.transform(u)
         if keepMetric:
-            self.region = RadFriendsRegion(members=w)
-            # Python-2 ordering: any float compares greater than None
-            grew = self.prev_maxdistance is None or self.region.maxdistance > self.prev_maxdistance
-            if self.force_shrink and grew:
-                self.region = RadFriendsRegion(members=w, maxdistance=self.prev_maxdistance)
-            self.prev_maxdistance = self.region.maxdistance
-            return
-        metric, metric_updated = self._fit_metric(u)
-        self.metric = metric
-        wnew = self.metric.transform(u)
-        self.region = RadFriendsRegion(members=wnew)
-        if not metric_updated and self.force_shrink and self.prev_maxdistance is not None:
-            if self.region.maxdistance > self.prev_maxdistance:
-                # same metric as before (w == wnew): never let the radius grow back
-                self.region = RadFriendsRegion(members=w, maxdistance=self.prev_maxdistance)
+            self.region = self._never_grow(RadFriendsRegion(members=w_old), w_old)
+        else:
+            new_metric, changed = self._fit_metric(u)
+            self.metric = new_metric
+            region = RadFriendsRegion(members=self.metric.transform(u))
+            # only a region in the SAME metric is comparable with the previous radius
+            if not changed and self.prev_maxdistance is not None:
+                region = self._never_grow(region, w_old)
+            self.region = region
         self.prev_maxdistance = self.region.maxdistance
 
     def are_inside_cluster(self, points):
@@ -176,48 +181,51 @@ class MetricLearningFriendsConstrainer(object):
 
     # ---- the draw -----------------------------------------------------------------------
     def _draw_constrained_prepare(self, Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs):
-        rebuild = self.ndraws_since_rebuild > self.rebuild_every or self.region is None
-        rebuild_metric = self.iter_since_metric_rebuild > self.metric_rebuild_every
-        if rebuild:
-            self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=not rebuild_metric)
-            self.ndraws_since_rebuild = 0
-            if rebuild_metric:
-                self.iter_since_metric_rebuild = 0
-        else:
-            rebuild_metric = False
+        """Rebuild policy at the start of a draw (hiermetriclearn.py:152-166): a new region
+        after ``rebuild_every`` likelihood calls (or when there is none), with a new metric if
+        this constrainer has been asked more than ``metric_rebuild_every`` times since the last
+        one.  Returns (region rebuilt, metric rebuilt)."""
+        region_due = self.region is None or self.ndraws_since_rebuild > self.rebuild_every
+        metric_due = self.iter_since_metric_rebuild > self.metric_rebuild_every
+        if not region_due:
+            assert self.generator is not None
+            return False, False
+        self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=not metric_due)
+        self.ndraws_since_rebuild = 0
+        if metric_due:
+            self.iter_since_metric_rebuild = 0
         assert self.generator is not None
-        return rebuild, rebuild_metric
+        return True, metric_due
 
     def draw_constrained(self, Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs):
         """Propose until a candidate beats the threshold of at least one data set
         (hiermetriclearn.py:173-211).  Returns ``(u, x, L, n_likelihood_calls)``."""
         loglikelihood_batch = kwargs.get('loglikelihood_batch')
         mask_key = kwargs.get('mask_key')
-        ntoaccept = 0
         self.iter_since_metric_rebuild += 1
-        rebuild, rebuild_metric = self._draw_constrained_prepare(
+        region_rebuilt, metric_rebuilt = self._draw_constrained_prepare(
             Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs)
         lookahead = min(self.MAX_LOOKAHEAD, max(1, getattr(self, '_last_ntoaccept', 1)))
+        tries = 0
         while True:
-            u, ntotal = self._next_candidate()
+            u, nproposed = self._next_candidate()
             assert (u >= 0).all() and (u <= 1).all(), u
             x, L = self._score(u, priortransform, loglikelihood, loglikelihood_batch, mask_key, lookahead)
-            ntoaccept += 1
+            tries += 1
             self.ndraws_since_rebuild += 1
-            if ntotal > 100000:
+            if nproposed > 100000:
                 self.direct_draws_efficient = False
             if numpy.any(L > Lmins):
-                self._last_ntoaccept = ntoaccept
-                return u, x, L, ntoaccept
-            lookahead = min(self.MAX_LOOKAHEAD, max(lookahead, 2 * ntoaccept))
-            # a long unsuccessful streak: tighten the region (at most once per draw, each)
-            if not rebuild and self.ndraws_since_rebuild > self.rebuild_every:
-                rebuild = True
+                self._last_ntoaccept = tries
+                return u, x, L, tries
+            lookahead = min(self.MAX_LOOKAHEAD, max(lookahead, 2 * tries))
+            # a long unsuccessful streak tightens the region -- each kind at most once per draw
+            # (hiermetriclearn.py:198-211); the candidate stream restarts from the new region
+            if not region_rebuilt and self.ndraws_since_rebuild > self.rebuild_every:
+                region_rebuilt = True
                 self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=True)
                 self.ndraws_since_rebuild = 0
-                continue
-            if not rebuild_metric and ntoaccept > 200:
-                rebuild_metric = True
+            elif not metric_rebuilt and tries > 200:
+                metric_rebuilt = True
                 self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=False)
                 self.iter_since_metric_rebuild = 0
-                continue

@@ -3,9 +3,14 @@
 Host-side mirror of the reference's ``multi_nested_integrator.py:26-175``: same call
 (``multi_nested_integrator(multi_sampler, tolerance, max_samples, min_samples)``), same result
 dictionary (``logZ``, ``logZerr``, ``weights``, ``information``, ``niterations``) and the same
-floating-point expressions in the same order, so that identical sampler output gives
-bit-identical evidences.  The progress bar of the reference is not reproduced (it has no
-effect on the results).
+floating-point expressions evaluated in the same order, so that identical sampler output gives
+bit-identical evidences (tests/test_orchestration.py).  The progress bar of the reference is not
+reproduced (it has no effect on the results).
+
+Per data set the integrator keeps the running evidence ``logZ`` and information ``H``; each
+iteration contributes one shell of prior volume ``exp(-i/nlive) (1 - exp(-1/nlive))`` weighted
+with the likelihood of the point that died, and every 50 iterations the live points are
+integrated as a remainder to decide which data sets are done.
 """
 import logging
 
@@ -15,35 +20,42 @@ from numpy import exp, log, logaddexp
 log_ = logging.getLogger("massivedatans_amd")
 
 
+def _absorb(logZ, H, shell_logwidth, Li):
+    """One weighted sample into (logZ, H): logZ' = logaddexp(logZ, w), and the information
+    update of multi_nested_integrator.py:46,160 (same association of terms)."""
+    wi = shell_logwidth + Li
+    grown = logaddexp(logZ, wi)
+    H = exp(wi - grown) * Li + exp(logZ - grown) * (H + logZ) - grown
+    return grown, H
+
+
 def integrate_remainder(sampler, logwidth, logVolremaining, logZ, H, globalLmax):
-    """Contribution of the current live points, which all share the shell width ``logwidth``
-    (multi_nested_integrator.py:26-59).  Returns (remainderZ, remainderZerr, totalZ, totalZerr,
-    totalZerr) per running data set."""
-    remainder = list(sampler.remainder())
-    logV = logwidth
-    L0 = globalLmax
-    Ls = numpy.exp([Li - L0 for _, _, Li in remainder])
-    LsMax = Ls.copy()
-    LsMax[-1] = numpy.exp(globalLmax - L0)
-    Lmax = LsMax[1:].sum(axis=0) + LsMax[-1]
-    Lmin = Ls[:-1].sum(axis=0) + Ls[0]
-    logLmid = log(Ls.sum(axis=0)) + L0
-    logZmid = logaddexp(logZ, logV + logLmid)
-    logZup = logaddexp(logZ, logV + log(Lmax) + L0)
-    logZlo = logaddexp(logZ, logV + log(Lmin) + L0)
-    logZerr = logZup - logZlo
+    """Evidence still held by the live points, which all share the shell width ``logwidth``
+    (multi_nested_integrator.py:26-59).  Returns per running data set: remainder log-evidence,
+    its bracketing error, total log-evidence, total error (twice, as the reference does)."""
+    live = list(sampler.remainder())                     # ascending likelihood, per data set
+    ref = globalLmax                                     # likelihoods are taken relative to this
+    rel = numpy.exp([Li - ref for _, _, Li in live])     # [nlive, nrunning]
+    # upper / lower Riemann sums: every point takes its upper (resp. lower) neighbour's value
+    rel_top = rel.copy()
+    rel_top[-1] = numpy.exp(globalLmax - ref)
+    upper = rel_top[1:].sum(axis=0) + rel_top[-1]
+    lower = rel[:-1].sum(axis=0) + rel[0]
+    log_mid = log(rel.sum(axis=0)) + ref
+    total_mid = logaddexp(logZ, logwidth + log_mid)
+    total_up = logaddexp(logZ, logwidth + log(upper) + ref)
+    total_lo = logaddexp(logZ, logwidth + log(lower) + ref)
+    bracket = total_up - total_lo
     assert numpy.isfinite(H).all()
-    assert numpy.isfinite(logZerr).all(), logZerr
+    assert numpy.isfinite(bracket).all(), bracket
 
-    for _, _, Li in remainder:
-        wi = logwidth + Li
-        logZnew = logaddexp(logZ, wi)
-        H = exp(wi - logZnew) * Li + exp(logZ - logZnew) * (H + logZ) - logZnew
+    # information if the run stopped here: absorb the live points one by one
+    for _, _, Li in live:
+        logZ, H = _absorb(logZ, H, logwidth, Li)
         H[H < 0] = 0
-        logZ = logZnew
 
-    total_err = logZerr + (H / sampler.nlive_points) ** 0.5
-    return logV + logLmid, logZerr, logZmid, total_err, total_err
+    spread = bracket + (H / sampler.nlive_points) ** 0.5
+    return logwidth + log_mid, bracket, total_mid, spread, spread
 
 
 def multi_nested_integrator(multi_sampler, tolerance=0.01, max_samples=None, min_samples=0,
@@ -51,80 +63,74 @@ def multi_nested_integrator(multi_sampler, tolerance=0.01, max_samples=None, min
     """Run ``multi_sampler`` until, for every data set, the evidence uncertainty (shell
     statistics + live-point remainder) is below ``tolerance`` (checked every 50 iterations,
     multi_nested_integrator.py:136), dropping finished data sets from the sampler as it goes."""
-    sampler = multi_sampler
-    nlive = sampler.nlive_points
-    ndata = multi_sampler.ndata
-    logVolremaining = 0
-    logwidth = log(1 - exp(-1. / nlive))
+    nlive = multi_sampler.nlive_points
+    ntotal = multi_sampler.ndata
+    shell = log(1 - exp(-1. / nlive))                    # log width of one shell at volume 1
+    log_volume = 0                                       # log prior volume still enclosed
     weights = []
 
-    i = 0
-    running = numpy.ones(ndata, dtype=bool)
-    last_remainderZ = numpy.zeros(ndata)
-    last_remainderZerr = numpy.zeros(ndata)
-    logZerr = numpy.zeros(ndata)
-    ui, xi, Li = next(sampler)
-    wi = logwidth + Li
-    logZ = wi
-    H = Li - logZ
-    ndim = ui.shape[1]
+    active = numpy.ones(ntotal, dtype=bool)              # data sets still being sampled
+    tail_Z = numpy.zeros(ntotal)                         # remainder evidence at the last check
+    tail_Zerr = numpy.zeros(ntotal)
+    stat_err = numpy.zeros(ntotal)
+    dead_u, dead_x, dead_L = next(multi_sampler)
+    logZ = shell + dead_L
+    H = dead_L - logZ
+    ndim = dead_u.shape[1]
     # live points of each data set at its termination, in order of increasing likelihood
-    tail_u = numpy.zeros((nlive, ndata, ndim))
-    tail_x = numpy.zeros((nlive, ndata, ndim))
-    tail_L = numpy.zeros((nlive, ndata))
-    tail_w = numpy.zeros(ndata)
+    tail_u = numpy.zeros((nlive, ntotal, ndim))
+    tail_x = numpy.zeros((nlive, ntotal, ndim))
+    tail_L = numpy.zeros((nlive, ntotal))
+    tail_w = numpy.zeros(ntotal)
+    it = 0
     while True:
-        i = i + 1
-        logwidth = log(1 - exp(-1. / nlive)) + logVolremaining
-        logVolremaining -= 1. / nlive
+        it += 1
+        logwidth = log(1 - exp(-1. / nlive)) + log_volume
+        log_volume -= 1. / nlive
 
         # one weighted sample per data set; finished data sets get zero weight
-        Lifull = numpy.full(ndata, -numpy.inf)
-        Lifull[running] = Li
-        uifull = numpy.zeros((ndata, ui.shape[1]))
-        uifull[running, :] = ui
-        xifull = numpy.zeros((ndata, ui.shape[1]))
-        xifull[running, :] = xi
-        weights.append([uifull, xifull, Lifull, numpy.where(running, logwidth, -numpy.inf), running])
+        row_L = numpy.full(ntotal, -numpy.inf)
+        row_L[active] = dead_L
+        row_u = numpy.zeros((ntotal, ndim))
+        row_u[active, :] = dead_u
+        row_x = numpy.zeros((ntotal, ndim))
+        row_x[active, :] = dead_x
+        weights.append([row_u, row_x, row_L, numpy.where(active, logwidth, -numpy.inf), active])
 
-        logZerr[running] = (H[running] / nlive) ** 0.5
+        stat_err[active] = (H[active] / nlive) ** 0.5
 
-        if i > min_samples and i % 50 == 1 or (max_samples and i > max_samples):
-            remainderZ, remainderZerr, totalZ, totalZerr, _ = integrate_remainder(
-                sampler, logwidth, logVolremaining, logZ[running], H[running], sampler.Lmax)
-            last_remainderZ[running] = remainderZ
-            last_remainderZerr[running] = remainderZerr
-            terminating = totalZerr < tolerance
-            if max_samples and i > max_samples:
-                terminating[:] = True
-            if terminating.any():
-                log_.debug('iteration %d: terminating %d data sets', i, terminating.sum())
-                for j, k in enumerate(numpy.where(running)[0]):
-                    if terminating[j]:
-                        tail_u[:, k], tail_x[:, k], tail_L[:, k] = sampler.remainder_arrays(j)
+        check = (it > min_samples and it % 50 == 1) or (max_samples and it > max_samples)
+        if check:
+            remZ, remZerr, _, total_err, _ = integrate_remainder(
+                multi_sampler, logwidth, log_volume, logZ[active], H[active], multi_sampler.Lmax)
+            tail_Z[active] = remZ
+            tail_Zerr[active] = remZerr
+            done = total_err < tolerance
+            if max_samples and it > max_samples:
+                done[:] = True
+            if done.any():
+                log_.debug('iteration %d: %d data sets finished', it, done.sum())
+                for j, k in enumerate(numpy.flatnonzero(active)):
+                    if done[j]:
+                        tail_u[:, k], tail_x[:, k], tail_L[:, k] = multi_sampler.remainder_arrays(j)
                         tail_w[k] = logwidth
-                sampler.cut_down(~terminating)
-                running[running] = ~terminating
-            if not running.any():
+                multi_sampler.cut_down(~done)
+                active[active] = ~done
+            if not active.any():
                 break
-        ui, xi, Li = next(sampler)
-        wi = logwidth + Li
-        logZnew = logaddexp(logZ[running], wi)
-        H[running] = exp(wi - logZnew) * Li + exp(logZ[running] - logZnew) * (H[running] + logZ[running]) - logZnew
-        logZ[running] = logZnew
+        dead_u, dead_x, dead_L = next(multi_sampler)
+        logZ[active], H[active] = _absorb(logZ[active], H[active], logwidth, dead_L)
 
     # the live points at termination complete the posterior sample (not needed for logZ)
-    all_tails = numpy.ones(ndata, dtype=bool)
+    everyone = numpy.ones(ntotal, dtype=bool)
     for k in range(nlive):
-        weights.append([tail_u[k], tail_x[k], tail_L[k], tail_w.copy(), all_tails])
-    logZerr = logZerr + last_remainderZerr
-    logZ = logaddexp(logZ, last_remainderZ)
+        weights.append([tail_u[k], tail_x[k], tail_L[k], tail_w.copy(), everyone])
 
     # the reference returns its loop variable after the tail loop, i.e. nlive-1
     # (SURVEY.md appendix A#12); sample.py reports len(weights) instead.  We keep that quirk
     # under the reference's key and add the true count.
-    return dict(logZ=logZ, logZerr=logZerr, weights=weights, information=H,
-                niterations=nlive - 1, nsamples=i)
+    return dict(logZ=logaddexp(logZ, tail_Z), logZerr=stat_err + tail_Zerr, weights=weights,
+                information=H, niterations=nlive - 1, nsamples=it)
 
 
 __all__ = ['multi_nested_integrator', 'integrate_remainder']
