@@ -447,3 +447,23 @@ def test_device_side_threshold_matches_host(nb, oracle):
         ms.set_radius(r)
         assert np.array_equal(ms.count(cand), want)         # threshold computed on the host
         ms.close()
+
+
+@pytest.mark.parametrize("nd,nx", [(601, 96), (530, 700), (515, 4096)])
+def test_k2_two_rows_per_workgroup_vs_oracle(oracle, nd, nx):
+    """Enough spectra and candidates (M >= 512, B >= 4) to take k_muse_rows2, with an odd row
+    count, against the oracle; plus a sparse selection that falls back to k_muse_rows."""
+    from massivedatans_amd.like import MuseSpectra
+    cube = gen.muse_like(nd, nx=nx)
+    sp = MuseSpectra(cube["x"], cube["y"], cube["v"])
+    rng = np.random.RandomState(nx)
+    B = 5
+    pars = np.column_stack([rng.uniform(-0.5, 0.5, B), rng.uniform(0, 0.02, B), rng.uniform(-0.1, 0.2, B),
+                            rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
+    ypred = np.array([gen.muse_template(cube["x"], p) for p in pars])
+    for mask in (np.ones(nd, bool), rng.uniform(size=nd) < 0.2):
+        got = sp.loglike_batch(ypred, mask)
+        for b in range(B):
+            want = oracle.muse_like(cube["y"], cube["v"], np.ascontiguousarray(ypred[b]), mask)[mask]
+            assert rel_err(got[b], want) < 1e-11
+    sp.close()
