@@ -119,6 +119,27 @@ def save_results(prefix, results, sampler, duration, ndata):
                        nevals=int(sampler.nevals)), f, indent=4)
 
 
+def distributed_backend(x, y):
+    """One process per GPU (torchrun): every rank runs the same host orchestration from the
+    same seed, scores only its contiguous block of spectra on its own GPU and all-gathers the
+    likelihood columns over RCCL, so all ranks take identical decisions (the 2-rank CPU test
+    reproduces the reference trace bit for bit this way).  Returns None in a single process."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1 and os.environ.get('MDNS_FORCE_DIST') != '1':
+        return None
+    # torch first: its HIP runtime must be the process's one runtime (see bench.py)
+    import torch
+    import torch.distributed as dist
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    if not dist.is_initialized():
+        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    os.environ.setdefault('MDNS_DEVICE', str(local_rank))
+    from .like import GaussLineSpectra
+    from .parallel import ShardedGaussLine
+    return ShardedGaussLine(x, y, lambda xs, ys: GaussLineSpectra(xs, ys, noise_level=noise_level))
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     if len(argv) < 3:
@@ -131,11 +152,18 @@ def main(argv=None):
     if constrainer_type != 'MLFRIENDS':
         sys.exit("CONSTRAINER=%s is not available: only MLFRIENDS runs on the accelerated path" % constrainer_type)
     nlive_points = int(os.environ.get('NLIVE_POINTS', '400'))
+    backend = distributed_backend(data['x'], data['y'])
     results, sampler, problem, duration = run(
-        data['x'], data['y'], nlive_points=nlive_points,
+        data['x'], data['y'], nlive_points=nlive_points, backend=backend,
         nsuperset_draws=int(os.environ.get('SUPERSET_DRAWS', '10')),
         use_graph=os.environ.get('USE_GRAPH', '1') == '1',
         max_samples=int(os.environ.get('MAXSAMPLES', 0)), min_samples=int(os.environ.get('MINSAMPLES', 0)))
+    if backend is not None:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if int(os.environ.get('RANK', '0')) != 0:
+        return                                     # every rank holds the same results; rank 0 writes
     prefix = '%s_%s_nlive%d_%d.out8' % (argv[1], constrainer_type, nlive_points, ndata)
     save_results(prefix, results, sampler, duration, ndata)
     print('logZ = %.1f +- %.1f' % (results['logZ'][0], results['logZerr'][0]))

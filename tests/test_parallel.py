@@ -37,6 +37,31 @@ def _worker(rank, world, port, q):
             want = np.unique(np.concatenate(allids))
             ok &= np.array_equal(uniq, want) and np.array_equal(pts, pile[want])
         lo, hi = parallel.shard_range(37, rank, world)
+        # the WHOLE analysis, SPMD: every rank runs the same host orchestration (same seed),
+        # scores only its block of spectra and all-gathers the likelihood columns; the result
+        # must be the reference trace, bit for bit, on every rank
+        from massivedatans_amd import sample
+        from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
+        import oracle_backend
+
+        class _MP(object):
+            def setattr(self, obj, name, val):
+                setattr(obj, name, val)
+
+        oracle_backend.patch_neighbors(_MP(), orc)
+        with np.load(os.path.join(ROOT, "tests", "golden", "trace_horns12.npz")) as f:
+            g = {k: f[k] for k in f.files}
+        d12 = gen.horns(12)
+        backend = parallel.ShardedGaussLine(d12["x"], d12["y"], lambda x, y: OracleSpectra(orc, x, y))
+        problem = sample.GaussLineProblem(d12["x"], d12["y"], backend=backend)
+        sampler = sample.build_sampler(problem, nlive_points=int(g["nlive"]), nsuperset_draws=int(g["nsuperset_draws"]),
+                                       use_graph=False, seed=1, batched=True)
+        with np.errstate(all="ignore"):
+            res = multi_nested_integrator(tolerance=0.5, multi_sampler=sampler, min_samples=0,
+                                          max_samples=int(g["max_samples"]))
+        ok &= sampler.ndraws == int(g["ndraws"]) and np.array_equal(res["logZ"], g["logZ"])
+        ok &= np.array_equal(sampler.live_pointsp, g["final_live_pointsp"])
+        ok &= np.random.uniform() == float(g["rng_probe"])
         q.put((rank, bool(ok), lo, hi))
     finally:
         dist.destroy_process_group()
