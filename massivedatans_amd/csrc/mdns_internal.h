@@ -17,6 +17,7 @@ struct Context {
 	int device = -1;
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;     // stream every launch goes to (own_stream unless overridden)
+	hipStream_t copy_stream = nullptr;  // small result read-backs that must not block the launch stream
 	int num_cus = 256;
 	// grow-only scratch: device workspace and pinned host staging
 	void *d_ws = nullptr;   size_t d_ws_bytes = 0;
@@ -86,11 +87,10 @@ bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int
 bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm);
 
 // launchers implemented in mdns_neighbors.hip
-// threshold on the squared distance: *d_thresh when d_thresh != nullptr, else thresh_sq
+// threshold on the squared distance: thresh_sq, or -- when d_round_sq != nullptr -- derived in
+// the kernel from the nround per-round maxima K6 left on the device
 bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
-                         const double *d_thresh, const double *d_cands, int M, int *d_counts);
-// d_state[0] = radius, d_state[1] = membership threshold, from the per-round maxima of K6
-bool launch_radius_threshold(const double *d_round_sq, int nb, double *d_state);
+                         const double *d_round_sq, int nround, const double *d_cands, int M, int *d_counts);
 bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_chosen,
                       int nbootstraps, double *d_round_sq);
 bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out);

@@ -54,6 +54,8 @@ __device__ __forceinline__ double sq_distance_fixed(const double *a, const doubl
 	return acc;
 }
 
+__device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb, double &radius, double &thresh);
+
 // ---------------------------------------------------------------------------------------
 // K3 / K4: how many members lie strictly within the radius of each candidate
 // ---------------------------------------------------------------------------------------
@@ -63,13 +65,20 @@ __device__ __forceinline__ double sq_distance_fixed(const double *a, const doubl
 template <int D, int SL>
 __global__ __launch_bounds__(kBlock) void k_count_within(
     const double *__restrict__ members, int K, int ndim, double thresh_value,
-    const double *__restrict__ thresh_ptr, const double *__restrict__ cands, int M,
+    const double *__restrict__ round_sq, int nround, const double *__restrict__ cands, int M,
     int *__restrict__ counts, int kchunk, int tile_n, int accumulate)
 {
 	constexpr int PTS = Geo<SL>::PTS, NSLICE = Geo<SL>::NSLICE;
-	// the threshold either came with the launch or was left in device memory by
-	// k_radius_threshold (a region whose radius was just computed, no host round trip)
-	const double thresh_sq = thresh_ptr ? *thresh_ptr : thresh_value;
+	// the threshold either came with the launch (host-known radius) or is derived here from
+	// the per-round maxima K6 has just left in device memory (stream order, no host round trip)
+	__shared__ double sh_thresh;
+	if (round_sq && threadIdx.x == 0) {
+		double r_unused, t;
+		radius_and_threshold(round_sq, nround, r_unused, t);
+		sh_thresh = t;
+	}
+	if (round_sq) __syncthreads();
+	const double thresh_sq = round_sq ? sh_thresh : thresh_value;
 	extern __shared__ double smem[];
 	double *tile = smem;                                                  // [tile_n][ndim]
 	int *part = reinterpret_cast<int *>(smem + (size_t) tile_n * ndim);   // [4][PTS]
@@ -158,15 +167,16 @@ __global__ void k_pack_chosen(const double *__restrict__ chosen, int K, int nboo
 	mask[i] = m;
 }
 
-// Radius and membership threshold of a region, on the device: state[0] = sqrt(max_b round_sq[b])
-// (cneighbors.c:160-174; sqrt after the max, monotone) and state[1] = the smallest double T
+// Radius and membership threshold of a region, on the device: radius = sqrt(max_b round_sq[b])
+// (cneighbors.c:160-174; sqrt after the max, monotone) and thresh = the smallest double T
 // with sqrt(T) >= radius, so that  sqrt(d) < radius  <=>  d < T  (cneighbors.c:88,109).  Same
 // bisection over bit patterns as mdns::sqrt_threshold on the host; hipcc's sqrt(double) is
 // correctly rounded (verified bit for bit against the host on 1.6e7 inputs, and the parity
-// tests compare both paths), so the two agree exactly.  One thread; normally ~5 square roots.
-__global__ void k_radius_threshold(const double *__restrict__ round_sq, int nb, double *__restrict__ state)
+// tests compare both paths), so the two agree exactly.  Run by one lane of every workgroup of
+// the membership kernel that follows a radius computation (normally ~5 square roots): no
+// launch of its own and no host round trip between K6 and K3.
+__device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb, double &radius, double &thresh)
 {
-	if (blockIdx.x != 0 || threadIdx.x != 0) return;
 	double best = 0.0;
 	for (int b = 0; b < nb; b++) {
 		const double v = sqrt(round_sq[b]);
@@ -199,17 +209,8 @@ __global__ void k_radius_threshold(const double *__restrict__ round_sq, int nb, 
 		}
 		T = __longlong_as_double((long long) u);
 	}
-	state[0] = r;
-	state[1] = T;
-}
-
-bool launch_radius_threshold(const double *d_round_sq, int nb, double *d_state)
-{
-	Context *c = ctx();
-	hipLaunchKernelGGL(k_radius_threshold, dim3(1), dim3(64), 0, c->stream, d_round_sq, nb, d_state);
-	hipError_t e = hipGetLastError();
-	if (e != hipSuccess) { set_error("launch of k_radius_threshold failed: %s", hipGetErrorString(e)); return false; }
-	return true;
+	radius = r;
+	thresh = T;
 }
 
 // NN == false (K6, cneighbors.c:137-168): rounds of the window packed in `mask`; a left-out
@@ -328,7 +329,7 @@ static int pick_tile(int ndim, size_t per_member_extra, size_t fixed_bytes)
 	case 7: LAUNCH(7); break; case 8: LAUNCH(8); break; default: LAUNCH(0); break; }
 
 bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
-                         const double *d_thresh, const double *d_cands, int M, int *d_counts)
+                         const double *d_round_sq, int nround, const double *d_cands, int M, int *d_counts)
 {
 	Context *c = ctx();
 	const size_t fixed = 4 * 64 * sizeof(int);
@@ -353,9 +354,9 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	dim3 grid(gx, gy);
 	ProfileScope prof(2);
 #define COUNT_LAUNCH(D) do { if (small) hipLaunchKernelGGL((k_count_within<D, 4>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, thresh_sq, d_thresh, d_cands, M, d_counts, kchunk, tile_n, accumulate); \
+		d_members, K, ndim, thresh_sq, d_round_sq, nround, d_cands, M, d_counts, kchunk, tile_n, accumulate); \
 	else hipLaunchKernelGGL((k_count_within<D, 1>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, thresh_sq, d_thresh, d_cands, M, d_counts, kchunk, tile_n, accumulate); } while (0)
+		d_members, K, ndim, thresh_sq, d_round_sq, nround, d_cands, M, d_counts, kchunk, tile_n, accumulate); } while (0)
 	MDNS_DIM_SWITCH(ndim, COUNT_LAUNCH)
 #undef COUNT_LAUNCH
 	return launched("k_count_within");
