@@ -1,15 +1,17 @@
 // RadFriends geometry kernels for gfx950 (MI355X): the all-pairs distance tests that replace
-// clustering/cneighbors.c.  Members (the live-point pool) are tiled through LDS; every lane
-// owns one candidate (K3/K4) or one pool point (K5/K6) and reads the tile by LDS broadcast.
+// clustering/cneighbors.c.  Members (the live-point pool) are tiled through LDS; a lane is a
+// (point, member-slice) pair: one candidate (K3/K4) or one pool point (K5/K6) and a share of
+// the members (see Geo below).
 //
 // Integer / bit exactness.  The squared distance is accumulated from 0 over the dimensions in
 // ascending order with separate multiply and add (no FMA: this file is compiled with
 // -ffp-contract=off and says so again below), which is the arithmetic of cneighbors.c:55-58.
 // The reference then tests  sqrt(d) < r  (cneighbors.c:88,109); since the correctly rounded
 // square root is monotone that is  d < T  with T = the smallest double whose root is >= r,
-// found on the host (mdns::sqrt_threshold), so no device sqrt is needed.  For the radii
-// (cneighbors.c:64-71,160-174) the root is taken once, on the host, after the max of the
-// min squared distances -- the same number because sqrt is monotone.
+// found on the host (mdns::sqrt_threshold) or, right after a radius computation, by one lane
+// of each membership workgroup (radius_and_threshold); the inner loops need no sqrt.  For the
+// radii (cneighbors.c:64-71,160-174) the root is taken once after the max of the min squared
+// distances -- the same number because sqrt is monotone.
 #include "mdns_internal.h"
 
 #pragma clang fp contract(off)
