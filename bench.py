@@ -117,7 +117,7 @@ def hbm_regime_leg(lib, _lib, ndata=1000000, nx=200, reps=20):
     lib.mdns_dev_free(d_L)
     lib.mdns_spectra_destroy(sp)
     gbs = ndata * (8 * nx + 8) / (us * 1e-6) / 1e9
-    return {"kernel": "k_gauss_rows", "workload": "%d spectra x %d channels (%.1f GB > 256 MiB Infinity Cache), "
+    return {"kernel": (lib.mdns_profile_kernel(0) or b"").decode(), "workload": "%d spectra x %d channels (%.1f GB > 256 MiB Infinity Cache), "
                                                   "1 candidate per pass" % (ndata, nx, ndata * nx * 8 / 1e9),
             "bound": "hbm", "launch_us": us, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": gbs / HBM_PEAK_GBS, "evals_per_s": ndata / (us * 1e-6)}
@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--pool", type=int, default=4 * NLIVE, help="unique live points in the pool (K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1.6 GB one-pass HBM-regime measurement")
+    ap.add_argument("--event-every", type=int, default=4, help="time every n-th launch of the dominant kernel")
+    ap.add_argument("--no-events", action="store_true", help="no per-launch events in the timed loop (roofline empty)")
     ap.add_argument("--workload", default="horns", choices=["horns", "nothing"])
     args = ap.parse_args()
 
@@ -226,7 +228,10 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    lib.mdns_profile(1)
+    # events only around the dominant kernel (every timed launch adds two event records), and its
+    # launches are sampled (every 4th), which keeps the cost of measuring out of `value`
+    lib.mdns_profile_every(args.event_every)
+    lib.mdns_profile(1 if not args.no_events else 0)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -235,7 +240,6 @@ def main():
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     fence()
-    lib.mdns_profile(0)
 
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -246,11 +250,19 @@ def main():
     n_launch, tot_ms = C.c_longlong(0), C.c_double(0)
     lib.mdns_profile_read(0, C.byref(n_launch), C.byref(tot_ms))
     k1_ms = tot_ms.value / max(1, n_launch.value)
+    kernel = (lib.mdns_profile_kernel(0) or b"").decode()      # e.g. "k_gauss_cols<8, 1>"
+    # the geometry kernels of the step, timed in a few extra (unreported) steps
+    lib.mdns_profile_every(1)
+    lib.mdns_profile(4 | 8)
+    for _ in range(min(args.steps, 50)):
+        step()
     other = {}
     for which, name in ((2, "count_within"), (3, "bootstrap")):
         n2, ms2 = C.c_longlong(0), C.c_double(0)
         lib.mdns_profile_read(which, C.byref(n2), C.byref(ms2))
         other[name + "_us"] = 1e3 * ms2.value / max(1, n2.value)
+    lib.mdns_profile(0)
+    fence()
 
     # sanity: the timed launches produced the right numbers (first candidate, a few spectra)
     L = np.empty(B * nd)
@@ -270,8 +282,8 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("k_gauss_rows_bytes_per_launch")
+            try:       # HBM bytes per launch of that kernel, from the committed --pmc passes
+                traffic = json.load(open(pmc))["kernels"]["mdns::" + kernel]["hbm_bytes"]
             except Exception:      # noqa: BLE001
                 traffic = None
         res = {
@@ -285,7 +297,7 @@ def main():
                                    % (args.workload, nd, nx, NLIVE, K, B),
                        "spectra_per_gpu": nd, "channels": nx, "candidates_per_step": B, "pool_points": K,
                        "parallelism": "datasets sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "k_gauss_rows", "achieved": achieved, "peak": HBM_PEAK_GBS,
+            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "launch_us": 1e3 * k1_ms, "launches_timed": int(n_launch.value),
                          "algorithmic_bytes_per_launch": alg_bytes,

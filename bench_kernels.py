@@ -20,7 +20,7 @@ def timed(lib, which, fn, reps=REPS, warm=3):
     for _ in range(warm):
         fn()
     lib.mdns_sync()
-    lib.mdns_profile(1)
+    lib.mdns_profile(15)
     for _ in range(reps):
         fn()
     lib.mdns_sync()

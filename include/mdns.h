@@ -176,12 +176,20 @@ int mdns_event_record(void *ev);
 double mdns_event_elapsed_ms(void *ev_start, void *ev_stop);   /* synchronises on ev_stop */
 
 /* Per-launch timing of the dominant kernels with HIP events on the library stream.
- * mdns_profile(1) clears the statistics and starts recording, mdns_profile(0) stops.
- * mdns_profile_read synchronises and returns, for kernel class `which` (0 = gauss rows,
- * 1 = muse rows, 2 = count-within, 3 = bootstrap nearest-chosen), the number of launches
- * timed and the sum of their durations in milliseconds. */
-int mdns_profile(int enable);
+ * Kernel classes: 0 = gauss log-likelihood, 1 = muse log-likelihood, 2 = count-within,
+ * 3 = bootstrap nearest-chosen.  mdns_profile(classes) takes a bit mask (bit k = class k; 15 =
+ * all): it clears the statistics of the named classes and records from now on exactly those;
+ * mdns_profile(0) stops.  Every timed launch costs two event records on the stream (about
+ * 9 us per 90 us step of bench.py when every launch is timed), so time only what is being
+ * measured; mdns_profile_every(n) times every n-th launch of a class only (default 1).
+ * mdns_profile_read synchronises and returns, for kernel class `which`, the number of launches
+ * timed and the sum of their durations in milliseconds.  mdns_profile_kernel names the
+ * kernel instantiation last launched for that class (as rocprofv3 prints it, without the
+ * namespace), e.g. "k_gauss_cols<8, 1>". */
+int mdns_profile(int classes);
+int mdns_profile_every(int n);
 int mdns_profile_read(int which, long long *launches, double *total_ms);
+const char *mdns_profile_kernel(int which);
 
 /* d_params f64[B,3], d_row_ids int32[M] or NULL, d_Lout f64[B,M]. */
 int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_params, int B,

@@ -27,7 +27,7 @@ ABI_SYMBOLS = (
     "mdns_region_radius", "mdns_region_count", "mdns_region_count_dev",
     "mdns_dev_alloc", "mdns_dev_free", "mdns_h2d", "mdns_d2h", "mdns_sync", "mdns_set_stream",
     "mdns_event_create", "mdns_event_destroy", "mdns_event_record", "mdns_event_elapsed_ms",
-    "mdns_profile", "mdns_profile_read",
+    "mdns_profile", "mdns_profile_every", "mdns_profile_read", "mdns_profile_kernel",
     "mdns_gauss_loglike_batch_dev", "mdns_muse_loglike_batch_dev", "mdns_muse3_loglike_batch_dev",
     "mdns_count_within_dev", "mdns_bootstrap_round_maxsq_dev",
 )
@@ -85,7 +85,9 @@ def _declare(lib):
         "mdns_event_record": (i, [vp]),
         "mdns_event_elapsed_ms": (d, [vp, vp]),
         "mdns_profile": (i, [i]),
+        "mdns_profile_every": (i, [i]),
         "mdns_profile_read": (i, [i, vp, vp]),
+        "mdns_profile_kernel": (C.c_char_p, [i]),
         "mdns_gauss_loglike_batch_dev": (i, [vp, vp, i, d, vp, i, vp]),
         "mdns_muse_loglike_batch_dev": (i, [vp, vp, i, vp, i, vp]),
         "mdns_muse3_loglike_batch_dev": (i, [vp, vp, i, vp, i, vp]),

@@ -162,7 +162,9 @@ double sqrt_threshold(double r)
 // per-launch event timing
 // ---------------------------------------------------------------------------------------
 struct TimedLaunch { int which; hipEvent_t start, stop; };
-static bool g_profiling = false;
+static long long g_prof_seen[4];
+static int g_prof_every = 1;
+static int g_profiling = 0;                   // bit k: time launches of kernel class k
 static std::vector<TimedLaunch> g_pending;
 static std::vector<hipEvent_t> g_event_pool;
 static long long g_prof_count[4] = {0, 0, 0, 0};
@@ -192,7 +194,8 @@ static void drain_pending()
 
 ProfileScope::ProfileScope(int which) : slot(-1)
 {
-	if (!g_profiling || !g_ctx_ready) return;
+	if (!(g_profiling & (1 << which)) || !g_ctx_ready) return;
+	if (g_prof_seen[which]++ % g_prof_every != 0) return;      // sampled: every n-th launch of a class
 	TimedLaunch t{which, pooled_event(), pooled_event()};
 	if (!t.start || !t.stop) return;
 	(void) hipEventRecord(t.start, g_ctx.stream);
@@ -304,13 +307,32 @@ extern "C" double mdns_event_elapsed_ms(void *a, void *b)
 	return (double) ms;
 }
 
-extern "C" int mdns_profile(int enable)
+extern "C" int mdns_profile(int classes)
 {
 	if (!ctx()) return 1;
 	drain_pending();
-	if (enable) for (int k = 0; k < 4; k++) { g_prof_count[k] = 0; g_prof_ms[k] = 0; }
-	g_profiling = enable != 0;
+	for (int k = 0; k < 4; k++)
+		if (classes & (1 << k)) { g_prof_count[k] = 0; g_prof_ms[k] = 0; g_prof_seen[k] = 0; }
+	g_profiling = classes & 15;
 	return 0;
+}
+extern "C" int mdns_profile_every(int n)
+{
+	g_prof_every = n > 1 ? n : 1;
+	return 0;
+}
+static char g_kernel_name[4][64];
+void mdns::note_kernel(int which, const char *fmt, ...)
+{
+	if (which < 0 || which > 3) return;
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_kernel_name[which], sizeof g_kernel_name[which], fmt, ap);
+	va_end(ap);
+}
+extern "C" const char *mdns_profile_kernel(int which)
+{
+	return which >= 0 && which <= 3 ? g_kernel_name[which] : "";
 }
 extern "C" int mdns_profile_read(int which, long long *launches, double *total_ms)
 {

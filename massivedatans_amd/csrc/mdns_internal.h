@@ -102,6 +102,8 @@ struct ProfileScope {
 	explicit ProfileScope(int which);
 	~ProfileScope();
 };
+// name of the kernel instantiation last launched for class `which` (mdns_profile_kernel)
+void note_kernel(int which, const char *fmt, ...);
 
 // smallest double T with sqrt(T) >= r, so that  sqrt(d) < r  <=>  d < T  for every d >= 0
 double sqrt_threshold(double r);

@@ -654,6 +654,7 @@ bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, i
 	const int nq_xcd = (nquads + 7) / 8;                      // quads per XCD (some may be empty)
 	const int blocks = 8 * nq_xcd * nbt;
 	ProfileScope prof(0);
+	note_kernel(0, "k_gauss_cols<%d, %d>", bt, (int) sp);
 #define COLS_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols<BT, sp>), dim3(blocks), dim3(kBlock), 0, c->stream, \
 	s->d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, d_out)
 	switch (bt) {
@@ -721,6 +722,7 @@ static void launch_gauss_rows_t(const mdns_spectra *s, const double *d_model, in
 	const int cap = num_cus * 8;
 	if (blocks > cap) blocks = cap;
 	if (blocks < 1) blocks = 1;
+	note_kernel(0, "k_gauss_rows<%d, %d, %d, %s>", NP, BT, R, B <= BT ? "true" : "false");
 	if (B <= BT)
 		hipLaunchKernelGGL((k_gauss_rows<NP, BT, R, true>), dim3(blocks), dim3(kBlock), 0, stream,
 		                   s->d_y, s->ld, s->nx, d_model, ldm, B, scale, d_rows, M, d_out);

@@ -56,6 +56,28 @@ __device__ __forceinline__ double sq_distance_fixed(const double *a, const doubl
 	return acc;
 }
 
+// Copies `count` words from global memory into LDS with all of a thread's loads in flight at
+// once (a plain strided copy loop is compiled to load -> wait -> store per trip, i.e. one full
+// memory latency per 256 words: that was 10 of the 14 us of the K = 400 bootstrap kernel).
+template <typename T>
+__device__ __forceinline__ void stage_to_lds(T *__restrict__ dst, const T *__restrict__ src, int count)
+{
+	constexpr int U = 8;
+	for (int base = 0; base < count; base += U * kBlock) {
+		T r[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int e = base + u * kBlock + (int) threadIdx.x;
+			r[u] = src[e < count ? e : count - 1];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int e = base + u * kBlock + (int) threadIdx.x;
+			if (e < count) dst[e] = r[u];
+		}
+	}
+}
+
 __device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb, double &radius, double &thresh);
 
 // ---------------------------------------------------------------------------------------
@@ -74,13 +96,6 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 	// the threshold either came with the launch (host-known radius) or is derived here from
 	// the per-round maxima K6 has just left in device memory (stream order, no host round trip)
 	__shared__ double sh_thresh;
-	if (round_sq && threadIdx.x == 0) {
-		double r_unused, t;
-		radius_and_threshold(round_sq, nround, r_unused, t);
-		sh_thresh = t;
-	}
-	if (round_sq) __syncthreads();
-	const double thresh_sq = round_sq ? sh_thresh : thresh_value;
 	extern __shared__ double smem[];
 	double *tile = smem;                                                  // [tile_n][ndim]
 	int *part = reinterpret_cast<int *>(smem + (size_t) tile_n * ndim);   // [4][PTS]
@@ -98,12 +113,21 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 #pragma unroll
 		for (int k = 0; k < D; k++) c[k] = cands[(size_t) jj * D + k];
 	}
+	// one lane derives the threshold while the others wait for the first tile's loads; it is
+	// read after the barrier that publishes that tile
+	if (round_sq && threadIdx.x == 0) {
+		double r_unused, t;
+		radius_and_threshold(round_sq, nround, r_unused, t);
+		sh_thresh = t;
+	}
+	double thresh_sq = thresh_value;
 	int hits = 0;
 	for (int t0 = kbeg; t0 < kend; t0 += tile_n) {
 		const int n = min(tile_n, kend - t0);
 		__syncthreads();
-		for (int e = threadIdx.x; e < n * ndim; e += kBlock) tile[e] = members[(size_t) t0 * ndim + e];
+		stage_to_lds(tile, members + (size_t) t0 * ndim, n * ndim);
 		__syncthreads();
+		if (round_sq) thresh_sq = sh_thresh;
 		if (D > 0) {
 #pragma unroll 4
 			for (int i = slice; i < n; i += NSLICE)
@@ -224,13 +248,15 @@ __device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb
 // round in which member j is NOT chosen the exponent and quiet bits of the distance are forced
 // to ones (-> quiet NaN), which v_min_f64 discards.  Partial minima of slices and waves meet by
 // shuffles and LDS (min is exact, the split cannot change the result).
-template <int D, bool NN, int SL>
+// RT = rounds carried per pass when !NN: 10 (what the reference's callers ask for,
+// radfriendsregion.py:59: nbootstraps = 10) or kRounds.
+template <int D, bool NN, int SL, int RT>
 __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
     const double *__restrict__ members, int K, int ndim, const unsigned *__restrict__ mask,
     int nb, double *__restrict__ round_sq, int tile_n)
 {
 	constexpr int PTS = Geo<SL>::PTS, NSLICE = Geo<SL>::NSLICE;
-	constexpr int NR = NN ? 1 : kRounds;
+	constexpr int NR = NN ? 1 : RT;
 	extern __shared__ double smem[];
 	double *tile = smem;                                          // [tile_n][ndim]
 	double *part = smem + (size_t) tile_n * ndim;                 // [4][NR][PTS]
@@ -256,8 +282,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 	for (int t0 = 0; t0 < K; t0 += tile_n) {
 		const int n = min(tile_n, K - t0);
 		__syncthreads();
-		for (int e = threadIdx.x; e < n * ndim; e += kBlock) tile[e] = members[(size_t) t0 * ndim + e];
-		if (!NN) for (int e = threadIdx.x; e < n; e += kBlock) tmask[e] = mask[t0 + e];
+		stage_to_lds(tile, members + (size_t) t0 * ndim, n * ndim);
+		if (!NN) stage_to_lds(tmask, mask + t0, n);
 		__syncthreads();
 		for (int jn = slice; jn < n; jn += NSLICE) {
 			double d;
@@ -390,12 +416,14 @@ static bool launch_nearest(const double *d_members, int K, int ndim, const doubl
 			if (!launched("k_pack_chosen")) return false;
 		}
 		ProfileScope prof(3);
-#define NEAR_LAUNCH(D) do { if (small) hipLaunchKernelGGL((k_nearest_chosen<D, NN, 4>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n); \
-	else hipLaunchKernelGGL((k_nearest_chosen<D, NN, 1>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n); } while (0)
+#define NEAR_LAUNCH_R(D, SL, RT) hipLaunchKernelGGL((k_nearest_chosen<D, NN, SL, RT>), grid, dim3(kBlock), lds, c->stream, \
+		d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n)
+#define NEAR_LAUNCH(D) do { \
+	if (small) { if (NN || nb <= 10) NEAR_LAUNCH_R(D, 4, 10); else NEAR_LAUNCH_R(D, 4, kRounds); } \
+	else       { if (NN || nb <= 10) NEAR_LAUNCH_R(D, 1, 10); else NEAR_LAUNCH_R(D, 1, kRounds); } } while (0)
 		MDNS_DIM_SWITCH(ndim, NEAR_LAUNCH)
 #undef NEAR_LAUNCH
+#undef NEAR_LAUNCH_R
 		if (!launched("k_nearest_chosen")) return false;
 	}
 	return true;

@@ -14,8 +14,10 @@ functions return, so they can be fed to the drop-in ``like()`` entry points unch
 device-resident layout ``[n_datasets, n_channels]`` is produced at upload time
 (:class:`massivedatans_amd.like.GaussLineData`).
 
-h5py is not available in this image, so :func:`save` / :func:`load` use ``.npz`` with the
-reference's dataset names.
+File containers: a path ending in ``.hdf5`` / ``.h5`` is read and written through h5py exactly as
+the reference does (same dataset names, gzip + shuffle), so files of the reference's generators
+can be fed in directly -- where h5py is installed.  It is not in this image (nor on the GPU
+box), so everything here and in the tests uses ``.npz`` with the reference's dataset names.
 """
 import numpy as np
 
@@ -102,14 +104,49 @@ def muse_like(n, nx=4096):
     return dict(x=x, y=y, v=v, z=z, scale=scale)
 
 
+def _is_hdf5(path):
+    return str(path).endswith(('.hdf5', '.h5'))
+
+
+def _h5py():
+    try:
+        import h5py
+    except ImportError:
+        raise RuntimeError("reading/writing .hdf5 needs h5py, which is not installed; "
+                           "use a .npz file (gen.save / gen.load) instead")
+    return h5py
+
+
+def write_datasets(path, data):
+    """``data``: name -> array.  ``.hdf5``: one gzip + shuffle dataset per name (scalars plain),
+    as gensimple_horns.py:61-67 and sample.py:202-211 write them; otherwise a compressed .npz."""
+    if _is_hdf5(path):
+        with _h5py().File(path, 'w') as f:
+            for k, v in data.items():
+                v = np.asarray(v)
+                if v.ndim == 0:
+                    f.create_dataset(k, data=v)
+                else:
+                    f.create_dataset(k, data=v, compression='gzip', shuffle=True)
+    else:
+        np.savez_compressed(path, **data)
+
+
+def read_datasets(path):
+    if _is_hdf5(path):
+        with _h5py().File(path, 'r') as f:
+            return {k: np.asarray(f[k][()]) for k in f.keys()}
+    with np.load(path) as f:
+        return {k: f[k] for k in f.files}
+
+
 def save(path, data):
-    np.savez(path, **data)
+    write_datasets(path, data)
 
 
 def load(path, ndata=None):
     """Counterpart of sample.py:28-31: ``x`` and the first ``ndata`` columns of ``y``."""
-    with np.load(path) as f:
-        out = {k: f[k] for k in f.files}
+    out = read_datasets(path)
     if ndata is not None:
         for k in ("y", "v"):
             if k in out:

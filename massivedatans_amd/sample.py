@@ -4,8 +4,9 @@ spectra at once -- wired to the MI355X hot path.
 Problem definition surface kept from the reference (sample.py:44-108):
 ``params``, ``nparams``, ``noise_level``, ``priortransform(cube)``,
 ``multi_loglikelihood(params, data_mask)``; then the same wiring of constrainers, sampler and
-integrator (sample.py:131-197) and the same outputs (sample.py:200-217; ``.npz`` instead of
-HDF5 because h5py is not available here -- dataset names are kept).
+integrator (sample.py:131-197) and the same outputs (sample.py:200-217).  Input and output are
+HDF5 through h5py where it is installed (``data_widths_100.hdf5`` works as in the reference);
+this image has no h5py, so here both are ``.npz`` with the same dataset names.
 
     python -m massivedatans_amd.sample data_widths_100.npz 100
 
@@ -109,11 +110,18 @@ def run(x, y, nlive_points=400, nsuperset_draws=10, use_graph=False, max_samples
 
 
 def save_results(prefix, results, sampler, duration, ndata):
-    """Outputs of sample.py:200-217 (same dataset names; .npz container)."""
+    """Outputs of sample.py:200-217, same dataset names: ``<prefix>.hdf5`` where h5py is installed
+    (what the reference's plotting scripts read), ``<prefix>.npz`` otherwise."""
+    from . import gen
     u, x, L, w, mask = list(zip(*results['weights']))
-    numpy.savez_compressed(prefix + '.npz', logZ=results['logZ'], logZerr=results['logZerr'],
-                           u=numpy.array(u), x=numpy.array(x), L=numpy.array(L), w=numpy.array(w),
-                           mask=numpy.array(mask), ndraws=sampler.ndraws)
+    try:
+        import h5py  # noqa: F401
+        suffix = '.hdf5'
+    except ImportError:
+        suffix = '.npz'
+    gen.write_datasets(prefix + suffix, dict(
+        logZ=results['logZ'], logZerr=results['logZerr'], u=numpy.array(u), x=numpy.array(x),
+        L=numpy.array(L), w=numpy.array(w), mask=numpy.array(mask), ndraws=sampler.ndraws))
     with open(prefix + '.stats.json', 'w') as f:
         json.dump(dict(ndraws=int(sampler.ndraws), duration=duration, ndata=int(ndata), niter=len(w),
                        nevals=int(sampler.nevals)), f, indent=4)

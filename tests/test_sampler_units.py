@@ -70,3 +70,74 @@ def test_shard_helpers():
     b = parallel.shard_bounds(10007, 8)
     assert b[0] == 0 and b[-1] == 10007 and np.all(np.diff(b) >= 1250) and np.all(np.diff(b) <= 1251)
     assert [parallel.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+
+
+def test_npz_roundtrip_keeps_reference_dataset_names(tmp_path):
+    from massivedatans_amd import gen
+    data = gen.horns(7)
+    path = str(tmp_path / "data_widths_7.npz")
+    gen.save(path, data)
+    back = gen.load(path, 5)
+    assert {"x", "y", "z"} <= set(back)                      # gensimple_horns.py:61-64
+    assert back["y"].shape == (200, 5) and np.array_equal(back["y"], data["y"][:, :5])
+    assert np.array_equal(back["x"], data["x"])
+
+
+class _FakeH5File(dict):
+    """Records what would be written through h5py (not installed in this image)."""
+    store = {}
+
+    def __init__(self, path, mode):
+        super().__init__()
+        self.path, self.mode = path, mode
+        if mode == 'r':
+            self.update({k: v for k, (v, _) in _FakeH5File.store[path].items()})
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+    def create_dataset(self, name, data=None, **kw):
+        _FakeH5File.store.setdefault(self.path, {})[name] = (np.asarray(data), kw)
+
+
+def test_hdf5_container_uses_reference_names_and_filters(tmp_path, monkeypatch):
+    """With h5py present, .hdf5 paths go through it with the reference's dataset names and
+    gzip + shuffle (sample.py:202-211, gensimple_horns.py:61-67)."""
+    import sys, types
+    from massivedatans_amd import gen, sample
+    fake = types.ModuleType("h5py")
+    fake.File = _FakeH5File
+    monkeypatch.setitem(sys.modules, "h5py", fake)
+    data = gen.nothing(4)
+    path = str(tmp_path / "data_nothing_4.hdf5")
+    gen.save(path, data)
+    for name, (arr, kw) in _FakeH5File.store[path].items():
+        assert kw == dict(compression='gzip', shuffle=True), name
+    assert np.array_equal(gen.load(path, 3)["y"], data["y"][:, :3])
+
+    class S:
+        ndraws, nevals = 12, 48
+    w = [[np.zeros((4, 3)), np.zeros((4, 3)), np.zeros(4), np.zeros(4), np.ones(4, bool)]] * 2
+    prefix = str(tmp_path / "out")
+    sample.save_results(prefix, dict(logZ=np.zeros(4), logZerr=np.ones(4), weights=w), S, 1.5, 4)
+    written = _FakeH5File.store[prefix + ".hdf5"]
+    assert set(written) == {"logZ", "logZerr", "u", "x", "L", "w", "mask", "ndraws"}
+    assert written["ndraws"][1] == {} and written["u"][0].shape == (2, 4, 3)
+    import json
+    stats = json.load(open(prefix + ".stats.json"))
+    assert stats["ndraws"] == 12 and stats["ndata"] == 4 and stats["niter"] == 2
+
+
+def test_hdf5_without_h5py_fails_loudly(tmp_path):
+    import pytest
+    from massivedatans_amd import gen
+    try:
+        import h5py  # noqa: F401
+        pytest.skip("h5py is installed")
+    except ImportError:
+        pass
+    with pytest.raises(RuntimeError, match="h5py"):
+        gen.load(str(tmp_path / "x.hdf5"))

@@ -48,7 +48,6 @@ def main():
             "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])}
     dom = [k for k in per_kernel if "k_gauss_cols" in k or "k_gauss_rows" in k]
     out = {"tag": tag, "units": "bytes per launch", "kernels": per_kernel, "durations": durations,
-           "k_gauss_rows_bytes_per_launch": per_kernel[dom[0]]["hbm_bytes"] if dom else None,
            "dominant_kernel": dom[0] if dom else None}
     for name in ("%s_pmc.json" % tag, "pmc_latest.json"):
         with open(os.path.join(ROOT, "profiles", name), "w") as f:
