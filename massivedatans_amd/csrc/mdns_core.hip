@@ -2,6 +2,7 @@
 // Kernels live in mdns_like.hip and mdns_neighbors.hip.
 #include "mdns_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -63,7 +64,6 @@ static int init_locked(int device)
 		if (g_ctx.d_mask) (void) hipFree(g_ctx.d_mask);
 		if (g_ctx.h_pin) (void) hipHostFree(g_ctx.h_pin);
 		if (g_ctx.own_stream) (void) hipStreamDestroy(g_ctx.own_stream);
-		if (g_ctx.copy_stream) (void) hipStreamDestroy(g_ctx.copy_stream);
 		g_ctx = Context();
 		g_ctx_ready = false;
 	}
@@ -73,7 +73,6 @@ static int init_locked(int device)
 	g_ctx.device = device;
 	g_ctx.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
 	if (!MDNS_HIP(hipStreamCreateWithFlags(&g_ctx.own_stream, hipStreamNonBlocking))) return 1;
-	if (!MDNS_HIP(hipStreamCreateWithFlags(&g_ctx.copy_stream, hipStreamNonBlocking))) return 1;
 	g_ctx.stream = g_ctx.own_stream;
 	g_ctx_ready = true;
 	return 0;
@@ -677,7 +676,7 @@ extern "C" int mdns_count_within_dev(const double *d_members, int K, int ndim, d
 	if (K < 0 || M < 0 || ndim <= 0) { set_error("mdns_count_within_dev: bad sizes"); return 1; }
 	if (M == 0) return 0;
 	if (K == 0) return MDNS_HIP(hipMemsetAsync(d_counts, 0, (size_t) M * sizeof(int), c->stream)) ? 0 : 1;
-	return launch_count_within(d_members, K, ndim, sqrt_threshold(maxdistance), nullptr, 0, d_cands, M, d_counts) ? 0 : 1;
+	return launch_count_within(d_members, K, ndim, sqrt_threshold(maxdistance), nullptr, d_cands, M, d_counts) ? 0 : 1;
 }
 
 extern "C" int mdns_bootstrap_round_maxsq_dev(const double *d_members, int K, int ndim,
@@ -803,16 +802,18 @@ struct mdns_region {
 	int K = 0, ndim = 0;
 	double radius = NAN;              // maxdistance, host copy
 	double thresh_sq = NAN;           // membership threshold on squared distances, host copy
-	// After a radius computation the per-round maxima stay in d_round: the membership kernel
-	// derives its threshold from them in its prologue (stream order, no host round trip) while
-	// they travel to the host on the copy stream for the host copies above.
+	// A radius computation ends on the device: the last workgroup of the bootstrap kernel
+	// writes {radius, threshold} to d_res (for the membership kernel, stream order) and to
+	// h_res (mapped host memory), then h_res->seq = seq.  The host polls for that.
 	double *d_round = nullptr;        // per-round max of squared nearest-chosen distances
-	double *h_round = nullptr;        // pinned mirror
 	int round_cap = 0;
-	int nround = 0;                   // rounds of the last radius computation
-	bool on_device = false;           // the membership kernel must use d_round
+	RegionResult *d_res = nullptr;
+	RegionResult *h_res = nullptr;    // hipHostMalloc (mapped, coherent)
+	RegionResult *h_res_dev = nullptr;   // its device address
+	unsigned *d_counter = nullptr;
+	unsigned long long seq = 0;
+	bool on_device = false;           // the membership kernel must use d_res
 	bool pending = false;             // the host copies still have to be fetched (async path)
-	hipEvent_t k6_done = nullptr, ready = nullptr;
 	double *d_chosen = nullptr; size_t chosen_cap = 0;
 	double *d_points = nullptr; size_t points_cap = 0;
 	int *d_counts = nullptr; size_t counts_cap = 0;
@@ -822,9 +823,13 @@ static mdns_region *region_new(const double *d_members, double *owned, int K, in
 {
 	mdns_region *r = new mdns_region();
 	r->d_members = d_members; r->owned = owned; r->K = K; r->ndim = ndim;
-	bool ok = MDNS_HIP(hipEventCreateWithFlags(&r->ready, hipEventDisableTiming));
-	ok = ok && MDNS_HIP(hipEventCreateWithFlags(&r->k6_done, hipEventDisableTiming));
+	bool ok = MDNS_HIP(hipMalloc((void **) &r->d_res, sizeof(RegionResult))) &&
+	          MDNS_HIP(hipMalloc((void **) &r->d_counter, sizeof(unsigned))) &&
+	          MDNS_HIP(hipMemset(r->d_counter, 0, sizeof(unsigned))) &&
+	          MDNS_HIP(hipHostMalloc((void **) &r->h_res, sizeof(RegionResult), hipHostMallocMapped | hipHostMallocCoherent)) &&
+	          MDNS_HIP(hipHostGetDevicePointer((void **) &r->h_res_dev, r->h_res, 0));
 	if (!ok) { mdns_region_destroy(r); return nullptr; }
+	r->h_res->seq = 0;
 	return r;
 }
 
@@ -853,12 +858,9 @@ extern "C" void mdns_region_destroy(mdns_region *r)
 	if (!r) return;
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
-	if (c && c->copy_stream) (void) hipStreamSynchronize(c->copy_stream);
-	void *bufs[] = {r->owned, r->d_round, r->d_chosen, r->d_points, r->d_counts};
+	void *bufs[] = {r->owned, r->d_round, r->d_chosen, r->d_points, r->d_counts, r->d_res, r->d_counter};
 	for (void *b : bufs) if (b) (void) hipFree(b);
-	if (r->h_round) (void) hipHostFree(r->h_round);
-	if (r->ready) (void) hipEventDestroy(r->ready);
-	if (r->k6_done) (void) hipEventDestroy(r->k6_done);
+	if (r->h_res) (void) hipHostFree(r->h_res);
 	delete r;
 }
 
@@ -876,11 +878,21 @@ extern "C" int mdns_region_set_radius(mdns_region *r, double maxdistance)
 static bool region_fetch(mdns_region *r)
 {
 	if (!r->pending) return true;
-	if (!MDNS_HIP(hipEventSynchronize(r->ready))) return false;
-	double best = 0;          // cneighbors.c:160-174; sqrt after the max (monotone)
-	for (int b = 0; b < r->nround; b++) { const double v = std::sqrt(r->h_round[b]); if (v > best) best = v; }
-	r->radius = best;
-	r->thresh_sq = sqrt_threshold(best);     // the kernels derive the same number (tested)
+	Context *c = ctx();
+	volatile unsigned long long *seq = &r->h_res->seq;
+	// The result usually is there already (the caller has launched other work meanwhile).
+	// While polling, look at the stream now and then: once it has drained, everything the
+	// kernel wrote is visible, and a failed launch shows up as an error instead of a hang.
+	for (unsigned spin = 0; *seq != r->seq; spin++) {
+		if ((spin & 1023) != 1023) continue;
+		const hipError_t e = hipStreamQuery(c->stream);
+		if (e == hipErrorNotReady) continue;
+		if (e != hipSuccess) { set_error("radius computation failed: %s", hipGetErrorString(e)); return false; }
+		if (*seq != r->seq) { set_error("radius computation finished without a result"); return false; }
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	r->radius = r->h_res->radius;
+	r->thresh_sq = sqrt_threshold(r->radius);     // the device derived the same number (tested)
 	r->pending = false;
 	return true;
 }
@@ -900,18 +912,13 @@ extern "C" int mdns_region_bootstrap_radius_async(mdns_region *r, const double *
 	if (r->round_cap < nbootstraps) {
 		(void) hipStreamSynchronize(c->stream);
 		if (r->d_round) { (void) hipFree(r->d_round); r->d_round = nullptr; }
-		if (r->h_round) { (void) hipHostFree(r->h_round); r->h_round = nullptr; }
 		if (!MDNS_HIP(hipMalloc((void **) &r->d_round, (size_t) nbootstraps * sizeof(double)))) return 1;
-		if (!MDNS_HIP(hipHostMalloc((void **) &r->h_round, (size_t) nbootstraps * sizeof(double), hipHostMallocDefault))) return 1;
+		// zero once: every finishing computation hands its slots back zeroed
+		if (!MDNS_HIP(hipMemsetAsync(r->d_round, 0, (size_t) nbootstraps * sizeof(double), c->stream))) return 1;
 		r->round_cap = nbootstraps;
 	}
-	if (!launch_bootstrap(r->d_members, r->K, r->ndim, d_chosen, nbootstraps, r->d_round)) return 1;
-	// the maxima go home on the copy stream, so the membership kernel need not queue behind them
-	if (!MDNS_HIP(hipEventRecord(r->k6_done, c->stream))) return 1;
-	if (!MDNS_HIP(hipStreamWaitEvent(c->copy_stream, r->k6_done, 0))) return 1;
-	if (!MDNS_HIP(hipMemcpyAsync(r->h_round, r->d_round, (size_t) nbootstraps * sizeof(double), hipMemcpyDeviceToHost, c->copy_stream))) return 1;
-	if (!MDNS_HIP(hipEventRecord(r->ready, c->copy_stream))) return 1;
-	r->nround = nbootstraps;
+	const BootstrapFinish fin = {r->d_counter, r->d_res, r->h_res_dev, ++r->seq};
+	if (!launch_bootstrap(r->d_members, r->K, r->ndim, d_chosen, nbootstraps, r->d_round, &fin)) return 1;
 	r->on_device = true;
 	r->pending = true;
 	return 0;
@@ -940,10 +947,10 @@ extern "C" int mdns_region_count_dev(mdns_region *r, const double *d_points, int
 	if (M < 0) { set_error("mdns_region_count: M=%d", M); return 1; }
 	if (M == 0) return 0;
 	if (!r->on_device && r->radius != r->radius) { set_error("mdns_region_count: the region has no radius yet"); return 1; }
-	// right after a radius computation the kernel derives the threshold from the per-round
-	// maxima in device memory (stream order)
-	return launch_count_within(r->d_members, r->K, r->ndim, r->thresh_sq, r->on_device ? r->d_round : nullptr,
-	                           r->nround, d_points, M, d_counts) ? 0 : 1;
+	// right after a radius computation the kernel takes the threshold the bootstrap kernel
+	// left in device memory (stream order)
+	return launch_count_within(r->d_members, r->K, r->ndim, r->thresh_sq, r->on_device ? r->d_res : nullptr,
+	                           d_points, M, d_counts) ? 0 : 1;
 }
 
 extern "C" int mdns_region_count(mdns_region *r, const double *points, int M, int *counts)

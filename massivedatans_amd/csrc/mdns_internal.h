@@ -17,7 +17,6 @@ struct Context {
 	int device = -1;
 	hipStream_t own_stream = nullptr;
 	hipStream_t stream = nullptr;     // stream every launch goes to (own_stream unless overridden)
-	hipStream_t copy_stream = nullptr;  // small result read-backs that must not block the launch stream
 	int num_cus = 256;
 	// grow-only scratch: device workspace and pinned host staging
 	void *d_ws = nullptr;   size_t d_ws_bytes = 0;
@@ -87,12 +86,29 @@ bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int
 bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm);
 
 // launchers implemented in mdns_neighbors.hip
-// threshold on the squared distance: thresh_sq, or -- when d_round_sq != nullptr -- derived in
-// the kernel from the nround per-round maxima K6 left on the device
+// What a radius computation leaves behind: written by the LAST workgroup of the bootstrap
+// kernel to finish (it alone knows that all per-round maxima are final), once into device
+// memory for the membership kernel that follows in stream order and once into mapped host
+// memory, where the host finds it by polling `seq` -- no event, no copy, no second stream.
+struct RegionResult {
+	double radius;                 // sqrt(max_b round_sq[b])            cneighbors.c:160-174
+	double thresh;                 // smallest T with sqrt(T) >= radius  cneighbors.c:88,109
+	unsigned long long seq;        // written last
+	unsigned long long pad;
+};
+struct BootstrapFinish {
+	unsigned *counter;             // device; zero outside a launch
+	RegionResult *d_res;           // device copy
+	RegionResult *h_res;           // mapped, host-coherent copy
+	unsigned long long seq;        // the value `seq` takes for this computation
+};
+
+// threshold on the squared distance: thresh_sq, or -- when d_res != nullptr -- the one the
+// preceding radius computation left on the device
 bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
-                         const double *d_round_sq, int nround, const double *d_cands, int M, int *d_counts);
+                         const RegionResult *d_res, const double *d_cands, int M, int *d_counts);
 bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_chosen,
-                      int nbootstraps, double *d_round_sq);
+                      int nbootstraps, double *d_round_sq, const BootstrapFinish *finish = nullptr);
 bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out);
 
 // optional per-launch event timing (mdns_profile); which: 0 gauss rows, 1 muse rows,

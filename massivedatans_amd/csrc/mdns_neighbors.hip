@@ -8,8 +8,8 @@
 // -ffp-contract=off and says so again below), which is the arithmetic of cneighbors.c:55-58.
 // The reference then tests  sqrt(d) < r  (cneighbors.c:88,109); since the correctly rounded
 // square root is monotone that is  d < T  with T = the smallest double whose root is >= r,
-// found on the host (mdns::sqrt_threshold) or, right after a radius computation, by one lane
-// of each membership workgroup (radius_and_threshold); the inner loops need no sqrt.  For the
+// found on the host (mdns::sqrt_threshold) or, at the end of a radius computation, by one lane
+// of the bootstrap kernel's last workgroup (radius_and_threshold); the inner loops need no sqrt.  For the
 // radii (cneighbors.c:64-71,160-174) the root is taken once after the max of the min squared
 // distances -- the same number because sqrt is monotone.
 #include "mdns_internal.h"
@@ -78,7 +78,6 @@ __device__ __forceinline__ void stage_to_lds(T *__restrict__ dst, const T *__res
 	}
 }
 
-__device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb, double &radius, double &thresh);
 
 // ---------------------------------------------------------------------------------------
 // K3 / K4: how many members lie strictly within the radius of each candidate
@@ -89,13 +88,13 @@ __device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb
 template <int D, int SL>
 __global__ __launch_bounds__(kBlock) void k_count_within(
     const double *__restrict__ members, int K, int ndim, double thresh_value,
-    const double *__restrict__ round_sq, int nround, const double *__restrict__ cands, int M,
+    const RegionResult *__restrict__ res, const double *__restrict__ cands, int M,
     int *__restrict__ counts, int kchunk, int tile_n, int accumulate)
 {
 	constexpr int PTS = Geo<SL>::PTS, NSLICE = Geo<SL>::NSLICE;
-	// the threshold either came with the launch (host-known radius) or is derived here from
-	// the per-round maxima K6 has just left in device memory (stream order, no host round trip)
-	__shared__ double sh_thresh;
+	// the threshold either came with the launch (host-known radius) or was left in device
+	// memory by the radius computation that precedes this launch in stream order
+	const double thresh_sq = res ? res->thresh : thresh_value;
 	extern __shared__ double smem[];
 	double *tile = smem;                                                  // [tile_n][ndim]
 	int *part = reinterpret_cast<int *>(smem + (size_t) tile_n * ndim);   // [4][PTS]
@@ -113,21 +112,12 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 #pragma unroll
 		for (int k = 0; k < D; k++) c[k] = cands[(size_t) jj * D + k];
 	}
-	// one lane derives the threshold while the others wait for the first tile's loads; it is
-	// read after the barrier that publishes that tile
-	if (round_sq && threadIdx.x == 0) {
-		double r_unused, t;
-		radius_and_threshold(round_sq, nround, r_unused, t);
-		sh_thresh = t;
-	}
-	double thresh_sq = thresh_value;
 	int hits = 0;
 	for (int t0 = kbeg; t0 < kend; t0 += tile_n) {
 		const int n = min(tile_n, kend - t0);
 		__syncthreads();
 		stage_to_lds(tile, members + (size_t) t0 * ndim, n * ndim);
 		__syncthreads();
-		if (round_sq) thresh_sq = sh_thresh;
 		if (D > 0) {
 #pragma unroll 4
 			for (int i = slice; i < n; i += NSLICE)
@@ -198,17 +188,11 @@ __global__ void k_pack_chosen(const double *__restrict__ chosen, int K, int nboo
 // with sqrt(T) >= radius, so that  sqrt(d) < radius  <=>  d < T  (cneighbors.c:88,109).  Same
 // bisection over bit patterns as mdns::sqrt_threshold on the host; hipcc's sqrt(double) is
 // correctly rounded (verified bit for bit against the host on 1.6e7 inputs, and the parity
-// tests compare both paths), so the two agree exactly.  Run by one lane of every workgroup of
-// the membership kernel that follows a radius computation (normally ~5 square roots): no
-// launch of its own and no host round trip between K6 and K3.
-__device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb, double &radius, double &thresh)
+// tests compare both paths), so the two agree exactly.  Run by one lane of the last workgroup
+// of a radius computation (normally ~15 square roots).
+__device__ void radius_and_threshold(double max_sq, double &radius, double &thresh)
 {
-	double best = 0.0;
-	for (int b = 0; b < nb; b++) {
-		const double v = sqrt(round_sq[b]);
-		if (v > best) best = v;
-	}
-	const double r = best;
+	const double r = sqrt(max_sq);     // sqrt after the max: same number, sqrt is monotone
 	double T;
 	if (!(r > 0.0)) T = 0.0;                       // nothing is strictly within a zero radius
 	else if (r == __longlong_as_double(0x7ff0000000000000LL)) T = r;
@@ -253,7 +237,8 @@ __device__ void radius_and_threshold(const double *__restrict__ round_sq, int nb
 template <int D, bool NN, int SL, int RT>
 __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
     const double *__restrict__ members, int K, int ndim, const unsigned *__restrict__ mask,
-    int nb, double *__restrict__ round_sq, int tile_n)
+    int nb, double *__restrict__ round_sq, int tile_n, BootstrapFinish fin, double *round_all, int nround_all,
+    const double *__restrict__ chosen, int nboot, int b0)
 {
 	constexpr int PTS = Geo<SL>::PTS, NSLICE = Geo<SL>::NSLICE;
 	constexpr int NR = NN ? 1 : RT;
@@ -273,7 +258,9 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 #pragma unroll
 		for (int k = 0; k < D; k++) c[k] = members[(size_t) ii * D + k];
 	}
-	const unsigned mymask = NN ? 0u : mask[ii];
+	// `chosen` != nullptr: small pools read the reference's f64[K][nboot] choice matrix
+	// themselves (cneighbors.c:146 tests != 0) instead of the bit masks of k_pack_chosen
+	const unsigned mymask = (NN || chosen) ? 0u : mask[ii];
 
 	double nearest[NR];
 #pragma unroll
@@ -283,7 +270,19 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 		const int n = min(tile_n, K - t0);
 		__syncthreads();
 		stage_to_lds(tile, members + (size_t) t0 * ndim, n * ndim);
-		if (!NN) stage_to_lds(tmask, mask + t0, n);
+		if (!NN && !chosen) stage_to_lds(tmask, mask + t0, n);
+		if (!NN && chosen) {
+			for (int e = threadIdx.x; e < n; e += kBlock) {
+				const double *row = chosen + (size_t) (t0 + e) * nboot + b0;
+				double flag[NR];
+#pragma unroll
+				for (int b = 0; b < NR; b++) flag[b] = row[b < nb ? b : 0];
+				unsigned m = 0;
+#pragma unroll
+				for (int b = 0; b < NR; b++) m |= (b < nb && flag[b] != 0.0 ? 1u : 0u) << b;
+				tmask[e] = m;
+			}
+		}
 		__syncthreads();
 		for (int jn = slice; jn < n; jn += NSLICE) {
 			double d;
@@ -321,12 +320,39 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 		if (lane < PTS) {
 			v = fmin(fmin(part[(0 * NR + b) * PTS + pt], part[(1 * NR + b) * PTS + pt]),
 			         fmin(part[(2 * NR + b) * PTS + pt], part[(3 * NR + b) * PTS + pt]));
-			const bool contributes = i < K && (NN ? true : (i >= 1 && !((mymask >> b) & 1u)));
+			bool is_chosen = (mymask >> b) & 1u;
+			if (!NN && chosen) is_chosen = chosen[(size_t) ii * nboot + b0 + b] != 0.0;
+			const bool contributes = i < K && (NN ? true : (i >= 1 && !is_chosen));
 			if (!contributes) v = 0.0;
 		}
 		v = wave_max(v);
 		if (lane == 0 && v > 0.0) atomic_max_nonneg(round_sq + b, v);
 	}
+	if (!fin.counter) return;
+	// The workgroup that finishes last turns the maxima into {radius, threshold} for the
+	// membership kernel (device copy) and for the host (mapped memory, `seq` written last).
+	__threadfence();                                   // this workgroup's atomics before its ticket
+	__syncthreads();
+	if (wv != 0) return;
+	unsigned ticket = 0;
+	if (lane == 0) ticket = atomicAdd(fin.counter, 1u);
+	if (__shfl(ticket, 0, 64) != gridDim.x - 1) return;
+	__threadfence();
+	double best = 0.0;
+	for (int b = lane; b < nround_all; b += 64)
+		best = fmax(best, __hip_atomic_load(round_all + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	best = wave_max(best);
+	// the slots go back to zero for the next computation (nobody else reads them any more)
+	for (int b = lane; b < nround_all; b += 64) round_all[b] = 0.0;
+	if (lane != 0) return;
+	double radius, thresh;
+	radius_and_threshold(best, radius, thresh);
+	fin.d_res->radius = radius;
+	fin.d_res->thresh = thresh;
+	*fin.counter = 0;
+	fin.h_res->radius = radius;
+	fin.h_res->thresh = thresh;
+	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -357,7 +383,7 @@ static int pick_tile(int ndim, size_t per_member_extra, size_t fixed_bytes)
 	case 7: LAUNCH(7); break; case 8: LAUNCH(8); break; default: LAUNCH(0); break; }
 
 bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
-                         const double *d_round_sq, int nround, const double *d_cands, int M, int *d_counts)
+                         const RegionResult *d_res, const double *d_cands, int M, int *d_counts)
 {
 	Context *c = ctx();
 	const size_t fixed = 4 * 64 * sizeof(int);
@@ -382,9 +408,9 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	dim3 grid(gx, gy);
 	ProfileScope prof(2);
 #define COUNT_LAUNCH(D) do { if (small) hipLaunchKernelGGL((k_count_within<D, 4>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, thresh_sq, d_round_sq, nround, d_cands, M, d_counts, kchunk, tile_n, accumulate); \
+		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate); \
 	else hipLaunchKernelGGL((k_count_within<D, 1>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, thresh_sq, d_round_sq, nround, d_cands, M, d_counts, kchunk, tile_n, accumulate); } while (0)
+		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate); } while (0)
 	MDNS_DIM_SWITCH(ndim, COUNT_LAUNCH)
 #undef COUNT_LAUNCH
 	return launched("k_count_within");
@@ -392,7 +418,7 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 
 template <bool NN>
 static bool launch_nearest(const double *d_members, int K, int ndim, const double *d_chosen,
-                           int nboot, double *d_round_sq)
+                           int nboot, double *d_round_sq, const BootstrapFinish *finish)
 {
 	Context *c = ctx();
 	const size_t fixed = 4 * kRounds * 64 * sizeof(double);
@@ -405,19 +431,25 @@ static bool launch_nearest(const double *d_members, int K, int ndim, const doubl
 		if (!d_mask) return false;
 	}
 	const bool small = (K + 63) / 64 < 2 * c->num_cus;          // latency shape below ~32k points
+	// A finishing computation leaves its slots zeroed (see the kernel), so no launch has to
+	// clear them; small pools then also read the choice matrix directly: one launch in all.
+	const bool fused = !NN && finish && K <= 2048;
 	const int pts = small ? 16 : 64;
 	dim3 grid((K + pts - 1) / pts);
 	for (int b0 = 0; b0 < nboot; b0 += kRounds) {
 		const int nb = nboot - b0 < kRounds ? nboot - b0 : kRounds;
-		if (!NN) {
+		if (!NN && !fused) {
 			const int nthreads = K > nb ? K : nb;
 			hipLaunchKernelGGL(k_pack_chosen, dim3((nthreads + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
 			                   d_chosen, K, nboot, b0, nb, d_mask, d_round_sq);
 			if (!launched("k_pack_chosen")) return false;
 		}
+		// only the launch of the last window finishes the computation
+		BootstrapFinish fin = {nullptr, nullptr, nullptr, 0};
+		if (finish && b0 + kRounds >= nboot) fin = *finish;
 		ProfileScope prof(3);
 #define NEAR_LAUNCH_R(D, SL, RT) hipLaunchKernelGGL((k_nearest_chosen<D, NN, SL, RT>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n)
+		d_members, K, ndim, d_mask, nb, d_round_sq + b0, tile_n, fin, d_round_sq, nboot, fused ? d_chosen : nullptr, nboot, b0)
 #define NEAR_LAUNCH(D) do { \
 	if (small) { if (NN || nb <= 10) NEAR_LAUNCH_R(D, 4, 10); else NEAR_LAUNCH_R(D, 4, kRounds); } \
 	else       { if (NN || nb <= 10) NEAR_LAUNCH_R(D, 1, 10); else NEAR_LAUNCH_R(D, 1, kRounds); } } while (0)
@@ -430,14 +462,14 @@ static bool launch_nearest(const double *d_members, int K, int ndim, const doubl
 }
 
 bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_chosen,
-                      int nbootstraps, double *d_round_sq)
+                      int nbootstraps, double *d_round_sq, const BootstrapFinish *finish)
 {
-	return launch_nearest<false>(d_members, K, ndim, d_chosen, nbootstraps, d_round_sq);
+	return launch_nearest<false>(d_members, K, ndim, d_chosen, nbootstraps, d_round_sq, finish);
 }
 
 bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out)
 {
-	return launch_nearest<true>(d_members, K, ndim, nullptr, 1, d_out);
+	return launch_nearest<true>(d_members, K, ndim, nullptr, 1, d_out, nullptr);
 }
 
 }  // namespace mdns

@@ -427,8 +427,8 @@ def test_k1_lane_kernel_vs_oracle(oracle, nd, nx, B):
 
 def test_device_side_threshold_matches_host(nb, oracle):
     """After mdns_region_bootstrap_radius* the membership threshold lives on the device
-    (radius_and_threshold, in the K3 prologue); it must select exactly the points the reference's sqrt(d) < r selects,
-    including candidates placed AT distance r from a member."""
+    (radius_and_threshold, run by the last workgroup of the bootstrap kernel); it must select
+    exactly the points the reference's sqrt(d) < r selects, including candidates placed AT distance r from a member."""
     rng = np.random.RandomState(77)
     for trial in range(60):
         K, ndim = int(rng.randint(5, 40)), int(rng.randint(1, 4))
