@@ -260,7 +260,16 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 	}
 	// `chosen` != nullptr: small pools read the reference's f64[K][nboot] choice matrix
 	// themselves (cneighbors.c:146 tests != 0) instead of the bit masks of k_pack_chosen
-	const unsigned mymask = (NN || chosen) ? 0u : mask[ii];
+	unsigned mymask = (NN || chosen) ? 0u : mask[ii];
+	if (!NN && chosen) {
+		// own flags now, together with the coordinates: nothing global is left for the epilogue
+		const double *row = chosen + (size_t) ii * nboot + b0;
+		double flag[NR];
+#pragma unroll
+		for (int b = 0; b < NR; b++) flag[b] = row[b < nb ? b : 0];
+#pragma unroll
+		for (int b = 0; b < NR; b++) mymask |= (b < nb && flag[b] != 0.0 ? 1u : 0u) << b;
+	}
 
 	double nearest[NR];
 #pragma unroll
@@ -272,15 +281,23 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 		stage_to_lds(tile, members + (size_t) t0 * ndim, n * ndim);
 		if (!NN && !chosen) stage_to_lds(tmask, mask + t0, n);
 		if (!NN && chosen) {
-			for (int e = threadIdx.x; e < n; e += kBlock) {
-				const double *row = chosen + (size_t) (t0 + e) * nboot + b0;
-				double flag[NR];
+			// the rows of all this thread's tile members requested before the first is used
+			constexpr int TRIPS = kMaxTile / kBlock;
+			double flag[TRIPS][NR];
 #pragma unroll
-				for (int b = 0; b < NR; b++) flag[b] = row[b < nb ? b : 0];
+			for (int t = 0; t < TRIPS; t++) {
+				const int e = min((int) threadIdx.x + t * kBlock, n - 1);
+				const double *row = chosen + (size_t) (t0 + e) * nboot + b0;
+#pragma unroll
+				for (int b = 0; b < NR; b++) flag[t][b] = row[b < nb ? b : 0];
+			}
+#pragma unroll
+			for (int t = 0; t < TRIPS; t++) {
+				const int e = (int) threadIdx.x + t * kBlock;
 				unsigned m = 0;
 #pragma unroll
-				for (int b = 0; b < NR; b++) m |= (b < nb && flag[b] != 0.0 ? 1u : 0u) << b;
-				tmask[e] = m;
+				for (int b = 0; b < NR; b++) m |= (b < nb && flag[t][b] != 0.0 ? 1u : 0u) << b;
+				if (e < n) tmask[e] = m;
 			}
 		}
 		__syncthreads();
@@ -320,9 +337,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 		if (lane < PTS) {
 			v = fmin(fmin(part[(0 * NR + b) * PTS + pt], part[(1 * NR + b) * PTS + pt]),
 			         fmin(part[(2 * NR + b) * PTS + pt], part[(3 * NR + b) * PTS + pt]));
-			bool is_chosen = (mymask >> b) & 1u;
-			if (!NN && chosen) is_chosen = chosen[(size_t) ii * nboot + b0 + b] != 0.0;
-			const bool contributes = i < K && (NN ? true : (i >= 1 && !is_chosen));
+			const bool contributes = i < K && (NN ? true : (i >= 1 && !((mymask >> b) & 1u)));
 			if (!contributes) v = 0.0;
 		}
 		v = wave_max(v);
