@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_rows(
 template <int BT, int SP>
 __global__ __launch_bounds__(kBlock) void k_gauss_cols(
     const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
-    double scale, const int *__restrict__ rows, int M, int ntiles, int nq_xcd, double *__restrict__ out)
+    double scale, const int *__restrict__ rows, int M, int ntiles, int nq_xcd, int nbt, int cu_slots, double *__restrict__ out)
 {
 	constexpr int CH = 8;                     // channels per software-pipeline stage (nxp % CH == 0)
 	const int lane = threadIdx.x & 63;
@@ -290,8 +290,18 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 	// results.
 	const int xcd = blockIdx.x & 7;
 	const int local = blockIdx.x >> 3;
-	const int bt = local / nq_xcd;
-	const int quad = (local % nq_xcd) * 8 + xcd;
+	// Within an XCD the dispatcher deals workgroups round-robin over the CUs (measured: `local`
+	// and `local + cu_slots` always share a CU), so slot = local % cu_slots names a CU.  Each
+	// slot takes a contiguous run of the XCD's items in candidate-tile-major order: the
+	// workgroups resident on a CU then read the SAME template tile through the scalar cache
+	// (12.8 KB at BT = 8) instead of five different ones (-12 % at B = 256).
+	const int slot = local % cu_slots, round = local / cu_slots;
+	const int nitems = nbt * nq_xcd;
+	const int first = (int) ((long long) slot * nitems / cu_slots);
+	const int next = (int) ((long long) (slot + 1) * nitems / cu_slots);
+	if (first + round >= next) return;
+	const int bt = (first + round) / nq_xcd;
+	const int quad = ((first + round) % nq_xcd) * 8 + xcd;
 	const int tile = quad * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	if (tile >= ntiles) return;
 	// YT is stored in tiles of 64 spectra: element (channel j, spectrum i) at
@@ -620,10 +630,17 @@ int gauss_cols_tile(int M, int B)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
-	// candidates per wave: the largest tile that still leaves about four waves per SIMD
-	// (measured on MI355X, 10 000 spectra: B=64 -> 4, B=256 -> 8, B=1024 -> 16), at least 4
-	int bt = 16;
-	while (bt > 4 && (long long) ntiles * ((B + bt - 1) / bt) < 16LL * c->num_cus) bt >>= 1;
+	// candidates per wave, from the waves per SIMD a tile size leaves (4 SIMDs per CU).
+	// Measured on MI355X (us per launch, 10 000 spectra unless noted; BT = 4 / 8 / 16):
+	//   B = 64: 25.7 / 28.2 / 46.5     B = 128: 40.0 / 31.8 / 46.7    B = 256: 76.0 / 49.4 / 56.8
+	//   B = 512: 144 / 97.1 / 92.6     B = 1024: 272 / 185 / 176      100 000 x 16: 56.8 / 40.5 / 51.0
+	// 8 wins from ~2.4 waves per SIMD on (its template tile, 12.8 KB at 200 channels, stays in
+	// the scalar cache and it needs half the L1 bandwidth of 4), 16 from ~4.5 on.
+	const long long simds = 4LL * c->num_cus;
+	auto waves10 = [&](int t) { return 10LL * ntiles * ((B + t - 1) / t); };
+	int bt = 4;
+	if (waves10(16) >= 45 * simds) bt = 16;
+	else if (waves10(8) >= 24 * simds) bt = 8;
 	while (bt > B && bt > 1) bt >>= 1;
 	static const char *forced_bt = getenv("MDNS_K1_BT");      // experiments only
 	if (forced_bt) { const int f = atoi(forced_bt); if (f == 1 || f == 2 || f == 4 || f == 8 || f == 16) bt = f; }
@@ -652,11 +669,16 @@ bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, i
 	const int nbt = (B + bt - 1) / bt;
 	const int nquads = (ntiles + 3) / 4;
 	const int nq_xcd = (nquads + 7) / 8;                      // quads per XCD (some may be empty)
-	const int blocks = 8 * nq_xcd * nbt;
+	// per XCD: nbt * nq_xcd items dealt to cu_slots CUs in contiguous runs (see the kernel).
+	// Against the plain order (item = local) measured on one box: 49.4 vs 54.7 us at B = 256,
+	// 31.8 vs 36.1 at B = 128, 391 vs 432 at 100 000 x 256; only 10 000 x 1024 lost (184 vs 176).
+	const int cu_slots = c->num_cus >= 8 ? c->num_cus / 8 : 1;
+	const int rounds = (nbt * nq_xcd + cu_slots - 1) / cu_slots;
+	const int blocks = 8 * cu_slots * rounds;
 	ProfileScope prof(0);
 	note_kernel(0, "k_gauss_cols<%d, %d>", bt, (int) sp);
 #define COLS_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols<BT, sp>), dim3(blocks), dim3(kBlock), 0, c->stream, \
-	s->d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, d_out)
+	s->d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_out)
 	switch (bt) {
 	case 16: COLS_LAUNCH(16); break;
 	case 8: COLS_LAUNCH(8); break;
