@@ -28,8 +28,9 @@ class MetricLearningFriendsConstrainer(object):
     REGION_BATCH = 10000
     #: probability of an extra unit-cube proposal round after each region refill (:126)
     CUBE_PROBABILITY = 0.1
-    #: most candidates scored ahead of need in one likelihood launch
-    MAX_LOOKAHEAD = 64
+    #: most candidates scored ahead of need in one likelihood launch (the batch size bench.py
+    #: times; the depth only reaches it in long unsuccessful streaks, doubling with the tries)
+    MAX_LOOKAHEAD = 256
 
     def __init__(self, metriclearner, rebuild_every=50, metric_rebuild_every=50, verbose=False,
                  keep_phantom_points=False, optimize_phantom_points=False, force_shrink=False):
