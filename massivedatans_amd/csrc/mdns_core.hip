@@ -805,12 +805,14 @@ struct mdns_region {
 	// A radius computation ends on the device: the last workgroup of the bootstrap kernel
 	// writes {radius, threshold} to d_res (for the membership kernel, stream order) and to
 	// h_res (mapped host memory), then h_res->seq = seq.  The host polls for that.
-	double *d_round = nullptr;        // per-round max of squared nearest-chosen distances
+	double *d_round = nullptr;        // per-round max of squared nearest-chosen distances (slab or own_round)
+	double *own_round = nullptr;
 	int round_cap = 0;
 	RegionResult *d_res = nullptr;
 	RegionResult *h_res = nullptr;    // hipHostMalloc (mapped, coherent)
 	RegionResult *h_res_dev = nullptr;   // its device address
 	unsigned *d_counter = nullptr;
+	int slot = -1;                    // result slot (take_result_slot)
 	unsigned long long seq = 0;
 	bool on_device = false;           // the membership kernel must use d_res
 	bool pending = false;             // the host copies still have to be fetched (async path)
@@ -819,17 +821,53 @@ struct mdns_region {
 	int *d_counts = nullptr; size_t counts_cap = 0;
 };
 
+// Result slots ({radius, threshold} on the device, its mapped host mirror and the ticket
+// counter) come from slabs allocated once: the host code builds a region handle per region,
+// and hipHostMalloc per handle was a millisecond each.
+static constexpr int kSlabSlots = 64;
+static constexpr int kSlotRounds = 16;    // per-round maxima kept in the slab (more: own buffer)
+struct ResultSlab { RegionResult *d_res; unsigned *d_counter; RegionResult *h_res, *h_res_dev; double *d_round; };
+static std::vector<ResultSlab> g_slabs;
+static std::vector<int> g_free_slots;
+
+static int take_result_slot()
+{
+	if (g_free_slots.empty()) {
+		ResultSlab slab = {nullptr, nullptr, nullptr, nullptr, nullptr};
+		const bool ok =
+		    MDNS_HIP(hipMalloc((void **) &slab.d_res, kSlabSlots * sizeof(RegionResult))) &&
+		    MDNS_HIP(hipMalloc((void **) &slab.d_counter, kSlabSlots * sizeof(unsigned))) &&
+		    MDNS_HIP(hipMemset(slab.d_counter, 0, kSlabSlots * sizeof(unsigned))) &&
+		    MDNS_HIP(hipMalloc((void **) &slab.d_round, kSlabSlots * kSlotRounds * sizeof(double))) &&
+		    MDNS_HIP(hipMemset(slab.d_round, 0, kSlabSlots * kSlotRounds * sizeof(double))) &&
+		    MDNS_HIP(hipHostMalloc((void **) &slab.h_res, kSlabSlots * sizeof(RegionResult), hipHostMallocMapped | hipHostMallocCoherent)) &&
+		    MDNS_HIP(hipHostGetDevicePointer((void **) &slab.h_res_dev, slab.h_res, 0));
+		if (!ok) return -1;
+		memset(slab.h_res, 0, kSlabSlots * sizeof(RegionResult));
+		const int base = (int) g_slabs.size() * kSlabSlots;
+		g_slabs.push_back(slab);
+		for (int i = kSlabSlots - 1; i >= 0; i--) g_free_slots.push_back(base + i);
+	}
+	const int slot = g_free_slots.back();
+	g_free_slots.pop_back();
+	return slot;
+}
+
 static mdns_region *region_new(const double *d_members, double *owned, int K, int ndim)
 {
 	mdns_region *r = new mdns_region();
 	r->d_members = d_members; r->owned = owned; r->K = K; r->ndim = ndim;
-	bool ok = MDNS_HIP(hipMalloc((void **) &r->d_res, sizeof(RegionResult))) &&
-	          MDNS_HIP(hipMalloc((void **) &r->d_counter, sizeof(unsigned))) &&
-	          MDNS_HIP(hipMemset(r->d_counter, 0, sizeof(unsigned))) &&
-	          MDNS_HIP(hipHostMalloc((void **) &r->h_res, sizeof(RegionResult), hipHostMallocMapped | hipHostMallocCoherent)) &&
-	          MDNS_HIP(hipHostGetDevicePointer((void **) &r->h_res_dev, r->h_res, 0));
-	if (!ok) { mdns_region_destroy(r); return nullptr; }
-	r->h_res->seq = 0;
+	r->slot = take_result_slot();
+	if (r->slot < 0) { mdns_region_destroy(r); return nullptr; }
+	const ResultSlab &slab = g_slabs[r->slot / kSlabSlots];
+	const int i = r->slot % kSlabSlots;
+	r->d_res = slab.d_res + i;
+	r->d_counter = slab.d_counter + i;
+	r->h_res = slab.h_res + i;
+	r->h_res_dev = slab.h_res_dev + i;
+	r->d_round = slab.d_round + (size_t) i * kSlotRounds;      // zero: every finishing computation leaves it so
+	r->round_cap = kSlotRounds;
+	r->seq = r->h_res->seq;            // a recycled slot keeps counting from where it was
 	return r;
 }
 
@@ -858,9 +896,9 @@ extern "C" void mdns_region_destroy(mdns_region *r)
 	if (!r) return;
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
-	void *bufs[] = {r->owned, r->d_round, r->d_chosen, r->d_points, r->d_counts, r->d_res, r->d_counter};
+	void *bufs[] = {r->owned, r->own_round, r->d_chosen, r->d_points, r->d_counts};
 	for (void *b : bufs) if (b) (void) hipFree(b);
-	if (r->h_res) (void) hipHostFree(r->h_res);
+	if (r->slot >= 0) g_free_slots.push_back(r->slot);      // the stream is idle: nobody writes it any more
 	delete r;
 }
 
@@ -911,8 +949,9 @@ extern "C" int mdns_region_bootstrap_radius_async(mdns_region *r, const double *
 	if (!region_fetch(r)) return 1;             // a previous result may still be travelling
 	if (r->round_cap < nbootstraps) {
 		(void) hipStreamSynchronize(c->stream);
-		if (r->d_round) { (void) hipFree(r->d_round); r->d_round = nullptr; }
-		if (!MDNS_HIP(hipMalloc((void **) &r->d_round, (size_t) nbootstraps * sizeof(double)))) return 1;
+		if (r->own_round) { (void) hipFree(r->own_round); r->own_round = nullptr; }
+		if (!MDNS_HIP(hipMalloc((void **) &r->own_round, (size_t) nbootstraps * sizeof(double)))) return 1;
+		r->d_round = r->own_round;
 		// zero once: every finishing computation hands its slots back zeroed
 		if (!MDNS_HIP(hipMemsetAsync(r->d_round, 0, (size_t) nbootstraps * sizeof(double), c->stream))) return 1;
 		r->round_cap = nbootstraps;
