@@ -467,3 +467,43 @@ def test_k2_two_rows_per_workgroup_vs_oracle(oracle, nd, nx):
             want = oracle.muse_like(cube["y"], cube["v"], np.ascontiguousarray(ypred[b]), mask)[mask]
             assert rel_err(got[b], want) < 1e-11
     sp.close()
+
+
+@pytest.mark.parametrize("nd,nx,B", [(12500, 200, 200), (777, 33, 300), (3300, 24, 1500), (10000, 200, 128)])
+def test_k1_lane_kernel_every_entry(oracle, nd, nx, B):
+    """Every entry of L[B, M] of the lane kernel, for shapes that exercise its placement logic:
+    12 500 spectra (49 quads: XCDs with unequal and empty shares, 7 items per CU), candidate
+    counts that are not multiples of the tile, the 16-candidate tile (1500 x 3300) and the
+    8-candidate tile at B = 128.  A work item that no workgroup picked up would leave its block
+    of the output untouched, so the output buffer is poisoned first."""
+    from massivedatans_amd.like import GaussLineSpectra
+    rng = np.random.RandomState(nd + nx + B)
+    x = np.sort(rng.uniform(400, 800, nx))
+    y = np.ascontiguousarray(rng.normal(0, 0.05, size=(nx, nd)))
+    sp = GaussLineSpectra(x, y, noise_level=0.01)
+    params = np.column_stack([rng.uniform(0.01, 1, B), rng.uniform(400, 800, B), 10 ** rng.uniform(0, 2, B)])
+    mask = np.ones(nd, bool)
+    lib = _lib.require_device()
+    got = np.full((B, nd), np.nan)
+    d_L = lib.mdns_dev_alloc(got.nbytes)
+    d_p = lib.mdns_dev_alloc(params.nbytes)
+    params = np.ascontiguousarray(params)
+    _lib.check(lib.mdns_h2d(d_L, _lib.ptr(got), got.nbytes), "h2d")          # poison
+    _lib.check(lib.mdns_h2d(d_p, _lib.ptr(params), params.nbytes), "h2d")
+    _lib.check(lib.mdns_gauss_loglike_batch_dev(sp.handle, d_p, B, 0.01, None, nd, d_L), "K1")
+    _lib.check(lib.mdns_d2h(_lib.ptr(got), d_L, got.nbytes), "d2h")
+    lib.mdns_dev_free(d_L)
+    lib.mdns_dev_free(d_p)
+    assert np.isfinite(got).all(), "work items left untouched: %d entries" % (~np.isfinite(got)).sum()
+    assert (lib.mdns_profile_kernel(0) or b"").startswith(b"k_gauss_cols")
+    for b0 in range(0, B, 50):
+        p = params[b0:b0 + 50]
+        model = p[:, 0, None] * np.exp(-0.5 * ((p[:, 1, None] - x[None, :]) / p[:, 2, None]) ** 2)   # [b, nx]
+        want = np.empty((len(p), nd))
+        for i in range(len(p)):
+            want[i] = -0.5 * (((model[i][:, None] - y) / 0.01) ** 2).sum(axis=0)
+        assert rel_err(got[b0:b0 + 50], want) < 1e-11
+    b = B - 1
+    want = -0.5 * oracle.gauss_like(x, y, params[b, 0], params[b, 1], params[b, 2], 0.01, mask)
+    assert rel_err(got[b], want) < RTOL_L
+    sp.close()
