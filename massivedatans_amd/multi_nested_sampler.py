@@ -145,6 +145,8 @@ class MultiNestedSampler(object):
         self.real_data_mask_all = numpy.ones(self.ndata) == 1
         self.ndraws = nlive_points
         self._shelves = _Shelves(ndata)
+        self._low = None                    # smallest live likelihoods per data set (_refresh_thresholds)
+        self._low_cap = -1
 
     @property
     def shelves(self):
@@ -310,11 +312,31 @@ class MultiNestedSampler(object):
         an iteration and a shelf only changes when it receives a point, so the thresholds are
         kept in ``self._higher`` and refreshed for exactly the rows whose shelf grew."""
         counts = self._shelves.n[rows]
-        for n in numpy.unique(counts[counts > 0]):
-            d = rows[counts == n]
-            # live likelihoods + the shelf entries (+inf padding sorts last)
-            merged = numpy.hstack((self.live_pointsL[:, d].T, self._shelves.L[d, :]))
-            self._higher[d] = numpy.partition(merged, n, axis=1)[:, n]
+        waiting = counts > 0
+        if not waiting.any():
+            return
+        rows, counts = rows[waiting], counts[waiting]
+        # The n+1 smallest of (live + shelf) lie among the n+1 smallest live values and the
+        # shelf, and n never exceeds the shelf capacity: so the cap+1 smallest live likelihoods
+        # of every data set, found once per iteration, replace the full columns (a selection,
+        # no arithmetic: the thresholds are the same numbers).
+        cap = self._shelves.p.shape[1]
+        if self._low is None or self._low_cap != cap:
+            k = min(cap, self.nlive_points - 1)
+            smallest = numpy.partition(self.live_pointsL, k, axis=0)[:k + 1]
+            self._low = numpy.ascontiguousarray(numpy.sort(smallest, axis=0).T)     # [ndata, k+1]
+            self._low_cap = cap
+        # rows in buckets of similar n, so that the arrays sorted are only 2 n + 1 wide
+        lo, hi = 0, 1
+        while lo < cap:
+            pick = (counts > lo) & (counts <= hi)
+            if pick.any():
+                r, n = rows[pick], counts[pick]
+                w = min(hi, cap)
+                merged = numpy.hstack((self._low[r, :w + 1], self._shelves.L[r, :w]))
+                merged.sort(axis=1)
+                self._higher[r] = merged[numpy.arange(len(r)), n]
+            lo, hi = hi, 2 * hi + 1
 
     def _fill_shelves(self, Lmins, allu, allp):
         superset_groups = None
@@ -327,6 +349,7 @@ class MultiNestedSampler(object):
             if passes == 1:
                 # thresholds of this iteration (only needed when something has to be drawn)
                 self._higher = Lmins.copy()
+                self._low = None
                 self._refresh_thresholds(numpy.flatnonzero(self._shelves.n > 0))
             focussed = passes > self.nsuperset_draws
             if focussed:
