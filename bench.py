@@ -162,8 +162,14 @@ def main():
     os.environ.setdefault("MDNS_DEVICE", str(local_rank))
     lib = _lib.require_device()
     if use_dist:
-        # kernels and the collective share one stream, so no cross-stream events are needed
-        lib.mdns_set_stream(C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        # The kernels go on torch's CURRENT stream, which the (synchronous-API) RCCL collective
+        # orders itself against on both sides: K6 of a step cannot start before that step's
+        # all-gather has delivered the pool.  A stream of our own, because torch's default
+        # stream is the null stream (handle 0), which mdns_set_stream reads as "library stream".
+        bench_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(bench_stream)
+        assert bench_stream.cuda_stream != 0
+        _lib.check(lib.mdns_set_stream(C.c_void_p(bench_stream.cuda_stream)), "mdns_set_stream")
 
     # ---- synthetic input, resident before the timed region --------------------------------
     nd, B, K = args.ndata, args.batch, args.pool
