@@ -58,7 +58,7 @@ class CachedConstrainer(object):
         return (len(mask) < len(self.last_mask) and len(mask) > 0.80 * len(self.last_mask)
                 and len(points) <= len(self.last_points) and len(points) > 0.90 * len(self.last_points)
                 and numpy.mean(self.last_realmask == realmask) > 0.80
-                and numpy.in1d(points, self.last_points).all())
+                and numpy.isin(points, self.last_points).all())
 
     def get(self, mask, realmask, points, it):
         self._advance_to(it)

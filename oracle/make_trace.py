@@ -170,16 +170,24 @@ CASES = {
     "horns3": (3, 30, 1500, 10, "horns"),         # terminates by tolerance
     "horns6": (6, 20, 300, 10, "horns"),          # capped; acceptance falls to ~1e-3 (242k draws)
     "horns12": (12, 24, 260, 10, "horns"),        # capped; focussed draws on many groups
+    # BASELINE.json configs[0] (100 spectra, 50 live points; 300 iterations as in SURVEY 3.3):
+    # 44 272 likelihood calls in the reference.  Stored without the per-iteration arrays.
+    "horns100": (100, 50, 300, 10, "horns"),
 }
+LIGHT = {"horns100"}          # cases kept small: no iter_L / iter_u
 
 
 def main():
     assert have_reference(), "oracle/_ref missing"
     stage_reference()
-    for name, (ndata, nlive, max_samples, nsd, generator) in CASES.items():
+    wanted = sys.argv[1:] or list(CASES)
+    for name in wanted:
+        ndata, nlive, max_samples, nsd, generator = CASES[name]
         t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
             out = run_reference(ndata, nlive, max_samples, nsd, generator)
+        if name in LIGHT:
+            out = {k: v for k, v in out.items() if k not in ("iter_L", "iter_u")}
         path = os.path.join(ROOT, "tests", "golden", "trace_%s.npz" % name)
         numpy.savez_compressed(path, **out)
         print("%s: %d iterations, running %s, ndraws %d, logZ[0] %.6f, %.1f s, %d bytes"

@@ -271,7 +271,7 @@ def test_geometry_full_size_properties(nb):
 
 
 # ---------------------------------------------------------------- end to end ---------------
-@pytest.mark.parametrize("case", ["nothing4", "horns3", "horns12"])
+@pytest.mark.parametrize("case", ["nothing4", "horns3", "horns12", "horns100"])
 def test_end_to_end_against_reference_trace(case):
     """The whole analysis on the GPU (HIP likelihood + HIP geometry + host orchestration) against
     the trace recorded from the reference's Python + C.  Geometry is bit-exact and likelihoods

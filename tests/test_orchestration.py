@@ -14,7 +14,9 @@ from massivedatans_amd import gen, sample
 from oracle_backend import OracleSpectra, patch_neighbors
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CASES = ["nothing4", "horns3", "horns12", "horns6"]
+# horns100 = BASELINE.json configs[0] (100 spectra, 50 live points, 300 iterations: the run of
+# SURVEY 3.3 with 44 272 likelihood calls); its fixture carries no per-iteration arrays
+CASES = ["nothing4", "horns3", "horns12", "horns6", "horns100"]
 
 
 class Recorder(object):
@@ -54,6 +56,8 @@ def test_trace_bit_exact(case, batched, oracle, monkeypatch):
     g["_name"] = case
     if case == "horns6" and batched:
         pytest.skip("242k draws: run once, unbatched")
+    if case == "horns100" and not batched:
+        pytest.skip("44k draws: run once, batched")
     patch_neighbors(monkeypatch, oracle)
     with np.errstate(all="ignore"):
         results, sampler, rec, rng_probe = run_case(g, oracle, batched)
@@ -65,8 +69,9 @@ def test_trace_bit_exact(case, batched, oracle, monkeypatch):
     assert np.array_equal(sampler.live_pointsp, g["final_live_pointsp"])
     assert len(results["weights"]) == int(g["nweights"])
     # floating point, bit for bit
-    assert np.array_equal(np.concatenate(rec.Ls), g["iter_L"])
-    assert np.array_equal(np.concatenate(rec.us), g["iter_u"])
+    if "iter_L" in g:
+        assert np.array_equal(np.concatenate(rec.Ls), g["iter_L"])
+        assert np.array_equal(np.concatenate(rec.us), g["iter_u"])
     assert np.array_equal(sampler.live_pointsL, g["final_live_pointsL"])
     assert np.array_equal(results["logZ"], g["logZ"])
     assert np.array_equal(results["logZerr"], g["logZerr"])
