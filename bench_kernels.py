@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Kernel-level micro-benchmarks (SURVEY.md 8(d) "kernel-level bench"): per-launch device time
-of each hot-path kernel over sweeps of batch size, mask density and pool size, measured with
-HIP events on the launch stream (mdns_profile).  One JSON line per case.
+"""Kernel-level micro-benchmarks (SURVEY.md 8(d) "kernel-level bench"): device time per call of
+each hot-path entry point over sweeps of batch size, mask density and pool size, measured with
+HIP events on the launch stream around back-to-back calls.  One JSON line per case.
 
     python bench_kernels.py [k1] [k1big] [k2] [k3] [k6]      (default: k1 k2 k3 k6)
 """
@@ -17,17 +17,20 @@ REPS = 30
 
 
 def timed(lib, which, fn, reps=REPS, warm=3):
+    """Microseconds per CALL: `reps` calls back to back between two events on the launch stream,
+    so every kernel of the call counts (template kernel, compaction of a selection, ...)."""
     for _ in range(warm):
         fn()
     lib.mdns_sync()
-    lib.mdns_profile(15)
+    e0, e1 = lib.mdns_event_create(), lib.mdns_event_create()
+    lib.mdns_event_record(e0)
     for _ in range(reps):
         fn()
-    lib.mdns_sync()
-    n, ms = C.c_longlong(0), C.c_double(0)
-    lib.mdns_profile_read(which, C.byref(n), C.byref(ms))
-    lib.mdns_profile(0)
-    return 1e3 * ms.value / max(1, n.value)     # microseconds per launch
+    lib.mdns_event_record(e1)
+    ms = lib.mdns_event_elapsed_ms(e0, e1)
+    lib.mdns_event_destroy(e0)
+    lib.mdns_event_destroy(e1)
+    return 1e3 * ms / reps
 
 
 def dev(lib, a):
@@ -42,13 +45,17 @@ def k1(lib, ndata=10000):
     nx = d["y"].shape[0]
     sp = lib.mdns_spectra_create(_lib.ptr(d["x"]), _lib.ptr(d["y"]), None, ndata, nx, 0)
     rng = np.random.RandomState(1)
-    for frac in (1.0, 0.5, 0.1, 0.01):
-        if frac < 1.0:
+    # masks of SURVEY 8(d): 100 %, (50 %,) 10 %, 1 % of the data sets and a single one
+    for frac in (1.0, 0.5, 0.1, 0.01, "single"):
+        if frac == "single":
+            rows = np.array([ndata // 2], dtype=np.int32)
+            d_rows, M = dev(lib, rows), 1
+        elif frac < 1.0:
             rows = np.flatnonzero(rng.uniform(size=ndata) < frac).astype(np.int32)
             d_rows, M = dev(lib, rows), len(rows)
         else:
             d_rows, M = None, ndata
-        for B in (1, 2, 4, 8, 16, 64, 256, 1024):
+        for B in (1, 2, 4, 8, 16, 64, 256, 1024, 4096):
             cube = rng.uniform(size=(B, 3))
             params = np.column_stack([10 ** (cube[:, 0] * 2 - 2), cube[:, 1] * 400 + 400, 10 ** (cube[:, 2] * 2)])
             d_p = dev(lib, params)
@@ -96,19 +103,27 @@ def k2(lib, ndata=4096, nx=4096):
     cube = gen.muse_like(ndata, nx=nx)
     sp = lib.mdns_spectra_create(_lib.ptr(cube["x"]), _lib.ptr(cube["y"]), _lib.ptr(cube["v"]), ndata, nx, 0)
     rng = np.random.RandomState(2)
-    for B in (1, 4, 16, 64):
-        pars = np.column_stack([rng.uniform(-0.5, 0.5, B), rng.uniform(0, 0.02, B), rng.uniform(-0.1, 0.2, B),
-                                rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
-        d_p = dev(lib, pars)
-        d_L = lib.mdns_dev_alloc(B * ndata * 8)
-        us = timed(lib, 1, lambda: lib.mdns_muse3_loglike_batch_dev(sp, d_p, B, None, ndata, d_L), reps=10)
-        evals = B * ndata
-        print(json.dumps({"kernel": "K2", "ndata": ndata, "nx": nx, "B": B, "us": us,
-                          "evals_per_s": evals / (us * 1e-6),
-                          "alg_GBps": evals * (16 * nx + 8) / (us * 1e-6) / 1e9,
-                          "phys_GBps": (ndata * nx * 16 + evals * 8) / (us * 1e-6) / 1e9}), flush=True)
-        lib.mdns_dev_free(d_p)
-        lib.mdns_dev_free(d_L)
+    for frac in (1.0, 0.1, 0.01, "single"):
+        if frac == "single":
+            rows = np.array([ndata // 2], dtype=np.int32)
+        elif frac < 1.0:
+            rows = np.flatnonzero(rng.uniform(size=ndata) < frac).astype(np.int32)
+        else:
+            rows = None
+        d_rows, M = (dev(lib, rows), len(rows)) if rows is not None else (None, ndata)
+        for B in (1, 4, 16, 64):
+            pars = np.column_stack([rng.uniform(-0.5, 0.5, B), rng.uniform(0, 0.02, B), rng.uniform(-0.1, 0.2, B),
+                                    rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
+            d_p = dev(lib, pars)
+            d_L = lib.mdns_dev_alloc(B * M * 8)
+            us = timed(lib, 1, lambda: lib.mdns_muse3_loglike_batch_dev(sp, d_p, B, d_rows, M, d_L), reps=10)
+            evals = B * M
+            print(json.dumps({"kernel": "K2", "ndata": ndata, "nx": nx, "mask": frac, "M": M, "B": B, "us": us,
+                              "evals_per_s": evals / (us * 1e-6),
+                              "alg_GBps": evals * (16 * nx + 8) / (us * 1e-6) / 1e9,
+                              "phys_GBps": (M * nx * 16 + evals * 8) / (us * 1e-6) / 1e9}), flush=True)
+            lib.mdns_dev_free(d_p)
+            lib.mdns_dev_free(d_L)
     lib.mdns_spectra_destroy(sp)
 
 

@@ -385,7 +385,7 @@ extern "C" mdns_spectra *mdns_spectra_create(const double *x, const double *y, c
 		s->ldT = ((ndata + 63) / 64) * 64;
 		const size_t telems = (size_t) cols_nx(nx) * s->ldT;
 		ok = MDNS_HIP(hipMalloc((void **) &s->d_yT, telems * sizeof(double)));
-		ok = ok && launch_tile_columns(s->d_y, s->ld, ndata, nx, s->d_yT);
+		ok = ok && launch_tile_columns(s->d_y, s->ld, ndata, nx, nullptr, s->d_yT);
 		ok = ok && MDNS_HIP(hipStreamSynchronize(c->stream));
 	}
 	if (ok && v) {
@@ -407,7 +407,7 @@ extern "C" void mdns_spectra_destroy(mdns_spectra *s)
 	if (!s) return;
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
-	void *bufs[] = {s->d_y, s->d_yT, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out};
+	void *bufs[] = {s->d_y, s->d_yT, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out, s->d_sel};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	delete s;
 }
@@ -455,7 +455,18 @@ extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_par
 		const int bt = gauss_cols_tile(M, B);
 		if (!grow(&s->d_model, &s->model_cap, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
 		if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model)) return 1;
-		return launch_gauss_cols(s, s->d_model, bt, B, scale, d_row_ids, M, d_Lout) ? 0 : 1;
+		// A selection is first copied into a compact replica (coalesced row reads, one pass)
+		// when the lane kernel would otherwise gather its columns once per candidate tile:
+		// many tiles, or a sparse selection (measured: 1 000 of 10 000 spectra, B = 256: 59 us
+		// gathering in the kernel).
+		const bool sparse = (size_t) M * 8 < (size_t) s->ndata;
+		if (d_row_ids && (B >= 128 || sparse)) {
+			const size_t need = (size_t) ((M + 63) / 64) * 64 * cols_nx(s->nx);
+			if (!grow(&s->d_sel, &s->sel_cap, need)) return 1;
+			if (!launch_tile_columns(s->d_y, s->ld, M, s->nx, d_row_ids, s->d_sel)) return 1;
+			return launch_gauss_cols(s, s->d_sel, s->d_model, bt, B, scale, nullptr, M, d_Lout) ? 0 : 1;
+		}
+		return launch_gauss_cols(s, s->d_yT, s->d_model, bt, B, scale, d_row_ids, M, d_Lout) ? 0 : 1;
 	}
 	const int ldm = model_ld(s->nx);
 	if (!grow(&s->d_model, &s->model_cap, (size_t) B * ldm)) return 1;

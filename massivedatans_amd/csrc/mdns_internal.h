@@ -49,6 +49,7 @@ struct mdns_spectra {
 	double *d_params = nullptr; size_t params_cap = 0;
 	int *d_rows = nullptr; size_t rows_cap = 0;
 	double *d_out = nullptr; size_t out_cap = 0;
+	double *d_sel = nullptr; size_t sel_cap = 0;       // compact replica of the current selection (K1 lane kernel)
 };
 
 namespace mdns {
@@ -68,7 +69,7 @@ int gauss_cols_tile(int M, int B);
 // tiled templates MT[ceil(B/bt)][cols_nx(nx)][bt], zero for b >= B and j >= nx
 bool launch_gauss_model_t(const double *d_x, int nx, const double *d_params, int B, int bt,
                           double *d_model_t);
-bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, int B,
+bool launch_gauss_cols(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                        double scale, const int *d_rows, int M, double *d_out);
 bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B,
                         double *d_model, int ldm);
@@ -80,7 +81,7 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld,
                       bool invert, int lds);
 // rows [ndata][ld] -> tiled channel-major replica [ceil(ndata/64)][cols_nx(nx)][64]
-bool launch_tile_columns(const double *d_y, int ld, int ndata, int nx, double *d_yt);
+bool launch_tile_columns(const double *d_y, int ld, int ndata, int nx, const int *d_rows, double *d_yt);
 bool launch_copy_rows(const double *d_src, int nx, int ndata, double *d_dst, int ld,
                       bool invert);
 bool launch_pad_model(const double *d_src, int nx, int B, double *d_dst, int ldm);

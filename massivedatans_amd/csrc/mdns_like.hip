@@ -152,14 +152,18 @@ __global__ void k_transpose(const double *__restrict__ src, int nx, int ndata, d
 // element (channel j, spectrum i) at ((i / 64) * nxp + j) * 64 + i % 64, zeros in the padding
 // (spectra >= ndata of the last tile, channels nx..nxp-1).  One workgroup = 64 spectra x 32
 // channels through an LDS tile: reads run along channels, writes along spectra.
+// With `rows` (int32[ndata]) spectrum i of the replica is row rows[i] of Y: the compact replica
+// of a selection.
 __global__ __launch_bounds__(kBlock) void k_tile_columns(const double *__restrict__ Y, int ld, int ndata, int nx,
-                                                         int nxp, double *__restrict__ YT)
+                                                         int nxp, const int *__restrict__ rows,
+                                                         double *__restrict__ YT)
 {
 	__shared__ double tile[64][33];
 	const int t = blockIdx.x, j0 = blockIdx.y * 32;
 	for (int r = threadIdx.x >> 5; r < 64; r += 8) {
 		const int i = t * 64 + r, j = j0 + (threadIdx.x & 31);
-		tile[r][threadIdx.x & 31] = (i < ndata && j < nx) ? Y[(size_t) i * ld + j] : 0.0;
+		const int src = (rows && i < ndata) ? rows[i] : i;
+		tile[r][threadIdx.x & 31] = (i < ndata && j < nx) ? Y[(size_t) src * ld + j] : 0.0;
 	}
 	__syncthreads();
 	for (int jj = threadIdx.x >> 6; jj < 32; jj += 4) {
@@ -446,8 +450,12 @@ template <int NP, int CB>
 __global__ __launch_bounds__(kBlock) void k_muse_rows(
     const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
     const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M,
-    double *__restrict__ out)
+    double *__restrict__ out, int bchunk)
 {
+	// grid.y splits the candidates (chunks of `bchunk`, a multiple of CB) when there are too
+	// few rows to fill the chip: a row is then loaded by several workgroups
+	const int bbeg = blockIdx.y * bchunk;
+	const int bend = min(B, bbeg + bchunk);
 	__shared__ double redA[4 * 2 * CB], redB[4 * CB];
 	const int ch = 2 * threadIdx.x;
 	bool valid[NP];
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(kBlock) void k_muse_rows(
 			w[p] = valid[p] ? *reinterpret_cast<const double2 *>(W + base + p * 512) : make_double2(0.0, 0.0);
 			yw[p] = make_double2(y[p].x * w[p].x, y[p].y * w[p].y);
 		}
-		for (int b0 = 0; b0 < B; b0 += CB) {
+		for (int b0 = bbeg; b0 < bend; b0 += CB) {
 			double2 m[CB][NP];
 			double sums[2 * CB];
 #pragma unroll
@@ -658,8 +666,8 @@ bool launch_gauss_model_t(const double *d_x, int nx, const double *d_params, int
 	return launched("k_gauss_model_t");
 }
 
-bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, int B, double scale,
-                       const int *d_rows, int M, double *d_out)
+bool launch_gauss_cols(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
+                       double scale, const int *d_rows, int M, double *d_out)
 {
 	Context *c = ctx();
 	// one spectrum per lane: two per lane (template values reused twice) measured 18 % slower
@@ -678,7 +686,7 @@ bool launch_gauss_cols(const mdns_spectra *s, const double *d_model_t, int bt, i
 	ProfileScope prof(0);
 	note_kernel(0, "k_gauss_cols<%d, %d>", bt, (int) sp);
 #define COLS_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols<BT, sp>), dim3(blocks), dim3(kBlock), 0, c->stream, \
-	s->d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_out)
+	d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_out)
 	switch (bt) {
 	case 16: COLS_LAUNCH(16); break;
 	case 8: COLS_LAUNCH(8); break;
@@ -715,13 +723,13 @@ bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int
 	return launched("k_transpose");
 }
 
-bool launch_tile_columns(const double *d_y, int ld, int ndata, int nx, double *d_yt)
+bool launch_tile_columns(const double *d_y, int ld, int ndata, int nx, const int *d_rows, double *d_yt)
 {
 	Context *c = ctx();
 	if (nx == 0 || ndata == 0) return true;
 	const int nxp = cols_nx(nx);
 	dim3 grid((ndata + 63) / 64, (nxp + 31) / 32);
-	hipLaunchKernelGGL(k_tile_columns, grid, dim3(kBlock), 0, c->stream, d_y, ld, ndata, nx, nxp, d_yt);
+	hipLaunchKernelGGL(k_tile_columns, grid, dim3(kBlock), 0, c->stream, d_y, ld, ndata, nx, nxp, d_rows, d_yt);
 	return launched("k_tile_columns");
 }
 
@@ -787,12 +795,20 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 	ProfileScope prof(1);
 	static const char *k2v = getenv("MDNS_K2_ROWS2");         // experiments only: "0" disables
 	const bool two_rows = B >= 4 && M >= 2 * c->num_cus && !(k2v && k2v[0] == '0');
+	// few rows, several candidates: split the candidates over grid.y until ~2 workgroups per CU
+	// (45 rows x 64 candidates: 69 us as one workgroup per row)
+	// (with more than half a workgroup per CU it measured slower: 407 rows x 16: 29.7 vs 24.2 us)
+	int gy = 2 * blocks <= c->num_cus ? (2 * c->num_cus + blocks - 1) / blocks : 1;
+	if (gy > (B + 1) / 2) gy = (B + 1) / 2;
+	if (gy < 1) gy = 1;
+	const int bchunk = 2 * (((B + gy - 1) / gy + 1) / 2);         // even: k_muse_rows<NP, 2> walks pairs
+	gy = (B + bchunk - 1) / bchunk;
 #define MUSE_LAUNCH(NP) do { if (two_rows) hipLaunchKernelGGL((k_muse_rows2<NP>), dim3((blocks + 1) / 2), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
-	else if (B >= 2) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks), dim3(kBlock), 0, c->stream, \
-		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
+	else if (B >= 2) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks, gy), dim3(kBlock), 0, c->stream, \
+		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, bchunk); \
 	else hipLaunchKernelGGL((k_muse_rows<NP, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, \
-		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); } while (0)
+		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, B); } while (0)
 	if (nx <= 512) MUSE_LAUNCH(1);
 	else if (nx <= 1024) MUSE_LAUNCH(2);
 	else if (nx <= 2048) MUSE_LAUNCH(4);

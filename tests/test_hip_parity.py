@@ -507,3 +507,45 @@ def test_k1_lane_kernel_every_entry(oracle, nd, nx, B):
     want = -0.5 * oracle.gauss_like(x, y, params[b, 0], params[b, 1], params[b, 2], 0.01, mask)
     assert rel_err(got[b], want) < RTOL_L
     sp.close()
+
+
+@pytest.mark.parametrize("nd,nx,B", [(7, 700, 33), (45, 4096, 64), (1, 1500, 9)])
+def test_k2_few_rows_many_candidates(oracle, nd, nx, B):
+    """Few spectra and many templates: the candidates are split over grid.y (odd counts, a
+    single row, full and partial selections).  Every entry against the oracle."""
+    from massivedatans_amd.like import MuseSpectra
+    cube = gen.muse_like(nd, nx=nx)
+    sp = MuseSpectra(cube["x"], cube["y"], cube["v"])
+    rng = np.random.RandomState(nx + B)
+    pars = np.column_stack([rng.uniform(-0.5, 0.5, B), rng.uniform(0, 0.02, B), rng.uniform(-0.1, 0.2, B),
+                            rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
+    ypred = np.array([gen.muse_template(cube["x"], p) for p in pars])
+    masks = [np.ones(nd, bool)]
+    if nd > 2:
+        masks.append(np.arange(nd) % 3 != 1)
+    for mask in masks:
+        got = sp.loglike_batch(ypred, mask)
+        assert got.shape == (B, int(mask.sum()))
+        for b in range(B):
+            want = oracle.muse_like(cube["y"], cube["v"], np.ascontiguousarray(ypred[b]), mask)[mask]
+            assert rel_err(got[b], want) < 1e-11
+    sp.close()
+
+
+@pytest.mark.parametrize("nd,frac,B", [(10000, 0.1, 256), (10000, 0.011, 40), (3000, 0.5, 130), (5000, 0.0003, 64)])
+def test_k1_sparse_selection_is_compacted_exactly(nd, frac, B):
+    """Selections that the lane kernel scores from a compact replica of the selected spectra
+    (many candidates or a sparse mask): the same numbers, bit for bit, as the corresponding
+    columns of the full-mask result of the same kernel."""
+    from massivedatans_amd.like import GaussLineSpectra
+    d = gen.horns(nd)
+    sp = GaussLineSpectra(d["x"], d["y"], noise_level=0.01)
+    rng = np.random.RandomState(B)
+    params = np.column_stack([rng.uniform(0.01, 1, B), rng.uniform(400, 800, B), 10 ** rng.uniform(0, 2, B)])
+    full = sp.loglike_batch(params, np.ones(nd, bool))
+    mask = rng.uniform(size=nd) < frac
+    mask[rng.randint(nd)] = True
+    got = sp.loglike_batch(params, mask)
+    assert got.shape == (B, int(mask.sum()))
+    assert np.array_equal(got, full[:, mask])
+    sp.close()
