@@ -549,3 +549,34 @@ def test_k1_sparse_selection_is_compacted_exactly(nd, frac, B):
     assert got.shape == (B, int(mask.sum()))
     assert np.array_equal(got, full[:, mask])
     sp.close()
+
+
+def test_c5_share_size_properties():
+    """Config C5's share of one of 8 GPUs (6 250 spectra x 4096 channels, 410 MB of y and 1/v on
+    the device): sizes and indexing at full scale, checked by properties -- the batched kernels
+    (two rows per workgroup) against the one-template kernel, a selection against the same
+    columns of the full result, templates evaluated on the device against uploaded ones, and
+    the defining formula (cmuselike.c:45-64) in numpy on a sample of spectra."""
+    from massivedatans_amd.like import MuseSpectra
+    nd, nx, B = 6250, 4096, 6
+    cube = gen.muse_like(nd, nx=nx)
+    sp = MuseSpectra(cube["x"], cube["y"], cube["v"])
+    rng = np.random.RandomState(5)
+    pars = np.column_stack([rng.uniform(-0.5, 0.5, B), rng.uniform(0, 0.02, B), rng.uniform(-0.1, 0.2, B),
+                            rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
+    ypred = np.array([gen.muse_template(cube["x"], p) for p in pars])
+    full = sp.loglike_batch(ypred)                               # two rows per workgroup
+    assert full.shape == (B, nd) and np.all(np.isfinite(full)) and np.all(full <= 0)
+    one = sp.loglike_batch(ypred[2:3])[0]                        # one-template kernel
+    assert rel_err(one, full[2]) < 1e-12
+    assert rel_err(sp.loglike_batch_lines(pars), full) < 1e-9    # device-side templates
+    mask = rng.uniform(size=nd) < 0.3
+    assert rel_err(sp.loglike_batch(ypred, mask), full[:, mask]) < 1e-12
+    for i in rng.choice(nd, size=40, replace=False):
+        y, v = cube["y"][:, i], cube["v"][:, i]
+        for b in (0, B - 1):
+            m = ypred[b]
+            s = (y * m / v).sum() / (1e-10 + (m * m / v).sum())
+            want = -0.5 * (((y - s * m) ** 2) / v).sum()
+            assert abs(full[b, i] - want) <= 1e-10 * abs(want)
+    sp.close()
