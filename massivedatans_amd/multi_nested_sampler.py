@@ -203,61 +203,101 @@ class MultiNestedSampler(object):
                     self.point_data_map[p].add(d)
 
     # ---- grouping data sets that share live points ---------------------------------------
+    def _distinct_points(self, selected):
+        """Sorted distinct point ids held by the data sets ``selected`` -- ``numpy.unique`` of
+        their columns, by counting instead of sorting -- and the holder count of every id."""
+        held = numpy.bincount(self.live_pointsp[:, selected].ravel(), minlength=len(self.pointpile))
+        return numpy.flatnonzero(held), held
+
     def _trivial_groups(self, data_mask, allp):
         """The cases where no decomposition is needed (multi_nested_sampler.py:206-235);
-        returns (groups or None, allp)."""
+        returns (groups or None, allp, holder counts or None)."""
         selected = numpy.where(data_mask)[0]
         if len(selected) == 1:
-            return [(data_mask, self.live_pointsp[:, selected[0]])], allp
-        if len(selected) != len(data_mask):
-            allp = numpy.unique(self.live_pointsp[:, selected].flatten())
+            return [(data_mask, self.live_pointsp[:, selected[0]])], allp, None
+        held = None
+        if len(selected) != len(data_mask) or allp is None:
+            allp, held = self._distinct_points(selected)
         if len(allp) < 2 * self.nlive_points:
             # fewer than 2 nlive distinct points over several data sets: some are shared
-            return [(data_mask, allp)], allp
+            return [(data_mask, allp)], allp, held
         if len(self.superpoints) > 0:
-            return [(data_mask, allp)], allp
-        return None, allp
+            return [(data_mask, allp)], allp, held
+        return None, allp, held
 
     def generate_subsets_nograph(self, data_mask, allp):
         """Groups of data sets connected through shared live points, grown from the first
         unhandled data set by walking its live points in discovery order
-        (multi_nested_sampler.py:237-266).  Yields (mask, list of point ids)."""
-        groups, allp = self._trivial_groups(data_mask, allp)
+        (multi_nested_sampler.py:237-266).  Yields (mask, point ids in discovery order).
+
+        The reference visits every listed point and intersects its holders with the data sets
+        still to place.  Most visits find nobody: ``held[p]`` counts the holders of p among the
+        data sets still to place, and the walk jumps from one point with holders to the next
+        (the counts only fall, so a point found empty stays empty).  Late in a run the selection
+        is one component of a thousand data sets and tens of thousands of points, of which a
+        few hundred bring somebody in."""
+        groups, allp, held = self._trivial_groups(data_mask, allp)
         if groups is not None:
             for g in groups:
                 yield g
             return
         self.rebuild_map()
+        lp = self.live_pointsp
         todo = data_mask.copy()
         todo_set = set(numpy.flatnonzero(todo).tolist())     # same content as `todo`, for set algebra
+        if held is None and todo.all():
+            held = self._refcount[:len(self.pointpile)].copy()     # every data set: the running id counts
+        elif held is None:
+            held = numpy.bincount(lp[:, todo].ravel(), minlength=len(self.pointpile))
+        known = numpy.zeros(len(held), dtype=bool)
+        BLOCK = 2048
         while todo_set:
             first = numpy.where(todo)[0][0]
             todo[first] = False
             todo_set.discard(int(first))
             members = [first]
-            points = self.live_pointsp[:, first].tolist()
+            column = lp[:, first]
+            held[column] -= 1                       # ids within a column are distinct
+            points = numpy.empty(max(4 * len(column), 1024), dtype=lp.dtype)
+            npoints = len(column)
+            points[:npoints] = column
+            known[column] = True
             i = 0
-            known = set(points)
-            while i < len(points) and todo_set:
-                # data sets still to place that hold this point (their order is immaterial:
-                # they only enter a mask and a numpy.unique)
-                newmembers = list(self.point_data_map[points[i]] & todo_set)
-                if newmembers:
-                    members += newmembers
-                    # the reference appends numpy.unique(...) of the new members' live points
-                    # that are not yet listed: ascending ids, each once
-                    cols = self.live_pointsp[:, newmembers]
-                    uniq = numpy.unique(cols) if cols.size > 256 else sorted(set(cols.ravel().tolist()))
-                    fresh = [p for p in (uniq.tolist() if cols.size > 256 else uniq) if p not in known]
-                    if fresh:
-                        known.update(fresh)
-                        points.extend(fresh)
-                    todo[newmembers] = False
-                    todo_set.difference_update(newmembers)
+            while todo_set:
+                # next listed point that a data set still to place holds
+                while i < npoints:
+                    hit = numpy.flatnonzero(held[points[i:min(npoints, i + BLOCK)]] > 0)
+                    if len(hit):
+                        i += int(hit[0])
+                        break
+                    i = min(npoints, i + BLOCK)
+                if i >= npoints:
+                    break
+                # (their order is immaterial: they only enter a mask and a sorted id list)
+                newmembers = list(self.point_data_map[int(points[i])] & todo_set)
+                members += newmembers
+                flat = lp[:, newmembers].ravel()
+                if flat.size < 512:
+                    numpy.subtract.at(held, flat, 1)
+                else:
+                    held -= numpy.bincount(flat, minlength=len(held))
+                # the reference appends numpy.unique(...) of the new members' live points
+                # that are not yet listed: ascending ids, each once (most are listed already)
+                unlisted = flat[~known[flat]]
+                if unlisted.size:
+                    fresh = numpy.unique(unlisted)
+                    known[fresh] = True
+                    if npoints + len(fresh) > len(points):
+                        points = numpy.concatenate((points, numpy.empty(max(len(points), len(fresh)), dtype=points.dtype)))
+                    points[npoints:npoints + len(fresh)] = fresh
+                    npoints += len(fresh)
+                todo[newmembers] = False
+                todo_set.difference_update(newmembers)
                 i += 1
+            known[points[:npoints]] = False            # next component starts clean
             member_mask = numpy.zeros(len(data_mask), dtype=bool)
             member_mask[members] = True
-            yield member_mask, points
+            yield member_mask, points[:npoints].copy()
 
     def generate_subsets_graph(self, data_mask, allp):
         """Connected components of the bipartite (data set, live point) graph, as the
@@ -265,7 +305,7 @@ class MultiNestedSampler(object):
         their lowest data-set index, point ids ascending.  igraph is not available in this
         image, so this ordering is restated from igraph's documented behaviour and is NOT pinned
         against a reference run (the pinned path is ``use_graph=False``)."""
-        groups, allp = self._trivial_groups(data_mask, allp)
+        groups, allp, _ = self._trivial_groups(data_mask, allp)
         if groups is not None:
             for g in groups:
                 yield g
@@ -354,7 +394,7 @@ class MultiNestedSampler(object):
             focussed = passes > self.nsuperset_draws
             if focussed:
                 data_mask = empty
-                _, points = self.get_unique_pointsp(self.live_pointsp[:, data_mask])
+                points = None                     # found by the grouping itself (one counting pass)
             else:
                 data_mask = self.data_mask_all
                 points = allp
