@@ -141,3 +141,57 @@ def test_hdf5_without_h5py_fails_loudly(tmp_path):
         pass
     with pytest.raises(RuntimeError, match="h5py"):
         gen.load(str(tmp_path / "x.hdf5"))
+
+
+def _fake_sampler(lp, npoints, nlive):
+    """Just enough of a MultiNestedSampler for the grouping code."""
+    from massivedatans_amd.multi_nested_sampler import MultiNestedSampler
+    s = MultiNestedSampler.__new__(MultiNestedSampler)
+    s.live_pointsp = lp
+    s.pointpile = np.zeros((npoints, 3))
+    s.nlive_points = nlive
+    s.superpoints = set()
+    s.point_data_map = None
+    s.ndata = lp.shape[1]
+    s._lpT = None
+    s._refcount = np.bincount(lp.ravel(), minlength=npoints)
+    return s
+
+
+def test_native_grouping_walk_equals_python_walk():
+    """csrc/host_groups.c against the Python statement of the reference's walk
+    (multi_nested_sampler.py:237-266): same groups in the same order, same point order --
+    on id matrices with one big component, many small ones, singletons and full selections."""
+    from massivedatans_amd import multi_nested_sampler as mns
+    if mns._host_lib() is None:
+        import pytest
+        pytest.skip("libmdns_host.so not built")
+    rng = np.random.RandomState(3)
+    for trial in range(40):
+        nlive = int(rng.randint(2, 9))
+        ndata = int(rng.randint(2, 60))
+        nclusters = int(rng.randint(1, 8))
+        # data sets draw their live points from the pool of their cluster (+ sometimes a shared one)
+        pools = [np.arange(c * 50, c * 50 + rng.randint(nlive, 50)) for c in range(nclusters)]
+        lp = np.empty((nlive, ndata), dtype=np.int64)
+        for d in range(ndata):
+            pool = pools[rng.randint(nclusters)]
+            if rng.uniform() < 0.2:
+                pool = np.arange(1000 + 10 * d, 1000 + 10 * d + nlive)        # a loner
+            lp[:, d] = rng.choice(pool, size=nlive, replace=False)
+        npoints = int(lp.max()) + 1
+        mask = rng.uniform(size=ndata) < rng.choice([0.3, 0.7, 1.0])
+        if mask.sum() < 2:
+            mask[:2] = True
+        s = _fake_sampler(lp, npoints, nlive)
+        native = [(m.copy(), np.asarray(p).copy()) for m, p in s.generate_subsets_nograph(mask, None)]
+        lib, mns._HOST_LIB = mns._HOST_LIB, False                              # force the Python walk
+        try:
+            python = [(m.copy(), np.asarray(p).copy()) for m, p in s.generate_subsets_nograph(mask, None)]
+        finally:
+            mns._HOST_LIB = lib
+        assert len(native) == len(python)
+        for (m1, p1), (m2, p2) in zip(native, python):
+            assert np.array_equal(m1, m2)
+            assert np.array_equal(p1, p2)
+        assert np.array_equal(np.sum([m for m, _ in native], axis=0) > 0, mask)
