@@ -8,9 +8,27 @@ from massivedatans_amd import gen, sample
 kind, ndata, nlive, cap = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 data = (gen.horns if kind == "horns" else gen.nothing)(ndata)
 t0 = time.time()
+# a heartbeat on stderr for long runs (the GPU queue treats a silent process as hung)
+import threading
+from massivedatans_amd import multi_nested_sampler as _mns
+_live = {}
+_orig_init = _mns.MultiNestedSampler.__init__
+def _init(self, *a, **k):
+    _orig_init(self, *a, **k)
+    _live["sampler"] = self
+_mns.MultiNestedSampler.__init__ = _init
+def _beat():
+    while not _live.get("done"):
+        time.sleep(60)
+        s = _live.get("sampler")
+        if s is not None and not _live.get("done"):
+            print("[%.0f s] iteration %d, %d data sets running, %d draws" % (time.time() - t0, s.global_iter, s.ndata, s.ndraws),
+                  file=sys.stderr, flush=True)
+threading.Thread(target=_beat, daemon=True).start()
 with np.errstate(all="ignore"):
     results, sampler, problem, duration = sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap,
                                                      use_graph=False)
+_live["done"] = True
 print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nlive, cap), "wall_s": duration,
                   "setup_s": time.time() - t0 - duration, "iterations": int(results["nsamples"]),
                   "ndraws": int(sampler.ndraws), "evals_useful": int(sampler.nevals),
