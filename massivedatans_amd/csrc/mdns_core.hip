@@ -827,9 +827,10 @@ struct mdns_region {
 	unsigned long long seq = 0;
 	bool on_device = false;           // the membership kernel must use d_res
 	bool pending = false;             // the host copies still have to be fetched (async path)
-	double *d_chosen = nullptr; size_t chosen_cap = 0;
-	double *d_points = nullptr; size_t points_cap = 0;
-	int *d_counts = nullptr; size_t counts_cap = 0;
+	size_t owned_bytes = 0, own_round_bytes = 0;      // pool_take sizes
+	void *d_chosen = nullptr; size_t chosen_bytes = 0;
+	void *d_points = nullptr; size_t points_bytes = 0;
+	void *d_counts = nullptr; size_t counts_bytes = 0;
 };
 
 // Result slots ({radius, threshold} on the device, its mapped host mirror and the ticket
@@ -864,6 +865,50 @@ static int take_result_slot()
 	return slot;
 }
 
+// Device buffers of the region handles come from a small cache: the host code builds a region
+// per rebuild of a constrained draw (thousands per run), and hipMalloc / hipFree per buffer were a
+// quarter of a millisecond per region.  Everything runs on one stream, so a buffer handed back
+// and taken again is reused in stream order: no synchronisation is needed.
+struct PoolEntry { size_t bytes; void *p; };
+static std::vector<PoolEntry> g_pool;
+
+static void *pool_take(size_t bytes, size_t *got)
+{
+	size_t want = 4096;
+	while (want < bytes) want <<= 1;
+	for (size_t i = 0; i < g_pool.size(); i++)
+		if (g_pool[i].bytes == want) {
+			void *p = g_pool[i].p;
+			g_pool[i] = g_pool.back();
+			g_pool.pop_back();
+			*got = want;
+			return p;
+		}
+	void *p = nullptr;
+	if (!MDNS_HIP(hipMalloc(&p, want))) return nullptr;
+	*got = want;
+	return p;
+}
+
+static void pool_give(void *p, size_t bytes)
+{
+	if (!p) return;
+	if (g_pool.size() >= 64) { (void) hipFree(p); return; }
+	g_pool.push_back({bytes, p});
+}
+
+// make *p hold at least `need` bytes (contents are not kept)
+static bool pool_fit(void **p, size_t *cap, size_t need)
+{
+	if (need <= *cap) return true;
+	pool_give(*p, *cap);
+	*cap = 0;
+	*p = pool_take(need, cap);
+	return *p != nullptr;
+}
+
+static bool region_fetch(mdns_region *r);
+
 static mdns_region *region_new(const double *d_members, double *owned, int K, int ndim)
 {
 	mdns_region *r = new mdns_region();
@@ -887,12 +932,15 @@ extern "C" mdns_region *mdns_region_create(const double *members, int K, int ndi
 	Context *c = ctx();
 	if (!c) return nullptr;
 	if (!members || K <= 0 || ndim <= 0) { set_error("mdns_region_create: bad arguments (K=%d ndim=%d)", K, ndim); return nullptr; }
-	double *d = nullptr;
 	const size_t bytes = (size_t) K * ndim * sizeof(double);
-	if (!MDNS_HIP(hipMalloc((void **) &d, bytes))) return nullptr;
+	size_t got = 0;
+	double *d = (double *) pool_take(bytes, &got);
+	if (!d) return nullptr;
 	if (!MDNS_HIP(hipMemcpyAsync(d, members, bytes, hipMemcpyHostToDevice, c->stream)) ||
-	    !MDNS_HIP(hipStreamSynchronize(c->stream))) { (void) hipFree(d); return nullptr; }
-	return region_new(d, d, K, ndim);
+	    !MDNS_HIP(hipStreamSynchronize(c->stream))) { pool_give(d, got); return nullptr; }
+	mdns_region *r = region_new(d, d, K, ndim);
+	if (r) r->owned_bytes = got; else pool_give(d, got);
+	return r;
 }
 
 extern "C" mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int ndim)
@@ -905,11 +953,15 @@ extern "C" mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int
 extern "C" void mdns_region_destroy(mdns_region *r)
 {
 	if (!r) return;
-	Context *c = ctx();
-	if (c) (void) hipStreamSynchronize(c->stream);
-	void *bufs[] = {r->owned, r->own_round, r->d_chosen, r->d_points, r->d_counts};
-	for (void *b : bufs) if (b) (void) hipFree(b);
-	if (r->slot >= 0) g_free_slots.push_back(r->slot);      // the stream is idle: nobody writes it any more
+	// a radius computation still in flight writes the result slot: let it land before the slot
+	// can go to another handle (the buffers themselves are reused in stream order)
+	if (r->pending && ctx()) (void) region_fetch(r);
+	pool_give(r->owned, r->owned_bytes);
+	pool_give(r->own_round, r->own_round_bytes);
+	pool_give(r->d_chosen, r->chosen_bytes);
+	pool_give(r->d_points, r->points_bytes);
+	pool_give(r->d_counts, r->counts_bytes);
+	if (r->slot >= 0) g_free_slots.push_back(r->slot);
 	delete r;
 }
 
@@ -959,9 +1011,7 @@ extern "C" int mdns_region_bootstrap_radius_async(mdns_region *r, const double *
 	if (nbootstraps <= 0) { set_error("mdns_region_bootstrap_radius: nbootstraps=%d", nbootstraps); return 1; }
 	if (!region_fetch(r)) return 1;             // a previous result may still be travelling
 	if (r->round_cap < nbootstraps) {
-		(void) hipStreamSynchronize(c->stream);
-		if (r->own_round) { (void) hipFree(r->own_round); r->own_round = nullptr; }
-		if (!MDNS_HIP(hipMalloc((void **) &r->own_round, (size_t) nbootstraps * sizeof(double)))) return 1;
+		if (!pool_fit((void **) &r->own_round, &r->own_round_bytes, (size_t) nbootstraps * sizeof(double))) return 1;
 		r->d_round = r->own_round;
 		// zero once: every finishing computation hands its slots back zeroed
 		if (!MDNS_HIP(hipMemsetAsync(r->d_round, 0, (size_t) nbootstraps * sizeof(double), c->stream))) return 1;
@@ -986,9 +1036,9 @@ extern "C" double mdns_region_bootstrap_radius(mdns_region *r, const double *cho
 	if (!c || !r) return NAN;
 	const size_t n = (size_t) r->K * (nbootstraps > 0 ? nbootstraps : 0);
 	if (n == 0) { set_error("mdns_region_bootstrap_radius: nbootstraps=%d", nbootstraps); return NAN; }
-	if (!grow(&r->d_chosen, &r->chosen_cap, n)) return NAN;
+	if (!pool_fit(&r->d_chosen, &r->chosen_bytes, n * sizeof(double))) return NAN;
 	if (!MDNS_HIP(hipMemcpyAsync(r->d_chosen, chosen, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return NAN;
-	return mdns_region_bootstrap_radius_dev(r, r->d_chosen, nbootstraps);
+	return mdns_region_bootstrap_radius_dev(r, (const double *) r->d_chosen, nbootstraps);
 }
 
 extern "C" int mdns_region_count_dev(mdns_region *r, const double *d_points, int M, int *d_counts)
@@ -1009,9 +1059,10 @@ extern "C" int mdns_region_count(mdns_region *r, const double *points, int M, in
 	if (!c || !r) return 1;
 	if (M <= 0) return M < 0;
 	const size_t n = (size_t) M * r->ndim;
-	if (!grow(&r->d_points, &r->points_cap, n) || !grow(&r->d_counts, &r->counts_cap, (size_t) M)) return 1;
+	if (!pool_fit(&r->d_points, &r->points_bytes, n * sizeof(double)) ||
+	    !pool_fit(&r->d_counts, &r->counts_bytes, (size_t) M * sizeof(int))) return 1;
 	if (!MDNS_HIP(hipMemcpyAsync(r->d_points, points, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
-	if (mdns_region_count_dev(r, r->d_points, M, r->d_counts) != 0) return 1;
+	if (mdns_region_count_dev(r, (const double *) r->d_points, M, (int *) r->d_counts) != 0) return 1;
 	if (!MDNS_HIP(hipMemcpyAsync(counts, r->d_counts, (size_t) M * sizeof(int), hipMemcpyDeviceToHost, c->stream))) return 1;
 	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
 }
