@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end analysis on the GPU: python tools/e2e_run.py <horns|nothing> <ndata> <nlive> <max_samples>"""
+"""End-to-end analysis on the GPU: python tools/e2e_run.py <horns|nothing> <ndata> <nlive> <max_samples>
+(max_samples 0 = run to the termination criterion; MDNS_E2E_PROFILE=1 adds a cProfile summary on stderr)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -25,9 +26,16 @@ def _beat():
             print("[%.0f s] iteration %d, %d data sets running, %d draws" % (time.time() - t0, s.global_iter, s.ndata, s.ndraws),
                   file=sys.stderr, flush=True)
 threading.Thread(target=_beat, daemon=True).start()
-with np.errstate(all="ignore"):
-    results, sampler, problem, duration = sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap,
-                                                     use_graph=False)
+def _go():
+    with np.errstate(all="ignore"):
+        return sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap, use_graph=False)
+if os.environ.get("MDNS_E2E_PROFILE") == "1":        # cProfile of the whole run, top entries on stderr
+    import cProfile, pstats
+    prof = cProfile.Profile()
+    results, sampler, problem, duration = prof.runcall(_go)
+    pstats.Stats(prof, stream=sys.stderr).sort_stats("tottime").print_stats(30)
+else:
+    results, sampler, problem, duration = _go()
 _live["done"] = True
 print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nlive, cap), "wall_s": duration,
                   "setup_s": time.time() - t0 - duration, "iterations": int(results["nsamples"]),
