@@ -68,9 +68,12 @@ def draw_bootstrap_choice(nsamples, nbootstraps):
     """The ``chosen`` matrix exactly as neighbors.py:170-174 builds it: one
     ``numpy.random.choice(arange(n), size=n, replace=True)`` per round on the GLOBAL legacy
     RNG stream (the call order is part of the results)."""
+    # legacy ``choice(arange(n), size=n)`` is ``randint(0, n, size=n)``, value by value, so all
+    # rounds come from one ``randint`` of shape (rounds, n): the same numbers from the same
+    # position of the stream (tests/test_sampler_units.py compares with the spelled-out calls)
+    idx = numpy.random.randint(0, nsamples, size=(nbootstraps, nsamples))
     chosen = numpy.zeros((nsamples, nbootstraps))
-    for b in range(nbootstraps):
-        chosen[numpy.random.choice(numpy.arange(nsamples), size=nsamples, replace=True), b] = 1.
+    chosen[idx, numpy.arange(nbootstraps)[:, None]] = 1.
     return chosen
 
 

@@ -154,8 +154,12 @@ class MultiNestedSampler(object):
         else:
             Ls = [multi_loglikelihood(x, data_mask=all_mask) for x in xs]
         self.nevals += nlive_points * ndata
-        self.pointpile = numpy.array(us)
-        self.pointpilex = numpy.array(xs)
+        # every point ever accepted; kept as views of buffers that grow geometrically (a run of
+        # 10 000 data sets accepts millions of points: copying the pile per point was 8 % of it)
+        self._pile_u = numpy.array(us)
+        self._pile_x = numpy.array(xs)
+        self.pointpile = self._pile_u
+        self.pointpilex = self._pile_x
         self.live_pointsp = numpy.array([[p] * ndata for p in range(nlive_points)])
         self.live_pointsL = numpy.array(Ls)
         self.superpoints = set(range(nlive_points))
@@ -168,7 +172,10 @@ class MultiNestedSampler(object):
         self.real_data_mask_all = numpy.ones(self.ndata) == 1
         self.ndraws = nlive_points
         self._shelves = _Shelves(ndata)
-        self._lpT = None                    # live_pointsp transposed, for the native grouping walk
+        self._real_indices = None
+        self._lpT = None                    # live_pointsp relabelled + transposed, for the native grouping walk
+        self._alive = None
+        self._label = numpy.zeros(1024, dtype=numpy.int64)
         self._low = None                    # smallest live likelihoods per data set (_refresh_thresholds)
         self._low_cap = -1
 
@@ -208,6 +215,7 @@ class MultiNestedSampler(object):
         self.data_mask_all = numpy.ones(self.ndata) == 1
         # in place: constrainer caches hold a reference to this array
         self.real_data_mask_all[self.real_data_mask_all] = surviving
+        self._real_indices = None
 
         def expand(mask):
             full = self.real_data_mask_all.copy()
@@ -281,11 +289,20 @@ class MultiNestedSampler(object):
         if nsel == 1:
             yield data_mask, self.live_pointsp[:, numpy.flatnonzero(data_mask)[0]]
             return
-        if self._lpT is None:                         # once per iteration: the matrix is fixed while
-            self._lpT = numpy.ascontiguousarray(self.live_pointsp.T)       # the shelves are filled
+        if self._lpT is None:
+            # Once per iteration (the matrix is fixed while the shelves are filled): the ids in
+            # use, relabelled 0..nalive-1 in ascending order, and the matrix transposed.  The pile
+            # holds every point ever accepted (millions by the end of a run); the walk's work
+            # arrays must be as long as the ids in use, not as the pile.
+            self._alive = numpy.flatnonzero(self._refcount[:len(self.pointpile)])
+            if len(self._label) < len(self.pointpile):
+                self._label = numpy.zeros(max(2 * len(self._label), len(self.pointpile) + 1024), dtype=numpy.int64)
+            self._label[self._alive] = numpy.arange(len(self._alive))
+            self._lpT = numpy.ascontiguousarray(self._label[self.live_pointsp.T])
         lp = self._lpT
+        alive = self._alive
         ndata, nlive = lp.shape
-        npoints = len(self.pointpile)
+        npoints = len(alive)
         mask8 = numpy.ascontiguousarray(data_mask, dtype=numpy.uint8)
         group_of = numpy.empty(ndata, dtype=numpy.int32)
         offsets = numpy.empty(ndata + 1, dtype=numpy.int64)
@@ -302,14 +319,14 @@ class MultiNestedSampler(object):
             cap = nsel * nlive                        # columns with repeated ids: the safe bound
         if n < 0:
             raise MemoryError("mdns_host_group_walk")
-        allp = distinct[:ndistinct.value]
+        allp = alive[distinct[:ndistinct.value]]      # labels ascend with the ids: still sorted
         if len(allp) < 2 * self.nlive_points or len(self.superpoints) > 0:
             yield data_mask, allp                     # some points are shared by all: one group
         elif n == 1:
-            yield data_mask.copy(), points[:offsets[1]]
+            yield data_mask.copy(), alive[points[:offsets[1]]]
         else:
             for g in range(n):
-                yield group_of == g, points[offsets[g]:offsets[g + 1]]
+                yield group_of == g, alive[points[offsets[g]:offsets[g + 1]]]
 
     def _walk_python(self, data_mask, held):
         """The same walk in Python (used when libmdns_host.so is not built, and as the
@@ -490,7 +507,9 @@ class MultiNestedSampler(object):
                 if len(groups) > 1 and not focussed and (self._shelves.n[joint_indices] > 0).all():
                     continue                      # this group needs nothing
                 Lmins_higher = self._higher[joint_indices].copy()
-                real_indices = numpy.where(self.real_data_mask_all)[0]
+                if self._real_indices is None:        # original index of every running data set
+                    self._real_indices = numpy.where(self.real_data_mask_all)[0]
+                real_indices = self._real_indices
                 if njoints == 1:
                     draw = self.individual_draw_constrained(real_indices[firstd], self.global_iter, sampler=self)
                 elif rebuilding_draw:
@@ -514,8 +533,14 @@ class MultiNestedSampler(object):
                 self.ndraws += int(n)
                 self.nevals += int(n) * njoints
                 ppi = len(self.pointpile)
-                self.pointpile = numpy.vstack((self.pointpile, [uj]))
-                self.pointpilex = numpy.vstack((self.pointpilex, [xj]))
+                if ppi == len(self._pile_u):
+                    room = numpy.empty((max(1024, ppi), self._pile_u.shape[1]))
+                    self._pile_u = numpy.vstack((self._pile_u, room))
+                    self._pile_x = numpy.vstack((self._pile_x, room))
+                self._pile_u[ppi] = uj
+                self._pile_x[ppi] = xj
+                self.pointpile = self._pile_u[:ppi + 1]
+                self.pointpilex = self._pile_x[:ppi + 1]
                 beats = Lj > Lmins_higher
                 self._shelves.append(joint_indices[beats], ppi, Lj[beats])
                 self._refresh_thresholds(joint_indices[beats])

@@ -154,6 +154,8 @@ def _fake_sampler(lp, npoints, nlive):
     s.point_data_map = None
     s.ndata = lp.shape[1]
     s._lpT = None
+    s._alive = None
+    s._label = np.zeros(16, dtype=np.int64)
     s._refcount = np.bincount(lp.ravel(), minlength=npoints)
     return s
 
@@ -195,3 +197,19 @@ def test_native_grouping_walk_equals_python_walk():
             assert np.array_equal(m1, m2)
             assert np.array_equal(p1, p2)
         assert np.array_equal(np.sum([m for m, _ in native], axis=0) > 0, mask)
+
+
+def test_bootstrap_choice_consumes_the_rng_like_the_reference():
+    """draw_bootstrap_choice against the reference's spelled-out loop (neighbors.py:170-174):
+    same matrix, and the global legacy RNG stream left at the same position."""
+    from massivedatans_amd.clustering.neighbors import draw_bootstrap_choice
+    for n in list(range(1, 60)) + [100, 257, 400, 3000]:
+        for B in (1, 10, 15):
+            np.random.seed(n * 31 + B)
+            want = np.zeros((n, B))
+            for b in range(B):
+                want[np.random.choice(np.arange(n), size=n, replace=True), b] = 1.
+            after_want = np.random.uniform()
+            np.random.seed(n * 31 + B)
+            got = draw_bootstrap_choice(n, B)
+            assert np.array_equal(got, want) and np.random.uniform() == after_want
