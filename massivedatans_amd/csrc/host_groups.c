@@ -1,7 +1,8 @@
 /* Host-side helper (plain C, no GPU): the grouping of data sets that share live points,
  * multi_nested_sampler.py:237-266 of the reference (generate_subsets_nograph), restated over
- * arrays.  Late in a run this walk is called hundreds of times per nested-sampling iteration on
- * a component of a thousand data sets; in Python it was two thirds of the wall-clock.
+ * arrays.  Late in a run this walk is called a hundred times per nested-sampling iteration, on
+ * anything from one data set to a component of thousands; in Python it was two thirds of the
+ * wall-clock.
  *
  * The result has to be what the reference's walk produces, ORDER included (the order of a
  * group's points decides which of them the bootstrap rounds leave out):
@@ -9,7 +10,9 @@
  *   - a group's points: the live points of its first data set in live-slot order, then, for
  *     every listed point in turn, the not yet listed live points of the data sets it brings
  *     in (those still unplaced that hold it), ascending and each once.
- * Integer work only. */
+ * Integer work only.  The cost of a call is proportional to the SELECTED data sets: the
+ * per-id work arrays belong to the caller, arrive zeroed and are handed back zeroed (only the
+ * entries of the ids the selection holds are touched). */
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -24,93 +27,102 @@ static int cmp_i64(const void *a, const void *b)
  *                                 sampler's matrix: the walk reads whole data sets)
  * mask      uint8[ndata]          the data sets to group
  * npoints                         ids are in [0, npoints)
+ * cnt       int32[npoints]  work  zero on entry and on return: holders of an id in the selection
+ * first     int64[npoints]  work  any content: where an id's holder list starts
+ * known     uint8[npoints]  work  zero on entry and on return
  * group_of  int32[ndata]   out    group index of every selected data set, -1 for the others
  * points    int64[cap]     out    the groups' point lists, one after the other
  * offsets   int64[ndata+1] out    group g owns points[offsets[g] : offsets[g+1]]
- * distinct  int64[npoints] out    the distinct ids held by the selection, ascending
- *                                 (numpy.unique of the selected columns); *ndistinct their number
+ * distinct  int64[npoints] out    the distinct ids held by the selection (numpy.unique of the
+ *                                 selected columns), ascending if `sorted_distinct` or if there
+ *                                 are fewer than `sort_below` of them; *ndistinct their number
  * Returns the number of groups, -1 if out of memory, -2 if `cap` is too small (cap >= the
- * number of distinct ids held by the selection is always enough). */
+ * number of distinct ids + nlive is enough when the ids of a data set are distinct). */
 int mdns_host_group_walk(const int64_t *lpT, int nlive, int ndata, const uint8_t *mask, int64_t npoints,
+                         int32_t *cnt, int64_t *first, uint8_t *known,
                          int32_t *group_of, int64_t *points, int64_t cap, int64_t *offsets,
-                         int64_t *distinct, int64_t *ndistinct)
+                         int64_t *distinct, int64_t *ndistinct, int sorted_distinct, int64_t sort_below)
 {
-	int64_t *start = (int64_t *) calloc((size_t) npoints + 1, sizeof(int64_t));   /* CSR: id -> holders */
-	uint8_t *known = (uint8_t *) calloc((size_t) npoints, 1);
+	(void) npoints;
 	uint8_t *todo = (uint8_t *) malloc((size_t) ndata);
-	int32_t *holders = NULL, *fresh_members = NULL;
+	int32_t *holders = NULL, *sel = NULL;
 	int64_t *fresh = NULL;
 	int ngroups = -1;
-	if (!start || !known || !todo) goto done;
+	int64_t nt = 0;                                   /* ids touched = distinct ids */
+	if (!todo) goto done;
 	int64_t nsel = 0;
 	for (int d = 0; d < ndata; d++) { todo[d] = mask[d] != 0; group_of[d] = -1; nsel += todo[d]; }
-	/* only the selected columns are ever touched: late in a run they are a tenth of the matrix */
-	fresh_members = (int32_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * sizeof(int32_t));
-	if (!fresh_members) goto done;
+	sel = (int32_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * sizeof(int32_t));
+	holders = (int32_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * nlive * sizeof(int32_t));
+	fresh = (int64_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * nlive * sizeof(int64_t));
+	if (!sel || !holders || !fresh) goto done;
 	{
 		int64_t j = 0;
-		for (int d = 0; d < ndata; d++) if (todo[d]) fresh_members[j++] = d;      /* ascending */
+		for (int d = 0; d < ndata; d++) if (todo[d]) sel[j++] = d;               /* ascending */
 	}
+	/* holders per id, the ids in the order they are first met (`distinct`) */
 	for (int64_t j = 0; j < nsel; j++) {
-		const int64_t *ids = lpT + (size_t) fresh_members[j] * nlive;
-		for (int k = 0; k < nlive; k++) start[ids[k] + 1]++;
-	}
-	{
-		int64_t n = 0;
-		for (int64_t p = 0; p < npoints; p++) if (start[p + 1]) distinct[n++] = p;
-		*ndistinct = n;
-	}
-	for (int64_t p = 0; p < npoints; p++) start[p + 1] += start[p];
-	holders = (int32_t *) malloc((size_t) (start[npoints] > 0 ? start[npoints] : 1) * sizeof(int32_t));
-	fresh = (int64_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * nlive * sizeof(int64_t));
-	int64_t *fill = (int64_t *) malloc((size_t) (npoints > 0 ? npoints : 1) * sizeof(int64_t));
-	if (!holders || !fresh || !fill) { free(fill); goto done; }
-	memcpy(fill, start, (size_t) npoints * sizeof(int64_t));
-	for (int64_t j = 0; j < nsel; j++) {          /* ascending data sets: holder lists come out sorted */
-		const int64_t *ids = lpT + (size_t) fresh_members[j] * nlive;
-		for (int k = 0; k < nlive; k++) holders[fill[ids[k]]++] = fresh_members[j];
-	}
-	free(fill);
-
-	int64_t used = 0, left = nsel;
-	int next_first = 0;
-	ngroups = 0;
-	offsets[0] = 0;
-	while (left > 0) {
-		while (!todo[next_first]) next_first++;
-		const int first = next_first;
-		todo[first] = 0; left--;
-		group_of[first] = ngroups;
-		const int64_t begin = used;
-		if (used + nlive > cap) { ngroups = -2; goto done; }
+		const int64_t *ids = lpT + (size_t) sel[j] * nlive;
 		for (int k = 0; k < nlive; k++) {
-			const int64_t p = lpT[(size_t) first * nlive + k];
-			points[used++] = p;
-			known[p] = 1;
+			if (cnt[ids[k]]++ == 0) distinct[nt++] = ids[k];
 		}
-		for (int64_t i = begin; i < used && left > 0; i++) {
-			const int64_t p = points[i];
-			int nnew = 0;
-			for (int64_t h = start[p]; h < start[p + 1]; h++) {
-				const int d = holders[h];
-				if (todo[d]) { todo[d] = 0; left--; group_of[d] = ngroups; fresh_members[nnew++] = d; }
+	}
+	*ndistinct = nt;
+	{
+		int64_t at = 0;
+		for (int64_t t = 0; t < nt; t++) { first[distinct[t]] = at; at += cnt[distinct[t]]; }
+	}
+	/* the running fill position is kept in first[] itself and taken back afterwards */
+	for (int64_t j = 0; j < nsel; j++) {
+		const int64_t *ids = lpT + (size_t) sel[j] * nlive;
+		for (int k = 0; k < nlive; k++) holders[first[ids[k]]++] = sel[j];
+	}
+	for (int64_t t = 0; t < nt; t++) first[distinct[t]] -= cnt[distinct[t]];   /* back to the list starts */
+
+	{
+		int64_t used = 0, left = nsel;
+		int next_first = 0;
+		ngroups = 0;
+		offsets[0] = 0;
+		while (left > 0) {
+			while (!todo[next_first]) next_first++;
+			const int lead = next_first;
+			todo[lead] = 0; left--;
+			group_of[lead] = ngroups;
+			const int64_t begin = used;
+			if (used + nlive > cap) { ngroups = -2; goto done; }
+			for (int k = 0; k < nlive; k++) {
+				const int64_t p = lpT[(size_t) lead * nlive + k];
+				points[used++] = p;
+				known[p] = 1;
 			}
-			if (!nnew) continue;
-			int64_t nfresh = 0;
-			for (int m = 0; m < nnew; m++) {
-				const int64_t *ids = lpT + (size_t) fresh_members[m] * nlive;
-				for (int k = 0; k < nlive; k++)
-					if (!known[ids[k]]) { known[ids[k]] = 1; fresh[nfresh++] = ids[k]; }      /* each once */
+			for (int64_t i = begin; i < used && left > 0; i++) {
+				const int64_t p = points[i];
+				int64_t nnew = 0;
+				for (int64_t h = first[p]; h < first[p] + cnt[p]; h++) {
+					const int d = holders[h];
+					if (todo[d]) { todo[d] = 0; left--; group_of[d] = ngroups; sel[nnew++] = d; }
+				}
+				if (!nnew) continue;
+				int64_t nfresh = 0;
+				for (int64_t m = 0; m < nnew; m++) {
+					const int64_t *ids = lpT + (size_t) sel[m] * nlive;
+					for (int k = 0; k < nlive; k++)
+						if (!known[ids[k]]) { known[ids[k]] = 1; fresh[nfresh++] = ids[k]; }   /* each once */
+				}
+				if (nfresh > 1) qsort(fresh, (size_t) nfresh, sizeof(int64_t), cmp_i64);    /* ascending */
+				if (used + nfresh > cap) { ngroups = -2; goto done; }
+				memcpy(points + used, fresh, (size_t) nfresh * sizeof(int64_t));
+				used += nfresh;
 			}
-			if (nfresh > 1) qsort(fresh, (size_t) nfresh, sizeof(int64_t), cmp_i64);   /* ascending */
-			if (used + nfresh > cap) { ngroups = -2; goto done; }
-			memcpy(points + used, fresh, (size_t) nfresh * sizeof(int64_t));
-			used += nfresh;
+			offsets[++ngroups] = used;
 		}
-		for (int64_t i = begin; i < used; i++) known[points[i]] = 0;       /* next group starts clean */
-		offsets[++ngroups] = used;
 	}
 done:
-	free(start); free(known); free(todo); free(holders); free(fresh_members); free(fresh);
+	/* the work arrays go back zeroed (also after a failure) */
+	for (int64_t t = 0; t < nt; t++) { cnt[distinct[t]] = 0; known[distinct[t]] = 0; }
+	if (ngroups >= 0 && (sorted_distinct || nt < sort_below) && nt > 1)
+		qsort(distinct, (size_t) nt, sizeof(int64_t), cmp_i64);
+	free(todo); free(holders); free(sel); free(fresh);
 	return ngroups;
 }

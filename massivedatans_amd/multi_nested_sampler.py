@@ -45,9 +45,9 @@ def _host_lib():
             lib = ctypes.CDLL(path)
             lib.mdns_host_group_walk.restype = ctypes.c_int
             lib.mdns_host_group_walk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                 ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                                 ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                                 ctypes.c_void_p]
+                                                 ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
+                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]
             _HOST_LIB = lib
         except OSError:
             _HOST_LIB = False
@@ -299,6 +299,11 @@ class MultiNestedSampler(object):
                 self._label = numpy.zeros(max(2 * len(self._label), len(self.pointpile) + 1024), dtype=numpy.int64)
             self._label[self._alive] = numpy.arange(len(self._alive))
             self._lpT = numpy.ascontiguousarray(self._label[self.live_pointsp.T])
+            # per-id work arrays of the walk: it hands them back zeroed after every call
+            self._walk_work = (numpy.zeros(len(self._alive), dtype=numpy.int32),
+                               numpy.empty(len(self._alive), dtype=numpy.int64),
+                               numpy.zeros(len(self._alive), dtype=numpy.uint8),
+                               numpy.empty(len(self._alive), dtype=numpy.int64))
         lp = self._lpT
         alive = self._alive
         ndata, nlive = lp.shape
@@ -306,22 +311,26 @@ class MultiNestedSampler(object):
         mask8 = numpy.ascontiguousarray(data_mask, dtype=numpy.uint8)
         group_of = numpy.empty(ndata, dtype=numpy.int32)
         offsets = numpy.empty(ndata + 1, dtype=numpy.int64)
-        distinct = numpy.empty(npoints, dtype=numpy.int64)
+        cnt, first, known, distinct = self._walk_work
         ndistinct = ctypes.c_int64(0)
         cap = min(npoints, nsel * nlive) + nlive
+        want_sorted = 1 if len(self.superpoints) > 0 else 0
         while True:
             points = numpy.empty(cap, dtype=numpy.int64)
             n = lib.mdns_host_group_walk(lp.ctypes.data, nlive, ndata, mask8.ctypes.data, npoints,
+                                         cnt.ctypes.data, first.ctypes.data, known.ctypes.data,
                                          group_of.ctypes.data, points.ctypes.data, cap, offsets.ctypes.data,
-                                         distinct.ctypes.data, ctypes.byref(ndistinct))
+                                         distinct.ctypes.data, ctypes.byref(ndistinct), want_sorted,
+                                         2 * self.nlive_points)
             if n != -2:
                 break
             cap = nsel * nlive                        # columns with repeated ids: the safe bound
         if n < 0:
             raise MemoryError("mdns_host_group_walk")
-        allp = alive[distinct[:ndistinct.value]]      # labels ascend with the ids: still sorted
-        if len(allp) < 2 * self.nlive_points or len(self.superpoints) > 0:
-            yield data_mask, allp                     # some points are shared by all: one group
+        if ndistinct.value < 2 * self.nlive_points or len(self.superpoints) > 0:
+            # some points are shared by all: one group, ids ascending (the walk sorted them for
+            # exactly these two cases; labels ascend with the ids)
+            yield data_mask, alive[distinct[:ndistinct.value]]
         elif n == 1:
             yield data_mask.copy(), alive[points[:offsets[1]]]
         else:

@@ -155,6 +155,7 @@ def _fake_sampler(lp, npoints, nlive):
     s.ndata = lp.shape[1]
     s._lpT = None
     s._alive = None
+    s._walk_work = None
     s._label = np.zeros(16, dtype=np.int64)
     s._refcount = np.bincount(lp.ravel(), minlength=npoints)
     return s
