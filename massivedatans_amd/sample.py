@@ -139,10 +139,17 @@ def distributed_backend(x, y):
     import torch
     import torch.distributed as dist
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
+    # MDNS_DIST_BACKEND=gloo exchanges through host memory: lets several ranks share one GPU
+    # (RCCL wants one device per rank), e.g. to rehearse the N-rank path on a one-GPU box
+    backend = os.environ.get('MDNS_DIST_BACKEND', 'nccl')
+    device = local_rank % max(1, torch.cuda.device_count())
+    torch.cuda.set_device(device)
     if not dist.is_initialized():
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-    os.environ.setdefault('MDNS_DEVICE', str(local_rank))
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(backend=backend)
+    os.environ.setdefault('MDNS_DEVICE', str(device))
     from .like import GaussLineSpectra
     from .parallel import ShardedGaussLine
     return ShardedGaussLine(x, y, lambda xs, ys: GaussLineSpectra(xs, ys, noise_level=noise_level))
