@@ -48,6 +48,45 @@ __device__ __forceinline__ double wave_sum(double v)
 	return __hiloint2double(hi, lo);
 }
 
+// Several sums at once (gfx950): v_permlane32_swap / v_permlane16_swap exchange half-waves and
+// 16-lane rows between TWO registers, so one swap + one add halves two sums together instead of
+// one.  a' = swap32(a, b) gives  lanes 0-31: a_i + a_{i+32},  lanes 32-63: the same for b;
+// swap16 does it again on rows.  Two values cost 18 instructions instead of 36, four cost 21
+// instead of 72 (per wave, doubles: every move is two 32-bit moves).
+__device__ __forceinline__ double swap_add32(double a, double b)
+{
+	const auto lo = __builtin_amdgcn_permlane32_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
+	const auto hi = __builtin_amdgcn_permlane32_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
+	return __hiloint2double((int) hi[0], (int) lo[0]) + __hiloint2double((int) hi[1], (int) lo[1]);
+}
+__device__ __forceinline__ double swap_add16(double a, double b)
+{
+	const auto lo = __builtin_amdgcn_permlane16_swap((unsigned) __double2loint(a), (unsigned) __double2loint(b), false, false);
+	const auto hi = __builtin_amdgcn_permlane16_swap((unsigned) __double2hiint(a), (unsigned) __double2hiint(b), false, false);
+	return __hiloint2double((int) hi[0], (int) lo[0]) + __hiloint2double((int) hi[1], (int) lo[1]);
+}
+// sum inside every 16-lane row; the row total ends in its lanes 12-15
+__device__ __forceinline__ double row_sum(double v)
+{
+	v += dpp_move<0xb1, 0xf>(v);
+	v += dpp_move<0x4e, 0xf>(v);
+	v += dpp_move<0x114, 0xf>(v);
+	v += dpp_move<0x118, 0xf>(v);
+	return v;
+}
+// wave totals of a and b: a's in lane 31, b's in lane 63 of the returned register
+__device__ __forceinline__ double wave_sums2(double a, double b)
+{
+	double v = row_sum(swap_add32(a, b));         // rows 0,1: a   rows 2,3: b
+	v += dpp_move<0x142, 0xa>(v);                 // row_bcast:15 -> rows 1 and 3 take rows 0 and 2
+	return v;
+}
+// wave totals of a, b, c, d in lanes 15, 47, 31, 63 of the returned register
+__device__ __forceinline__ double wave_sums4(double a, double b, double c, double d)
+{
+	return row_sum(swap_add16(swap_add32(a, b), swap_add32(c, d)));   // rows: a, c, b, d
+}
+
 // ---------------------------------------------------------------------------------------
 // templates
 // ---------------------------------------------------------------------------------------
@@ -429,14 +468,26 @@ __device__ __forceinline__ double block_sum4(double v, double *slot /* [4] in LD
 
 // sums N values over the 256 threads with ONE barrier: wave shuffles, then 4 x N LDS words.
 // `slot` [4][N] must not be in use by a reduction that other waves may still be reading.
-template <int N>
+// SWAPS: use the permlane-swap reductions (k_muse_rows2<8> sits at the 256-VGPR limit: with
+// both of its reductions on swaps it ran 32 % slower, with only the four-value one 14 % faster)
+template <int N, bool SWAPS = true>
 __device__ __forceinline__ void block_sums(double (&v)[N], double *slot)
 {
 	const int wv = threadIdx.x >> 6;
+	const int lane = threadIdx.x & 63;
+	if constexpr (N == 4 && SWAPS) {
+		const double t = wave_sums4(v[0], v[1], v[2], v[3]);
+		// lanes 15, 31, 47, 63 hold the totals of v[0], v[2], v[1], v[3]
+		if ((lane & 15) == 15) slot[wv * 4 + ((lane >> 5) | ((lane >> 3) & 2))] = t;
+	} else if constexpr (N == 2 && SWAPS) {
+		const double t = wave_sums2(v[0], v[1]);
+		if ((lane & 31) == 31) slot[wv * 2 + (lane >> 5)] = t;
+	} else {
 #pragma unroll
-	for (int i = 0; i < N; i++) {
-		const double t = wave_sum(v[i]);
-		if ((threadIdx.x & 63) == 0) slot[wv * N + i] = t;
+		for (int i = 0; i < N; i++) {
+			const double t = wave_sum(v[i]);
+			if (lane == 0) slot[wv * N + i] = t;
+		}
 	}
 	__syncthreads();
 #pragma unroll
@@ -577,7 +628,7 @@ __global__ __launch_bounds__(kBlock) void k_muse_rows2(
 				}
 				chi[r] = acc;
 			}
-			block_sums<RB>(chi, redB);
+			block_sums<RB, false>(chi, redB);
 			if (threadIdx.x < RB && k0 + threadIdx.x < M)
 				out[(size_t) b * M + k0 + threadIdx.x] = -0.5 * (threadIdx.x == 0 ? chi[0] : chi[RB - 1]);
 		}
