@@ -301,7 +301,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 			}
 		}
 		__syncthreads();
-		for (int jn = slice; jn < n; jn += NSLICE) {
+		// one member: its squared distance offered to every round
+		auto offer = [&](int jn) {
 			double d;
 			if (D > 0) d = sq_distance_fixed<(D > 0 ? D : 1)>(tile + jn * D, c);
 			else d = sq_distance(members + (size_t) ii * ndim, tile + jn * ndim, ndim);
@@ -320,7 +321,15 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 					nearest[b] = min_or_skip(nearest[b], cand);
 				}
 			}
+		};
+		// two members per trip: the second one's LDS reads and distance overlap the first one's
+		// chain of minima (one wave per SIMD at the usual pool sizes: nothing else hides them)
+		int jn = slice;
+		for (; jn + NSLICE < n; jn += 2 * NSLICE) {
+			offer(jn);
+			offer(jn + NSLICE);
 		}
+		if (jn < n) offer(jn);
 	}
 	// min over the slices of this wave, then over the waves; finally the max over the
 	// contributing points: one atomic per wave and round
