@@ -445,7 +445,10 @@ static bool launch_nearest(const double *d_members, int K, int ndim, const doubl
                            int nboot, double *d_round_sq, const BootstrapFinish *finish)
 {
 	Context *c = ctx();
-	const size_t fixed = 4 * kRounds * 64 * sizeof(double);
+	const bool small = (K + 63) / 64 < 2 * c->num_cus;          // latency shape below ~32k points
+	// partial minima [4 waves][rounds carried][points per workgroup]: exactly what the kernel
+	// instantiation uses (the LDS a workgroup asks for bounds the workgroups per CU: 3 at 46 KB)
+	const size_t fixed = (size_t) 4 * (NN ? 1 : (nboot > 10 ? kRounds : 10)) * (small ? 16 : 64) * sizeof(double);
 	const int tile_n = pick_tile(ndim, sizeof(unsigned), fixed);
 	if (tile_n <= 0) { set_error("ndim=%d too large for the member tile", ndim); return false; }
 	const size_t lds = (size_t) tile_n * ndim * sizeof(double) + fixed + (size_t) tile_n * sizeof(unsigned);
@@ -454,7 +457,6 @@ static bool launch_nearest(const double *d_members, int K, int ndim, const doubl
 		d_mask = (unsigned *) mask_scratch((size_t) K * sizeof(unsigned));
 		if (!d_mask) return false;
 	}
-	const bool small = (K + 63) / 64 < 2 * c->num_cus;          // latency shape below ~32k points
 	// A finishing computation leaves its slots zeroed (see the kernel), so no launch has to
 	// clear them; small pools then also read the choice matrix directly: one launch in all.
 	const bool fused = !NN && finish && K <= 2048;
