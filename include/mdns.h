@@ -142,6 +142,10 @@ void mdns_region_destroy(mdns_region *r);
  * on the device.  Returns the radius and keeps it as the region's maxdistance; NaN on failure. */
 double mdns_region_bootstrap_radius(mdns_region *r, const double *chosen, int nbootstraps);
 double mdns_region_bootstrap_radius_dev(mdns_region *r, const double *d_chosen, int nbootstraps);
+/* The same with the choice matrix packed by the caller: bit b of packed[i] (uint32[K], host) is
+ * set when point i is chosen in round b, i.e. chosen[i][b] != 0 (cneighbors.c:146); at most 16
+ * rounds.  A twentieth of the bytes to build and to upload. */
+double mdns_region_bootstrap_radius_packed(mdns_region *r, const unsigned *packed, int nbootstraps);
 /* The same without waiting: radius and membership threshold are finished ON the device, so a
  * following mdns_region_count_dev needs no host round trip; mdns_region_radius() then waits
  * for and returns the value (the host needs it for the bounding box, radfriendsregion.py:69).

@@ -22,7 +22,7 @@ ABI_SYMBOLS = (
     "mdns_spectra_create", "mdns_spectra_destroy", "mdns_spectra_ndata", "mdns_spectra_nx",
     "mdns_gauss_loglike_batch", "mdns_muse_loglike_batch", "mdns_muse3_loglike_batch",
     "mdns_region_create", "mdns_region_wrap_dev", "mdns_region_destroy",
-    "mdns_region_bootstrap_radius", "mdns_region_bootstrap_radius_dev",
+    "mdns_region_bootstrap_radius", "mdns_region_bootstrap_radius_dev", "mdns_region_bootstrap_radius_packed",
     "mdns_region_bootstrap_radius_async", "mdns_region_set_radius",
     "mdns_region_radius", "mdns_region_count", "mdns_region_count_dev",
     "mdns_dev_alloc", "mdns_dev_free", "mdns_h2d", "mdns_d2h", "mdns_sync", "mdns_set_stream",
@@ -69,6 +69,7 @@ def _declare(lib):
         "mdns_region_destroy": (None, [vp]),
         "mdns_region_bootstrap_radius": (d, [vp, vp, i]),
         "mdns_region_bootstrap_radius_dev": (d, [vp, vp, i]),
+        "mdns_region_bootstrap_radius_packed": (d, [vp, vp, i]),
         "mdns_region_bootstrap_radius_async": (i, [vp, vp, i]),
         "mdns_region_set_radius": (i, [vp, d]),
         "mdns_region_radius": (d, [vp]),

@@ -77,6 +77,26 @@ def draw_bootstrap_choice(nsamples, nbootstraps):
     return chosen
 
 
+def draw_bootstrap_masks(nsamples, nbootstraps):
+    """The same choice as :func:`draw_bootstrap_choice`, from the same position of the RNG stream,
+    packed: bit b of ``masks[i]`` is set when point i is chosen in round b (uint32[nsamples],
+    nbootstraps <= 16).  Cheaper to build and to upload than the f64 matrix."""
+    if nbootstraps > 16:
+        raise ValueError("at most 16 rounds fit the packed form")
+    idx = numpy.random.randint(0, nsamples, size=(nbootstraps, nsamples))
+    masks = numpy.zeros(nsamples, dtype=numpy.uint32)
+    for b in range(nbootstraps):
+        hit = numpy.zeros(nsamples, dtype=numpy.uint32)
+        hit[idx[b]] = 1 << b
+        masks |= hit
+    return masks
+
+
+def unpack_bootstrap_masks(masks, nbootstraps):
+    """masks -> the reference's f64[nsamples, nbootstraps] matrix."""
+    return ((masks[:, None] >> numpy.arange(nbootstraps, dtype=numpy.uint32)[None, :]) & 1).astype(float)
+
+
 def bootstrapped_maxdistance_chosen(xx, chosen):
     """K6 for a given chosen matrix (cneighbors.c:125-179)."""
     xx = _pts(xx, "xx")
@@ -130,6 +150,16 @@ class MemberSet(object):
         r = self._lib.mdns_region_bootstrap_radius(self._h, _lib.ptr(chosen), chosen.shape[1])
         if r != r:
             raise _lib.MdnsError("mdns_region_bootstrap_radius failed: " + _lib.last_error())
+        return r
+
+    def bootstrap_radius_packed(self, masks, nbootstraps):
+        """K6 for a packed choice (:func:`draw_bootstrap_masks`)."""
+        masks = numpy.ascontiguousarray(masks, dtype=numpy.uint32)
+        if masks.shape != (self.nmembers,):
+            raise ValueError("masks must be uint32[nmembers]")
+        r = self._lib.mdns_region_bootstrap_radius_packed(self._h, _lib.ptr(masks), int(nbootstraps))
+        if r != r:
+            raise _lib.MdnsError("mdns_region_bootstrap_radius_packed failed: " + _lib.last_error())
         return r
 
     def set_radius(self, maxdistance):

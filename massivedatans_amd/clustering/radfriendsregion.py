@@ -27,8 +27,12 @@ class RadFriendsRegion(object):
         if maxdistance is None:
             # bootstrapped safe radius (radfriendsregion.py:62-64 -> neighbors.py:170-177):
             # nbootstraps numpy.random.choice calls on the global stream, then K6
-            chosen = neighbors.draw_bootstrap_choice(len(members), nbootstraps)
-            maxdistance = self._set.bootstrap_radius(chosen)
+            if nbootstraps <= 16:
+                masks = neighbors.draw_bootstrap_masks(len(members), nbootstraps)
+                maxdistance = self._set.bootstrap_radius_packed(masks, nbootstraps)
+            else:
+                chosen = neighbors.draw_bootstrap_choice(len(members), nbootstraps)
+                maxdistance = self._set.bootstrap_radius(chosen)
         else:
             self._set.set_radius(maxdistance)
         self.maxdistance = maxdistance

@@ -1041,6 +1041,22 @@ extern "C" double mdns_region_bootstrap_radius(mdns_region *r, const double *cho
 	return mdns_region_bootstrap_radius_dev(r, (const double *) r->d_chosen, nbootstraps);
 }
 
+extern "C" double mdns_region_bootstrap_radius_packed(mdns_region *r, const unsigned *packed, int nbootstraps)
+{
+	Context *c = ctx();
+	if (!c || !r) return NAN;
+	if (nbootstraps <= 0 || nbootstraps > 16 || !packed) { set_error("mdns_region_bootstrap_radius_packed: nbootstraps=%d (1..16)", nbootstraps); return NAN; }
+	if (!region_fetch(r)) return NAN;
+	const size_t bytes = (size_t) r->K * sizeof(unsigned);
+	if (!pool_fit(&r->d_chosen, &r->chosen_bytes, bytes)) return NAN;
+	if (!MDNS_HIP(hipMemcpyAsync(r->d_chosen, packed, bytes, hipMemcpyHostToDevice, c->stream))) return NAN;
+	const BootstrapFinish fin = {r->d_counter, r->d_res, r->h_res_dev, ++r->seq};
+	if (!launch_bootstrap_packed(r->d_members, r->K, r->ndim, (const unsigned *) r->d_chosen, nbootstraps, r->d_round, &fin)) return NAN;
+	r->on_device = true;
+	r->pending = true;
+	return mdns_region_radius(r);
+}
+
 extern "C" int mdns_region_count_dev(mdns_region *r, const double *d_points, int M, int *d_counts)
 {
 	if (!ctx() || !r) return 1;

@@ -110,6 +110,9 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
                          const RegionResult *d_res, const double *d_cands, int M, int *d_counts);
 bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_chosen,
                       int nbootstraps, double *d_round_sq, const BootstrapFinish *finish = nullptr);
+// the same with the choice already packed: bit b of d_packed[i] = point i is chosen in round b
+bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const unsigned *d_packed,
+                             int nbootstraps, double *d_round_sq, const BootstrapFinish *finish);
 bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out);
 
 // optional per-launch event timing (mdns_profile); which: 0 gauss rows, 1 muse rows,

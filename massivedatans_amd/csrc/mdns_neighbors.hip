@@ -440,9 +440,12 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	return launched("k_count_within");
 }
 
+// d_packed != nullptr: the caller already holds the choice as one bit per round and point
+// (nboot <= kRounds, finishing computation: its slots are zero), so nothing has to be packed.
 template <bool NN>
 static bool launch_nearest(const double *d_members, int K, int ndim, const double *d_chosen,
-                           int nboot, double *d_round_sq, const BootstrapFinish *finish)
+                           int nboot, double *d_round_sq, const BootstrapFinish *finish,
+                           const unsigned *d_packed = nullptr)
 {
 	Context *c = ctx();
 	const bool small = (K + 63) / 64 < 2 * c->num_cus;          // latency shape below ~32k points
@@ -452,19 +455,19 @@ static bool launch_nearest(const double *d_members, int K, int ndim, const doubl
 	const int tile_n = pick_tile(ndim, sizeof(unsigned), fixed);
 	if (tile_n <= 0) { set_error("ndim=%d too large for the member tile", ndim); return false; }
 	const size_t lds = (size_t) tile_n * ndim * sizeof(double) + fixed + (size_t) tile_n * sizeof(unsigned);
-	unsigned *d_mask = nullptr;
-	if (!NN) {
+	unsigned *d_mask = const_cast<unsigned *>(d_packed);
+	if (!NN && !d_packed) {
 		d_mask = (unsigned *) mask_scratch((size_t) K * sizeof(unsigned));
 		if (!d_mask) return false;
 	}
 	// A finishing computation leaves its slots zeroed (see the kernel), so no launch has to
 	// clear them; small pools then also read the choice matrix directly: one launch in all.
-	const bool fused = !NN && finish && K <= 2048;
+	const bool fused = !NN && finish && K <= 2048 && !d_packed;
 	const int pts = small ? 16 : 64;
 	dim3 grid((K + pts - 1) / pts);
 	for (int b0 = 0; b0 < nboot; b0 += kRounds) {
 		const int nb = nboot - b0 < kRounds ? nboot - b0 : kRounds;
-		if (!NN && !fused) {
+		if (!NN && !fused && !d_packed) {
 			const int nthreads = K > nb ? K : nb;
 			hipLaunchKernelGGL(k_pack_chosen, dim3((nthreads + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
 			                   d_chosen, K, nboot, b0, nb, d_mask, d_round_sq);
@@ -491,6 +494,13 @@ bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_
                       int nbootstraps, double *d_round_sq, const BootstrapFinish *finish)
 {
 	return launch_nearest<false>(d_members, K, ndim, d_chosen, nbootstraps, d_round_sq, finish);
+}
+
+bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const unsigned *d_packed,
+                             int nbootstraps, double *d_round_sq, const BootstrapFinish *finish)
+{
+	if (nbootstraps > kRounds || !finish) { set_error("packed bootstrap: at most %d rounds, finishing only", kRounds); return false; }
+	return launch_nearest<false>(d_members, K, ndim, nullptr, nbootstraps, d_round_sq, finish, d_packed);
 }
 
 bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out)

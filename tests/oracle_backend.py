@@ -49,6 +49,9 @@ def patch_neighbors(monkeypatch, oracle):
             self.radius = boot(self.members, chosen)
             return self.radius
 
+        def bootstrap_radius_packed(self, masks, nbootstraps):
+            return self.bootstrap_radius(neighbors.unpack_bootstrap_masks(np.asarray(masks), nbootstraps))
+
         def set_radius(self, r):
             self.radius = float(r)
 

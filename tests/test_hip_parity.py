@@ -580,3 +580,22 @@ def test_c5_share_size_properties():
             want = -0.5 * (((y - s * m) ** 2) / v).sum()
             assert abs(full[b, i] - want) <= 1e-10 * abs(want)
     sp.close()
+
+
+def test_packed_bootstrap_choice_gives_the_same_radius(nb, oracle):
+    """mdns_region_bootstrap_radius_packed (bit masks built by draw_bootstrap_masks) against the
+    f64 choice matrix of the reference's interface and the oracle: bit-exact radii, for pools on
+    both sides of the fused-kernel limit and several round counts."""
+    rng = np.random.RandomState(11)
+    for K, ndim, B in [(7, 2, 10), (100, 3, 10), (400, 3, 10), (1500, 3, 10), (3000, 5, 16), (2500, 3, 3)]:
+        pts = rng.uniform(size=(K, ndim))
+        np.random.seed(K + B)
+        masks = nb.draw_bootstrap_masks(K, B)
+        chosen = nb.unpack_bootstrap_masks(masks, B)
+        want = oracle.bootstrapped_maxdistance(np.ascontiguousarray(pts), np.ascontiguousarray(chosen))
+        s = nb.MemberSet(pts)
+        assert s.bootstrap_radius_packed(masks, B) == want
+        assert s.bootstrap_radius(chosen) == want
+        far = pts[:5] + want * 0.999 / np.sqrt(ndim)
+        assert np.array_equal(s.count(far), oracle.count_within_distance_of(np.ascontiguousarray(pts), want, np.ascontiguousarray(far)))
+        s.close()

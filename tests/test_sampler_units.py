@@ -203,7 +203,7 @@ def test_native_grouping_walk_equals_python_walk():
 def test_bootstrap_choice_consumes_the_rng_like_the_reference():
     """draw_bootstrap_choice against the reference's spelled-out loop (neighbors.py:170-174):
     same matrix, and the global legacy RNG stream left at the same position."""
-    from massivedatans_amd.clustering.neighbors import draw_bootstrap_choice
+    from massivedatans_amd.clustering.neighbors import draw_bootstrap_choice, draw_bootstrap_masks, unpack_bootstrap_masks
     for n in list(range(1, 60)) + [100, 257, 400, 3000]:
         for B in (1, 10, 15):
             np.random.seed(n * 31 + B)
@@ -214,3 +214,7 @@ def test_bootstrap_choice_consumes_the_rng_like_the_reference():
             np.random.seed(n * 31 + B)
             got = draw_bootstrap_choice(n, B)
             assert np.array_equal(got, want) and np.random.uniform() == after_want
+            np.random.seed(n * 31 + B)
+            masks = draw_bootstrap_masks(n, B)
+            assert np.random.uniform() == after_want
+            assert np.array_equal(unpack_bootstrap_masks(masks, B), want)
