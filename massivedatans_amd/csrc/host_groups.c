@@ -14,6 +14,7 @@
  * per-id work arrays belong to the caller, arrive zeroed and are handed back zeroed (only the
  * entries of the ids the selection holds are touched). */
 #include <stdint.h>
+#include <limits.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -21,6 +22,27 @@ static int cmp_i64(const void *a, const void *b)
 {
 	const int64_t x = *(const int64_t *) a, y = *(const int64_t *) b;
 	return (x > y) - (x < y);
+}
+
+/* ascending sort of n non-negative ids; `tmp` has room for n.  Byte-wise counting sort over as
+ * many bytes as the largest id needs (the big batches -- a component's first point can bring in
+ * a thousand data sets with 10^5 new ids -- made qsort the most expensive part of the walk). */
+static void sort_ids(int64_t *v, int64_t n, int64_t *tmp)
+{
+	if (n < 2) return;
+	if (n < 192) { qsort(v, (size_t) n, sizeof(int64_t), cmp_i64); return; }
+	int64_t top = 0;
+	for (int64_t i = 0; i < n; i++) if (v[i] > top) top = v[i];
+	int64_t *src = v, *dst = tmp;
+	for (int shift = 0; shift < 64 && (top >> shift) != 0; shift += 8) {
+		int64_t count[257];
+		memset(count, 0, sizeof count);
+		for (int64_t i = 0; i < n; i++) count[((src[i] >> shift) & 255) + 1]++;
+		for (int b = 0; b < 256; b++) count[b + 1] += count[b];
+		for (int64_t i = 0; i < n; i++) dst[count[(src[i] >> shift) & 255]++] = src[i];
+		int64_t *t = src; src = dst; dst = t;
+	}
+	if (src != v) memcpy(v, src, (size_t) n * sizeof(int64_t));
 }
 
 /* lpT       int64[ndata][nlive]   live-point ids, one ROW per data set (the transpose of the
@@ -46,7 +68,7 @@ int mdns_host_group_walk(const int64_t *lpT, int nlive, int ndata, const uint8_t
 	(void) npoints;
 	uint8_t *todo = (uint8_t *) malloc((size_t) ndata);
 	int32_t *holders = NULL, *sel = NULL;
-	int64_t *fresh = NULL;
+	int64_t *fresh = NULL, *sort_tmp = NULL;
 	int ngroups = -1;
 	int64_t nt = 0;                                   /* ids touched = distinct ids */
 	if (!todo) goto done;
@@ -55,7 +77,8 @@ int mdns_host_group_walk(const int64_t *lpT, int nlive, int ndata, const uint8_t
 	sel = (int32_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * sizeof(int32_t));
 	holders = (int32_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * nlive * sizeof(int32_t));
 	fresh = (int64_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * nlive * sizeof(int64_t));
-	if (!sel || !holders || !fresh) goto done;
+	sort_tmp = (int64_t *) malloc((size_t) (nsel > 0 ? nsel : 1) * nlive * sizeof(int64_t));
+	if (!sel || !holders || !fresh || !sort_tmp) goto done;
 	{
 		int64_t j = 0;
 		for (int d = 0; d < ndata; d++) if (todo[d]) sel[j++] = d;               /* ascending */
@@ -68,16 +91,22 @@ int mdns_host_group_walk(const int64_t *lpT, int nlive, int ndata, const uint8_t
 		}
 	}
 	*ndistinct = nt;
+	/* An id with a single holder in the selection can never bring anybody in (its holder is the
+	 * data set that listed it): late in a run that is nine ids in ten.  Only shared ids get a
+	 * holder list. */
 	{
 		int64_t at = 0;
-		for (int64_t t = 0; t < nt; t++) { first[distinct[t]] = at; at += cnt[distinct[t]]; }
+		for (int64_t t = 0; t < nt; t++)
+			if (cnt[distinct[t]] >= 2) { first[distinct[t]] = at; at += cnt[distinct[t]]; }
 	}
 	/* the running fill position is kept in first[] itself and taken back afterwards */
 	for (int64_t j = 0; j < nsel; j++) {
 		const int64_t *ids = lpT + (size_t) sel[j] * nlive;
-		for (int k = 0; k < nlive; k++) holders[first[ids[k]]++] = sel[j];
+		for (int k = 0; k < nlive; k++)
+			if (cnt[ids[k]] >= 2) holders[first[ids[k]]++] = sel[j];
 	}
-	for (int64_t t = 0; t < nt; t++) first[distinct[t]] -= cnt[distinct[t]];   /* back to the list starts */
+	for (int64_t t = 0; t < nt; t++)
+		if (cnt[distinct[t]] >= 2) first[distinct[t]] -= cnt[distinct[t]];      /* back to the list starts */
 
 	{
 		int64_t used = 0, left = nsel;
@@ -98,19 +127,33 @@ int mdns_host_group_walk(const int64_t *lpT, int nlive, int ndata, const uint8_t
 			}
 			for (int64_t i = begin; i < used && left > 0; i++) {
 				const int64_t p = points[i];
+				if (cnt[p] < 2) continue;
 				int64_t nnew = 0;
 				for (int64_t h = first[p]; h < first[p] + cnt[p]; h++) {
 					const int d = holders[h];
 					if (todo[d]) { todo[d] = 0; left--; group_of[d] = ngroups; sel[nnew++] = d; }
 				}
 				if (!nnew) continue;
-				int64_t nfresh = 0;
+				int64_t nfresh = 0, lo = INT64_MAX, hi = -1;
 				for (int64_t m = 0; m < nnew; m++) {
 					const int64_t *ids = lpT + (size_t) sel[m] * nlive;
-					for (int k = 0; k < nlive; k++)
-						if (!known[ids[k]]) { known[ids[k]] = 1; fresh[nfresh++] = ids[k]; }   /* each once */
+					for (int k = 0; k < nlive; k++) {
+						const int64_t q = ids[k];
+						if (!known[q]) {                                                        /* each once */
+							known[q] = 2; fresh[nfresh++] = q;
+							if (q < lo) lo = q;
+							if (q > hi) hi = q;
+						}
+					}
 				}
-				if (nfresh > 1) qsort(fresh, (size_t) nfresh, sizeof(int64_t), cmp_i64);    /* ascending */
+				/* ascending: a dense batch is read off the marks in id order, a sparse one is sorted */
+				if (nfresh >= 192 && hi - lo < 24 * nfresh) {
+					int64_t n = 0;
+					for (int64_t q = lo; q <= hi; q++) if (known[q] == 2) { known[q] = 1; fresh[n++] = q; }
+				} else {
+					for (int64_t f = 0; f < nfresh; f++) known[fresh[f]] = 1;
+					sort_ids(fresh, nfresh, sort_tmp);
+				}
 				if (used + nfresh > cap) { ngroups = -2; goto done; }
 				memcpy(points + used, fresh, (size_t) nfresh * sizeof(int64_t));
 				used += nfresh;
@@ -121,8 +164,8 @@ int mdns_host_group_walk(const int64_t *lpT, int nlive, int ndata, const uint8_t
 done:
 	/* the work arrays go back zeroed (also after a failure) */
 	for (int64_t t = 0; t < nt; t++) { cnt[distinct[t]] = 0; known[distinct[t]] = 0; }
-	if (ngroups >= 0 && (sorted_distinct || nt < sort_below) && nt > 1)
-		qsort(distinct, (size_t) nt, sizeof(int64_t), cmp_i64);
-	free(todo); free(holders); free(sel); free(fresh);
+	if (ngroups >= 0 && (sorted_distinct || nt < sort_below) && nt > 1 && sort_tmp)
+		sort_ids(distinct, nt, sort_tmp);
+	free(todo); free(holders); free(sel); free(fresh); free(sort_tmp);
 	return ngroups;
 }
