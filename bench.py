@@ -155,11 +155,15 @@ def main():
         # becomes the one runtime of the process, which libmdns_hip.so then binds to as well
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        # one visible device per rank (HIP_VISIBLE_DEVICES set by a launcher) or all of them
+        device_index = local_rank % max(1, torch.cuda.device_count())
+        torch.cuda.set_device(device_index)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+    else:
+        device_index = local_rank
 
     from massivedatans_amd import _lib, gen
-    os.environ.setdefault("MDNS_DEVICE", str(local_rank))
+    os.environ.setdefault("MDNS_DEVICE", str(device_index))
     lib = _lib.require_device()
     if use_dist:
         # The kernels go on torch's CURRENT stream, which the (synchronous-API) RCCL collective
