@@ -71,3 +71,13 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".c", ".cpp")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in text and "oracle." not in text and "import oracle" not in text, f
+
+
+def test_host_helper_library_is_built_and_used(built):
+    """libmdns_host.so (the native grouping walk) is built by the same Makefile and picked up
+    by the sampler -- the trace tests must exercise the native code, not its Python fallback."""
+    from massivedatans_amd import multi_nested_sampler as mns
+    path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmdns_host.so")
+    assert os.path.exists(path), "run make -C massivedatans_amd/csrc"
+    assert hasattr(C.CDLL(path), "mdns_host_group_walk")
+    assert mns._host_lib() is not None
