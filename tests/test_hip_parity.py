@@ -622,3 +622,30 @@ def test_c2_size_bookkeeping_matches_the_cpu_path(kind, cap):
     got = hashlib.sha256(np.ascontiguousarray(sampler.pointpile, dtype=np.float64).tobytes()).hexdigest()
     assert got == want["pointpile_sha256"]
     assert np.max(np.abs(results["logZ"][:5] - np.array(want["logZ_first5"]))) < 1e-9
+
+
+def test_full_c3_run_matches_the_cpu_path():
+    """BASELINE.json configs[2] (10 000 no-signal spectra, 100 live points) TO TERMINATION on the
+    GPU against the same complete run on the CPU oracle backends (tests/golden/full_c3.npz from
+    oracle/make_full_c3.py): same iterations and draws, the pile of accepted points byte for
+    byte, and the evidences of all 10 000 data sets within 1e-9 (relative bar of BASELINE.json:
+    1e-6)."""
+    import hashlib
+    from massivedatans_amd import sample
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "full_c3.npz")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated (oracle/make_full_c3.py)")
+    with np.load(path) as f:
+        want = {k: f[k] for k in f.files}
+    data = gen.nothing(10000)
+    with np.errstate(all="ignore"):
+        results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=0, use_graph=False)
+    assert results["nsamples"] == int(want["iterations"])
+    assert sampler.ndraws == int(want["ndraws"])
+    assert len(sampler.pointpile) == int(want["npoints"])
+    got = hashlib.sha256(np.ascontiguousarray(sampler.pointpile, dtype=np.float64).tobytes()).hexdigest()
+    assert got == str(want["pointpile_sha256"])
+    assert np.max(np.abs(results["logZ"] - want["logZ"])) < 1e-9
+    assert np.max(np.abs(results["logZ"] - want["logZ"]) / np.abs(want["logZ"])) < 1e-6
+    assert np.allclose(results["logZerr"], want["logZerr"], rtol=1e-6, atol=1e-9)
