@@ -1,12 +1,13 @@
 #!/usr/bin/env python3
-"""BASELINE.json configs[2] (gennothing, 10 000 spectra, 100 live points) run TO TERMINATION by our
-host orchestration on the CPU oracle backends: evidences of all data sets, draw count and a
-SHA-256 of the pile of accepted points.  About 2.5 minutes on 8 cores.  The pair orchestration +
+"""BASELINE.json configs[2] (gennothing) or configs[1] (horns), 10 000 spectra and 100 live points,
+run TO TERMINATION by our host orchestration on the CPU oracle backends: evidences of all data
+sets, draw count and a SHA-256 of the pile of accepted points.  gennothing: 2.5 minutes on 8
+cores; horns: hours (its regions hold thousands of points for several hundred iterations).  The pair orchestration +
 oracle is pinned bit for bit against the reference on the small traces; this fixture lets the GPU
 path be compared with it over a complete run at full size.  Test infrastructure: writes
-tests/golden/full_c3.npz.
+tests/golden/full_c3.npz (nothing) or full_c2.npz (horns).
 
-    python oracle/make_full_c3.py
+    python oracle/make_full_run.py [nothing|horns]
 """
 import hashlib
 import os
@@ -32,14 +33,15 @@ class _Patch(object):
 def main():
     o = Oracle(kind="port-omp")
     oracle_backend.patch_neighbors(_Patch(), o)
-    data = gen.nothing(10000)
+    kind = sys.argv[1] if len(sys.argv) > 1 else "nothing"
+    data = (gen.nothing if kind == "nothing" else gen.horns)(10000)
     backend = oracle_backend.OracleSpectra(o, data["x"], data["y"])
     t = time.time()
     with np.errstate(all="ignore"):
         results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=0,
                                             use_graph=False, backend=backend)
     digest = hashlib.sha256(np.ascontiguousarray(sampler.pointpile, dtype=np.float64).tobytes()).hexdigest()
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "full_c3.npz"),
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "full_c3.npz" if kind == "nothing" else "full_c2.npz"),
                         logZ=results["logZ"], logZerr=results["logZerr"], ndraws=sampler.ndraws,
                         npoints=len(sampler.pointpile), iterations=results["nsamples"],
                         pointpile_sha256=np.array(digest))

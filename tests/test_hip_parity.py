@@ -627,7 +627,7 @@ def test_c2_size_bookkeeping_matches_the_cpu_path(kind, cap):
 def test_full_c3_run_matches_the_cpu_path():
     """BASELINE.json configs[2] (10 000 no-signal spectra, 100 live points) TO TERMINATION on the
     GPU against the same complete run on the CPU oracle backends (tests/golden/full_c3.npz from
-    oracle/make_full_c3.py): same iterations and draws, the pile of accepted points byte for
+    oracle/make_full_run.py): same iterations and draws, the pile of accepted points byte for
     byte, and the evidences of all 10 000 data sets within 1e-9 (relative bar of BASELINE.json:
     1e-6)."""
     import hashlib
@@ -635,7 +635,7 @@ def test_full_c3_run_matches_the_cpu_path():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "tests", "golden", "full_c3.npz")
     if not os.path.exists(path):
-        pytest.skip("fixture not generated (oracle/make_full_c3.py)")
+        pytest.skip("fixture not generated (oracle/make_full_run.py)")
     with np.load(path) as f:
         want = {k: f[k] for k in f.files}
     data = gen.nothing(10000)
