@@ -624,21 +624,25 @@ def test_c2_size_bookkeeping_matches_the_cpu_path(kind, cap):
     assert np.max(np.abs(results["logZ"][:5] - np.array(want["logZ_first5"]))) < 1e-9
 
 
-def test_full_c3_run_matches_the_cpu_path():
-    """BASELINE.json configs[2] (10 000 no-signal spectra, 100 live points) TO TERMINATION on the
-    GPU against the same complete run on the CPU oracle backends (tests/golden/full_c3.npz from
-    oracle/make_full_run.py): same iterations and draws, the pile of accepted points byte for
-    byte, and the evidences of all 10 000 data sets within 1e-9 (relative bar of BASELINE.json:
-    1e-6)."""
+@pytest.mark.parametrize("kind", ["nothing", "horns"])
+def test_full_run_matches_the_cpu_path(kind):
+    """BASELINE.json configs[2] (10 000 no-signal spectra) / configs[1] (horns), 100 live points,
+    TO TERMINATION on the GPU against the same complete run on the CPU oracle backends
+    (tests/golden/full_c3.npz / full_c2.npz from oracle/make_full_run.py): same iterations and
+    draws, the pile of accepted points byte for byte, and the evidences of all 10 000 data sets
+    within 1e-9 (relative bar of BASELINE.json: 1e-6).  The horns run takes 3.5 minutes on the
+    GPU (hours on the CPU) and only runs with MDNS_LONG_TESTS=1."""
     import hashlib
     from massivedatans_amd import sample
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "tests", "golden", "full_c3.npz")
+    path = os.path.join(root, "tests", "golden", "full_c3.npz" if kind == "nothing" else "full_c2.npz")
     if not os.path.exists(path):
-        pytest.skip("fixture not generated (oracle/make_full_run.py)")
+        pytest.skip("fixture not generated (oracle/make_full_run.py %s)" % kind)
+    if kind == "horns" and os.environ.get("MDNS_LONG_TESTS") != "1":
+        pytest.skip("3.5 minutes: set MDNS_LONG_TESTS=1")
     with np.load(path) as f:
         want = {k: f[k] for k in f.files}
-    data = gen.nothing(10000)
+    data = (gen.nothing if kind == "nothing" else gen.horns)(10000)
     with np.errstate(all="ignore"):
         results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=0, use_graph=False)
     assert results["nsamples"] == int(want["iterations"])
