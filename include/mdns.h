@@ -160,6 +160,74 @@ int mdns_region_count(mdns_region *r, const double *points, int M, int *counts);
 int mdns_region_count_dev(mdns_region *r, const double *d_points, int M, int *d_counts);
 
 /* ------------------------------------------------------------------------------------ */
+/* Part 2b: the constrained draw decided on the device (extension) */
+/* ------------------------------------------------------------------------------------ */
+
+/*
+ * The floating-point state of the joint sampler, resident in HBM: what the reference keeps in
+ * `live_pointsL[nlive, ndata]` (multi_nested_sampler.py:111) and in the likelihoods of its
+ * shelves (`self.shelves`, :117), plus what it derives from them on every draw -- the
+ * thresholds `Lmins_higher` (:438-447: for a data set with n accepted points waiting, the
+ * (n+1)-th smallest of its live and shelf likelihoods).  Everything is indexed by the ORIGINAL
+ * data-set index of the spectra handle, also after data sets have finished (`cut_down`, :148-173).
+ * The integer side (point ids, shelves' ids, data-set graph) stays with the host.
+ */
+typedef struct mdns_joint mdns_joint;
+
+/* shelf_cap: accepted points a data set can hold waiting (grown on demand, see mdns_joint_reserve). */
+mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_cap);
+void mdns_joint_destroy(mdns_joint *j);
+
+/* Initial live points (multi_nested_sampler.py:88-103): scores params f64[nlive,3] = (A, mu, sig)
+ * against ALL spectra and keeps the result as the live likelihood matrix; nothing is returned
+ * (mdns_joint_get_live reads it back).  All data sets are running, all shelves empty. */
+int mdns_joint_init_gauss(mdns_joint *j, const double *params, double noise_level);
+/* The same from a host matrix liveL f64[nlive, ndata] (row p = live slot p). */
+int mdns_joint_set_live(mdns_joint *j, const double *liveL);
+/* liveL f64[nlive, ndata] <- the device matrix (the integrator's remainder, :536-563). */
+int mdns_joint_get_live(mdns_joint *j, double *liveL);
+
+/* The data sets still running (multi_nested_sampler.py:148-173): rows int32[nrun], ascending
+ * original indices.  prepare/advance work on exactly these, in this order. */
+int mdns_joint_set_running(mdns_joint *j, const int *rows, int nrun);
+
+/* Start of an iteration (multi_nested_sampler.py:130-143 `prepare`): per running data set the
+ * lowest live likelihood Lmin f64[nrun] and its live slot argmin int32[nrun] (first occurrence,
+ * as numpy.argmin); shelf entries that no longer beat Lmin are dropped in order (:137-138) --
+ * keep uint64[nrun * ceil(cap/64)] gets, per data set, bit k of word k/64 set when its entry k
+ * stays (words per data set: mdns_joint_keep_words); thresholds are refreshed. */
+int mdns_joint_prepare(mdns_joint *j, double *Lmin, int *argmin, unsigned long long *keep);
+int mdns_joint_keep_words(const mdns_joint *j);
+/* End of an iteration (multi_nested_sampler.py:494-534): every running data set gives up the
+ * live point found by the last prepare and takes the head of its shelf.  Fails when a running
+ * data set has an empty shelf. */
+int mdns_joint_advance(mdns_joint *j);
+/* Make room for shelves of at least `shelf_cap` entries (contents kept). */
+int mdns_joint_reserve(mdns_joint *j, int shelf_cap);
+int mdns_joint_shelf_cap(const mdns_joint *j);
+
+/*
+ * One chunk of a constrained draw (hiermetriclearn.py:181-196 + multi_nested_sampler.py:462-485):
+ * the B candidates params f64[B,3] (already proposed by the host, in order) are scored against
+ * the M selected spectra row_ids int32[M] (ascending original indices; NULL = all, M = ndata);
+ * candidate b is acceptable when it beats the threshold of at least one selected data set
+ * (`any(L > Lmins)`, hiermetriclearn.py:193).  *accepted = index of the FIRST acceptable
+ * candidate, or -1.  For that candidate only: Lrow f64[M] its likelihoods, fillbits
+ * uint64[ceil(M/64)] with bit k set when it beats the threshold of the k-th selected data set
+ * (multi_nested_sampler.py:482-485); those data sets' shelves receive it and their thresholds
+ * move up, all on the device.  Likelihoods of the other candidates never reach memory.
+ * B <= 1024.
+ */
+int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B, double noise_level,
+                          const int *row_ids, int M, int *accepted, double *Lrow,
+                          unsigned long long *fillbits);
+#define MDNS_JOINT_MAX_BATCH 1024
+
+/* Current thresholds of all data sets, higher f64[ndata] (tests; NaN before the first prepare),
+ * and the shelf sizes n int32[ndata]. */
+int mdns_joint_get_thresholds(mdns_joint *j, double *higher, int *shelf_n);
+
+/* ------------------------------------------------------------------------------------ */
 /* Part 3: raw device entry points (all pointers are DEVICE pointers; asynchronous on the */
 /* library stream; no host synchronisation)                                             */
 /* ------------------------------------------------------------------------------------ */
@@ -203,6 +271,28 @@ int mdns_muse_loglike_batch_dev(mdns_spectra *s, const double *d_ypred, int B,
                                 const int *d_row_ids, int M, double *d_Lout);
 int mdns_muse3_loglike_batch_dev(mdns_spectra *s, const double *d_params, int B,
                                  const int *d_row_ids, int M, double *d_Lout);
+
+/* The two halves of mdns_joint_draw_gauss on device pointers, nothing waits for the host:
+ * score leaves one accept flag per candidate in the handle (int32[MDNS_JOINT_MAX_BATCH], 1 =
+ * beats some selected data set of THIS handle's spectra; mdns_joint_flags_dev -- with the data
+ * sets sharded over ranks a MAX all-reduce of that buffer in place makes every rank see every
+ * rank's flags), commit takes the first flagged candidate and leaves, in the handle's result
+ * buffer (mdns_joint_result_dev; device memory, valid until the next score),
+ * {int32 accepted, int32 status (0 ok, 1 shelf overflow), 8 bytes unused} | fillbits
+ * uint64[ceil(M/64)] | Lrow f64[M]  (mdns_joint_result_bytes(M) bytes in all). */
+int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B, double noise_level,
+                         const int *d_row_ids, int M);
+int *mdns_joint_flags_dev(mdns_joint *j);
+int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M);
+const void *mdns_joint_result_dev(mdns_joint *j);
+size_t mdns_joint_result_bytes(int M);
+/* prepare / advance without the copies to the host (results stay in the handle);
+ * mdns_joint_restore_live_dev overwrites the live matrix from d_liveL f64[nlive, ndata] and
+ * empties the shelves (bench.py re-runs the same iteration). */
+int mdns_joint_prepare_dev(mdns_joint *j);
+int mdns_joint_advance_dev(mdns_joint *j);
+int mdns_joint_restore_live_dev(mdns_joint *j, const double *d_liveL);
+const double *mdns_joint_live_dev(mdns_joint *j);
 
 /* K3 on device: d_members f64[K,ndim], d_cands f64[M,ndim]; d_counts int32[M] is
  * OVERWRITTEN with the number of members strictly within maxdistance (no early stop). */

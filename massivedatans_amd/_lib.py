@@ -30,7 +30,16 @@ ABI_SYMBOLS = (
     "mdns_profile", "mdns_profile_every", "mdns_profile_read", "mdns_profile_kernel",
     "mdns_gauss_loglike_batch_dev", "mdns_muse_loglike_batch_dev", "mdns_muse3_loglike_batch_dev",
     "mdns_count_within_dev", "mdns_bootstrap_round_maxsq_dev",
+    "mdns_joint_create", "mdns_joint_destroy", "mdns_joint_init_gauss", "mdns_joint_set_live",
+    "mdns_joint_get_live", "mdns_joint_set_running", "mdns_joint_prepare", "mdns_joint_keep_words",
+    "mdns_joint_advance", "mdns_joint_reserve", "mdns_joint_shelf_cap", "mdns_joint_draw_gauss",
+    "mdns_joint_get_thresholds", "mdns_joint_score_dev", "mdns_joint_flags_dev", "mdns_joint_commit_dev",
+    "mdns_joint_result_dev", "mdns_joint_result_bytes", "mdns_joint_prepare_dev", "mdns_joint_advance_dev",
+    "mdns_joint_restore_live_dev", "mdns_joint_live_dev",
 )
+
+#: mdns.h MDNS_JOINT_MAX_BATCH
+JOINT_MAX_BATCH = 1024
 
 
 class MdnsError(RuntimeError):
@@ -94,6 +103,28 @@ def _declare(lib):
         "mdns_muse3_loglike_batch_dev": (i, [vp, vp, i, vp, i, vp]),
         "mdns_count_within_dev": (i, [vp, i, i, d, vp, i, vp]),
         "mdns_bootstrap_round_maxsq_dev": (i, [vp, i, i, vp, i, vp]),
+        "mdns_joint_create": (vp, [vp, i, i]),
+        "mdns_joint_destroy": (None, [vp]),
+        "mdns_joint_init_gauss": (i, [vp, vp, d]),
+        "mdns_joint_set_live": (i, [vp, vp]),
+        "mdns_joint_get_live": (i, [vp, vp]),
+        "mdns_joint_set_running": (i, [vp, vp, i]),
+        "mdns_joint_prepare": (i, [vp, vp, vp, vp]),
+        "mdns_joint_keep_words": (i, [vp]),
+        "mdns_joint_advance": (i, [vp]),
+        "mdns_joint_reserve": (i, [vp, i]),
+        "mdns_joint_shelf_cap": (i, [vp]),
+        "mdns_joint_draw_gauss": (i, [vp, vp, i, d, vp, i, vp, vp, vp]),
+        "mdns_joint_get_thresholds": (i, [vp, vp, vp]),
+        "mdns_joint_score_dev": (i, [vp, vp, i, d, vp, i]),
+        "mdns_joint_flags_dev": (vp, [vp]),
+        "mdns_joint_commit_dev": (i, [vp, vp, i]),
+        "mdns_joint_result_dev": (vp, [vp]),
+        "mdns_joint_result_bytes": (sz, [i]),
+        "mdns_joint_prepare_dev": (i, [vp]),
+        "mdns_joint_advance_dev": (i, [vp]),
+        "mdns_joint_restore_live_dev": (i, [vp, vp]),
+        "mdns_joint_live_dev": (vp, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -9,7 +9,7 @@ import ctypes as C
 
 import numpy
 
-from .. import _lib
+from .. import _host, _lib
 
 
 def _pts(a, name):
@@ -77,12 +77,18 @@ def draw_bootstrap_choice(nsamples, nbootstraps):
     return chosen
 
 
-def draw_bootstrap_masks(nsamples, nbootstraps):
+def draw_bootstrap_masks(nsamples, nbootstraps, native=True):
     """The same choice as :func:`draw_bootstrap_choice`, from the same position of the RNG stream,
     packed: bit b of ``masks[i]`` is set when point i is chosen in round b (uint32[nsamples],
     nbootstraps <= 16).  Cheaper to build and to upload than the f64 matrix."""
     if nbootstraps > 16:
         raise ValueError("at most 16 rounds fit the packed form")
+    # native: the same draws taken from numpy's own bit generator in C (csrc/host_rng.c); the
+    # lines below are the statement it is tested against (tests/test_sampler_units.py)
+    if native:
+        masks = _host.bootstrap_masks(nsamples, nbootstraps)
+        if masks is not None:
+            return masks
     idx = numpy.random.randint(0, nsamples, size=(nbootstraps, nsamples))
     masks = numpy.zeros(nsamples, dtype=numpy.uint32)
     for b in range(nbootstraps):

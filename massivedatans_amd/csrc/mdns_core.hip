@@ -427,6 +427,35 @@ static bool check_batch(const mdns_spectra *s, int B, int M, const char *who)
 	return true;
 }
 
+namespace mdns {
+bool ensure_model(mdns_spectra *s, size_t doubles) { return grow(&s->d_model, &s->model_cap, doubles); }
+bool ensure_selection(mdns_spectra *s, size_t doubles) { return grow(&s->d_sel, &s->sel_cap, doubles); }
+
+// K1 with the lane kernel whatever the shape (one lane per spectrum, channels summed in
+// ascending order): L[B, M] to d_Lout.  The likelihood of a (candidate, spectrum) pair computed
+// here does not depend on B, M or the tile shape.
+int gauss_loglike_cols_dev(mdns_spectra *s, const double *d_params, int B, double noise_level,
+                           const int *d_row_ids, int M, double *d_Lout)
+{
+	if (!s->d_yT) { set_error("the lane kernel needs the channel-major replica (spectra without variances)"); return 1; }
+	const double scale = -0.5 / (noise_level * noise_level);
+	const int bt = gauss_cols_tile(M, B);
+	if (!ensure_model(s, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
+	if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model)) return 1;
+	// A selection is first copied into a compact replica (coalesced row reads, one pass)
+	// when the lane kernel would otherwise gather its columns once per candidate tile:
+	// many tiles, or a sparse selection (measured: 1 000 of 10 000 spectra, B = 256: 59 us
+	// gathering in the kernel).
+	const bool sparse = (size_t) M * 8 < (size_t) s->ndata;
+	if (d_row_ids && (B >= 128 || sparse)) {
+		if (!ensure_selection(s, (size_t) ((M + 63) / 64) * 64 * cols_nx(s->nx))) return 1;
+		if (!launch_tile_columns(s->d_y, s->ld, M, s->nx, d_row_ids, s->d_sel)) return 1;
+		return launch_gauss_cols(s, s->d_sel, s->d_model, bt, B, scale, nullptr, M, d_Lout) ? 0 : 1;
+	}
+	return launch_gauss_cols(s, s->d_yT, s->d_model, bt, B, scale, d_row_ids, M, d_Lout) ? 0 : 1;
+}
+}  // namespace mdns
+
 extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_params, int B,
                                             double noise_level, const int *d_row_ids, int M,
                                             double *d_Lout)
@@ -451,23 +480,7 @@ extern "C" int mdns_gauss_loglike_batch_dev(mdns_spectra *s, const double *d_par
 	bool use_cols = s->d_yT && ((dense && B >= 2 && (long long) M * B >= 150000) || B >= 32);
 	if (forced && !strcmp(forced, "rows")) use_cols = false;
 	if (forced && !strcmp(forced, "cols") && s->d_yT) use_cols = true;
-	if (use_cols) {
-		const int bt = gauss_cols_tile(M, B);
-		if (!grow(&s->d_model, &s->model_cap, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
-		if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model)) return 1;
-		// A selection is first copied into a compact replica (coalesced row reads, one pass)
-		// when the lane kernel would otherwise gather its columns once per candidate tile:
-		// many tiles, or a sparse selection (measured: 1 000 of 10 000 spectra, B = 256: 59 us
-		// gathering in the kernel).
-		const bool sparse = (size_t) M * 8 < (size_t) s->ndata;
-		if (d_row_ids && (B >= 128 || sparse)) {
-			const size_t need = (size_t) ((M + 63) / 64) * 64 * cols_nx(s->nx);
-			if (!grow(&s->d_sel, &s->sel_cap, need)) return 1;
-			if (!launch_tile_columns(s->d_y, s->ld, M, s->nx, d_row_ids, s->d_sel)) return 1;
-			return launch_gauss_cols(s, s->d_sel, s->d_model, bt, B, scale, nullptr, M, d_Lout) ? 0 : 1;
-		}
-		return launch_gauss_cols(s, s->d_yT, s->d_model, bt, B, scale, d_row_ids, M, d_Lout) ? 0 : 1;
-	}
+	if (use_cols) return gauss_loglike_cols_dev(s, d_params, B, noise_level, d_row_ids, M, d_Lout);
 	const int ldm = model_ld(s->nx);
 	if (!grow(&s->d_model, &s->model_cap, (size_t) B * ldm)) return 1;
 	if (!launch_gauss_model(s->d_x, s->nx, d_params, B, s->d_model, ldm)) return 1;

@@ -61,14 +61,39 @@ inline int model_ld(int nx) { return nx <= 0 ? 512 : ((nx + 511) / 512) * 512; }
 // channel count of the channel-major replica / transposed templates: padded (with zeros) to
 // the software-pipeline depth of k_gauss_cols
 inline int cols_nx(int nx) { return ((nx + 7) / 8) * 8; }
+// grow-only device buffers of a spectra handle (contents not kept): templates, compact replica
+bool ensure_model(mdns_spectra *s, size_t doubles);
+bool ensure_selection(mdns_spectra *s, size_t doubles);
+// K1 through the lane kernel whatever the shape (mdns_core.hip)
+int gauss_loglike_cols_dev(mdns_spectra *s, const double *d_params, int B, double noise_level,
+                           const int *d_row_ids, int M, double *d_Lout);
 // launchers implemented in mdns_like.hip (all asynchronous on ctx()->stream)
 bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B,
                         double *d_model, int ldm);
 // candidates per wave of k_gauss_cols for M selected spectra and B candidates (1..16)
 int gauss_cols_tile(int M, int B);
 // tiled templates MT[ceil(B/bt)][cols_nx(nx)][bt], zero for b >= B and j >= nx
+// (d_zero, nzero): a small int buffer the kernel clears on the way (accept flags + result header)
 bool launch_gauss_model_t(const double *d_x, int nx, const double *d_params, int B, int bt,
-                          double *d_model_t);
+                          double *d_model_t, int *d_zero = nullptr, int nzero = 0);
+// device arrays of the joint sampler state (mdns_joint.hip), all indexed by original data set
+struct JointArrays {
+	double *live;      // [nlive][ndata]   live-point likelihoods (multi_nested_sampler.py:111)
+	double *shelfL;    // [cap][ndata]     likelihoods waiting on the shelves (:117)
+	int *shelfn;       // [ndata]          how many
+	double *higher;    // [ndata]          threshold of the next draw (:438-447)
+	int nlive, cap, ndata;
+};
+// what a chunk of a constrained draw leaves for the host (mdns.h, mdns_joint_commit_dev)
+struct JointHeader { int accepted; int status; long long pad; };
+// accept test fused into the lane kernel: flags[b] = 1 when candidate b beats a threshold
+bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
+                              double scale, const int *d_rows, const int *d_thr_rows, int M,
+                              const double *d_higher, int *d_flags);
+// first flagged candidate: its likelihood row, fill bits, shelf appends, new thresholds
+bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,
+                              double scale, const int *d_rows, const int *d_thr_rows, int M, const int *d_flags,
+                              const JointArrays &st, void *d_header, unsigned long long *d_fillbits, double *d_Lrow);
 bool launch_gauss_cols(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                        double scale, const int *d_rows, int M, double *d_out);
 bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B,

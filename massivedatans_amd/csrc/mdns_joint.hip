@@ -1,0 +1,488 @@
+// The floating-point state of the joint sampler on the device, and the constrained draw that is
+// decided there (include/mdns.h, Part 2b).
+//
+// The reference keeps, per data set, the likelihoods of its live points (`live_pointsL[nlive,
+// ndata]`, multi_nested_sampler.py:111) and of the accepted points waiting on its shelf (:117),
+// and derives from them, for every draw, the thresholds `Lmins_higher` (:438-447).  Here all of
+// that lives in HBM, one column per data set (lane = data set: every access is coalesced over
+// the data sets), indexed by the ORIGINAL data-set index for the whole run:
+//
+//   live   [nlive][ndata]   slot p of data set d at p * ndata + d
+//   shelfL [cap][ndata]     FIFO, entry e at e * ndata + d, shelfn[d] entries
+//   higher [ndata]          threshold of the next draw: with n entries waiting, the (n+1)-th
+//                           smallest of live + shelf (find_nsmallest, :44-47)
+//
+// Thresholds are order statistics of ~100 numbers; they are always computed from the two
+// arrays above (no auxiliary sorted lists that could go out of step): by repeated
+// "smallest value above the previous one" passes at the start of an iteration, and by ONE such
+// pass when an accepted point joins a shelf (k_gauss_cols_commit in mdns_like.hip).
+#include "mdns_internal.h"
+
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+namespace mdns {
+
+static constexpr int kBlock = 256;
+static constexpr int kFlagInts = MDNS_JOINT_MAX_BATCH;            // accept flags, one int per candidate
+static constexpr int kZeroInts = kFlagInts + (int) (sizeof(JointHeader) / sizeof(int));
+
+// Start of an iteration, one lane per running data set (multi_nested_sampler.py:130-143):
+// lowest live likelihood and its slot (first occurrence, as numpy.argmin), shelf entries that
+// do not beat it dropped in order, threshold for what is still waiting.
+__global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const int *__restrict__ running, int nrun,
+                                                          double *__restrict__ Lmin, int *__restrict__ argmin_run,
+                                                          int *__restrict__ argmin, unsigned long long *__restrict__ keep,
+                                                          int keep_words)
+{
+	const int r = blockIdx.x * kBlock + threadIdx.x;
+	if (r >= nrun) return;
+	const int d = running[r];
+	const size_t nd = (size_t) st.ndata;
+	double m = st.live[d];
+	int am = 0;
+	for (int p = 1; p < st.nlive; p++) {
+		const double v = st.live[p * nd + d];
+		if (v < m) { m = v; am = p; }
+	}
+	// purge (multi_nested_sampler.py:137-138: keep entries with L > Lmin, order kept)
+	const int n = st.shelfn[d];
+	int w = 0;
+	for (int word = 0; word < keep_words; word++) {
+		unsigned long long bits = 0;
+		const int e1 = min(n, 64 * (word + 1));
+		for (int e = 64 * word; e < e1; e++) {
+			const double v = st.shelfL[e * nd + d];
+			if (v > m) {
+				bits |= 1ull << (e & 63);
+				if (w != e) st.shelfL[w * nd + d] = v;
+				w++;
+			}
+		}
+		keep[(size_t) r * keep_words + word] = bits;
+	}
+	st.shelfn[d] = w;
+	// (w+1)-th smallest of live + shelf: walk up the distinct values, counting multiplicities
+	double thr = m;
+	if (w > 0) {
+		double prev = 0.0;
+		bool first = true;
+		int below = 0;
+		while (true) {
+			double cur = INFINITY;
+			int times = 0;
+			for (int p = 0; p < st.nlive; p++) {
+				const double v = st.live[p * nd + d];
+				if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
+			}
+			for (int e = 0; e < w; e++) {
+				const double v = st.shelfL[e * nd + d];
+				if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
+			}
+			below += times;
+			thr = cur;
+			if (below >= w + 1 || times == 0) break;
+			prev = cur;
+			first = false;
+		}
+	}
+	st.higher[d] = thr;
+	Lmin[r] = m;
+	argmin_run[r] = am;
+	argmin[d] = am;
+}
+
+// End of an iteration (multi_nested_sampler.py:494-534): the worst live point of every running
+// data set is replaced by the head of its shelf.
+__global__ __launch_bounds__(kBlock) void k_joint_advance(JointArrays st, const int *__restrict__ running, int nrun,
+                                                          const int *__restrict__ argmin, int *__restrict__ status)
+{
+	const int r = blockIdx.x * kBlock + threadIdx.x;
+	if (r >= nrun) return;
+	const int d = running[r];
+	const size_t nd = (size_t) st.ndata;
+	const int n = st.shelfn[d];
+	if (n <= 0) { atomicOr(status, 1); return; }
+	st.live[argmin[d] * nd + d] = st.shelfL[d];
+	for (int e = 1; e < n; e++) st.shelfL[(e - 1) * nd + d] = st.shelfL[e * nd + d];
+	st.shelfn[d] = n - 1;
+}
+
+__global__ void k_joint_fill(double *__restrict__ p, size_t n, double value)
+{
+	for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t) gridDim.x * blockDim.x) p[e] = value;
+}
+
+}  // namespace mdns
+
+using namespace mdns;
+
+struct mdns_joint {
+	mdns_spectra *s = nullptr;
+	int nlive = 0, cap = 0, ndata = 0;
+	JointArrays st = {};
+	int *d_running = nullptr;  int nrun = 0;
+	double *d_Lmin = nullptr;          // [ndata] by position in the running list
+	int *d_argmin_run = nullptr;       // [ndata] by position in the running list
+	int *d_argmin = nullptr;           // [ndata] by data set
+	unsigned long long *d_keep = nullptr;  size_t keep_cap = 0;
+	int *d_status = nullptr;           // sticky failure bits of advance
+	// one allocation: accept flags | header | fill bits | likelihood row  (the model kernel of a
+	// chunk clears flags + header; header onward is what the host reads)
+	int *d_flags = nullptr;
+	char *d_result = nullptr;          // = (char *) (d_flags + kFlagInts)
+	// staging of the host-pointer draw
+	double *d_params = nullptr;
+	int *d_rows = nullptr;
+	char *h_pin = nullptr;  size_t pin_bytes = 0;
+	// what the last score launched with (commit uses the same spectra replica and templates)
+	const double *last_yT = nullptr;
+	const int *last_gather = nullptr;
+	int last_bt = 0, last_B = 0;
+	double last_scale = 0;
+	bool prepared = false;
+};
+
+static size_t result_bytes(int M) { return sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8 + (size_t) M * 8; }
+extern "C" size_t mdns_joint_result_bytes(int M) { return result_bytes(M > 0 ? M : 0); }
+static int keep_words_of(int cap) { return (cap + 63) / 64; }
+
+static bool joint_sync(Context *c) { return MDNS_HIP(hipStreamSynchronize(c->stream)); }
+
+extern "C" void mdns_joint_destroy(mdns_joint *j)
+{
+	if (!j) return;
+	Context *c = ctx();
+	if (c) (void) hipStreamSynchronize(c->stream);
+	void *bufs[] = {j->st.live, j->st.shelfL, j->st.shelfn, j->st.higher, j->d_running, j->d_Lmin, j->d_argmin_run,
+	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params, j->d_rows};
+	for (void *b : bufs) if (b) (void) hipFree(b);
+	if (j->h_pin) (void) hipHostFree(j->h_pin);
+	delete j;
+}
+
+extern "C" mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_cap)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (!s || nlive <= 0 || s->ndata <= 0) { set_error("mdns_joint_create: bad arguments (nlive=%d)", nlive); return nullptr; }
+	if (!s->d_yT || !s->d_x) { set_error("mdns_joint_create: the spectra need a wavelength grid and no variances (Gaussian-line problem)"); return nullptr; }
+	if (shelf_cap < 4) shelf_cap = 4;
+	mdns_joint *j = new mdns_joint();
+	j->s = s; j->nlive = nlive; j->cap = shelf_cap; j->ndata = s->ndata;
+	const size_t nd = (size_t) s->ndata;
+	const size_t res = (size_t) kFlagInts * sizeof(int) + result_bytes(s->ndata);
+	bool ok =
+	    MDNS_HIP(hipMalloc((void **) &j->st.live, (size_t) nlive * nd * sizeof(double))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->st.shelfL, (size_t) shelf_cap * nd * sizeof(double))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->st.shelfn, nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->st.higher, nd * sizeof(double))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_running, nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_Lmin, nd * sizeof(double))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_argmin_run, nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_argmin, nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_status, sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_flags, res)) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 3 * sizeof(double))) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_rows, nd * sizeof(int)));
+	if (ok) {
+		j->d_result = (char *) (j->d_flags + kFlagInts);
+		j->st.nlive = nlive; j->st.cap = shelf_cap; j->st.ndata = s->ndata;
+		std::vector<int> all(nd);
+		for (size_t i = 0; i < nd; i++) all[i] = (int) i;
+		ok = MDNS_HIP(hipMemsetAsync(j->st.shelfn, 0, nd * sizeof(int), c->stream)) &&
+		     MDNS_HIP(hipMemsetAsync(j->d_status, 0, sizeof(int), c->stream)) &&
+		     MDNS_HIP(hipMemsetAsync(j->d_flags, 0, res, c->stream)) &&
+		     MDNS_HIP(hipMemsetAsync(j->d_argmin, 0, nd * sizeof(int), c->stream)) &&
+		     MDNS_HIP(hipMemcpyAsync(j->d_running, all.data(), nd * sizeof(int), hipMemcpyHostToDevice, c->stream));
+		if (ok) {
+			hipLaunchKernelGGL(k_joint_fill, dim3(256), dim3(kBlock), 0, c->stream, j->st.higher, nd, (double) NAN);
+			ok = MDNS_HIP(hipGetLastError()) && joint_sync(c);
+		}
+		j->nrun = s->ndata;
+	}
+	if (!ok) { mdns_joint_destroy(j); return nullptr; }
+	return j;
+}
+
+static char *joint_pin(mdns_joint *j, size_t bytes)
+{
+	if (bytes <= j->pin_bytes) return j->h_pin;
+	Context *c = ctx();
+	if (j->h_pin) { (void) hipStreamSynchronize(c->stream); (void) hipHostFree(j->h_pin); j->h_pin = nullptr; j->pin_bytes = 0; }
+	const size_t want = bytes + bytes / 2 + 4096;
+	if (!MDNS_HIP(hipHostMalloc((void **) &j->h_pin, want, hipHostMallocDefault))) return nullptr;
+	j->pin_bytes = want;
+	return j->h_pin;
+}
+
+extern "C" int mdns_joint_shelf_cap(const mdns_joint *j) { return j ? j->cap : -1; }
+extern "C" int mdns_joint_keep_words(const mdns_joint *j) { return j ? keep_words_of(j->cap) : -1; }
+
+extern "C" int mdns_joint_reserve(mdns_joint *j, int shelf_cap)
+{
+	Context *c = ctx();
+	if (!c || !j) return 1;
+	if (shelf_cap <= j->cap) return 0;
+	int cap = j->cap;
+	while (cap < shelf_cap) cap *= 2;
+	const size_t nd = (size_t) j->ndata;
+	double *bigger = nullptr;
+	if (!MDNS_HIP(hipMalloc((void **) &bigger, (size_t) cap * nd * sizeof(double)))) return 1;
+	// entry-major layout: the old array is a prefix of the new one
+	if (!MDNS_HIP(hipMemcpyAsync(bigger, j->st.shelfL, (size_t) j->cap * nd * sizeof(double), hipMemcpyDeviceToDevice, c->stream)) ||
+	    !joint_sync(c)) { (void) hipFree(bigger); return 1; }
+	(void) hipFree(j->st.shelfL);
+	j->st.shelfL = bigger;
+	j->cap = j->st.cap = cap;
+	return 0;
+}
+
+static int joint_reset(mdns_joint *j)
+{
+	Context *c = ctx();
+	j->prepared = false;
+	return MDNS_HIP(hipMemsetAsync(j->st.shelfn, 0, (size_t) j->ndata * sizeof(int), c->stream)) &&
+	       MDNS_HIP(hipMemsetAsync(j->d_status, 0, sizeof(int), c->stream)) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_init_gauss(mdns_joint *j, const double *params, double noise_level)
+{
+	Context *c = ctx();
+	if (!c || !j || !params) return 1;
+	if (j->nlive > MDNS_JOINT_MAX_BATCH) { set_error("mdns_joint_init_gauss: nlive=%d > %d", j->nlive, MDNS_JOINT_MAX_BATCH); return 1; }
+	char *pin = joint_pin(j, (size_t) j->nlive * 24);
+	if (!pin) return 1;
+	memcpy(pin, params, (size_t) j->nlive * 24);
+	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, (size_t) j->nlive * 24, hipMemcpyHostToDevice, c->stream))) return 1;
+	// always the lane kernel: every likelihood of a run is then the same chain of operations
+	if (gauss_loglike_cols_dev(j->s, j->d_params, j->nlive, noise_level, nullptr, j->ndata, j->st.live) != 0) return 1;
+	if (joint_reset(j) != 0) return 1;
+	return joint_sync(c) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_restore_live_dev(mdns_joint *j, const double *d_liveL)
+{
+	Context *c = ctx();
+	if (!c || !j || !d_liveL) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(j->st.live, d_liveL, (size_t) j->nlive * j->ndata * sizeof(double), hipMemcpyDeviceToDevice, c->stream))) return 1;
+	return joint_reset(j);
+}
+
+extern "C" const double *mdns_joint_live_dev(mdns_joint *j) { return j ? j->st.live : nullptr; }
+
+extern "C" int mdns_joint_set_live(mdns_joint *j, const double *liveL)
+{
+	Context *c = ctx();
+	if (!c || !j || !liveL) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(j->st.live, liveL, (size_t) j->nlive * j->ndata * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
+	if (joint_reset(j) != 0) return 1;
+	return joint_sync(c) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_get_live(mdns_joint *j, double *liveL)
+{
+	Context *c = ctx();
+	if (!c || !j || !liveL) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(liveL, j->st.live, (size_t) j->nlive * j->ndata * sizeof(double), hipMemcpyDeviceToHost, c->stream))) return 1;
+	return joint_sync(c) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_get_thresholds(mdns_joint *j, double *higher, int *shelf_n)
+{
+	Context *c = ctx();
+	if (!c || !j) return 1;
+	if (higher && !MDNS_HIP(hipMemcpyAsync(higher, j->st.higher, (size_t) j->ndata * sizeof(double), hipMemcpyDeviceToHost, c->stream))) return 1;
+	if (shelf_n && !MDNS_HIP(hipMemcpyAsync(shelf_n, j->st.shelfn, (size_t) j->ndata * sizeof(int), hipMemcpyDeviceToHost, c->stream))) return 1;
+	return joint_sync(c) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_set_running(mdns_joint *j, const int *rows, int nrun)
+{
+	Context *c = ctx();
+	if (!c || !j) return 1;
+	if (nrun < 0 || nrun > j->ndata || (nrun > 0 && !rows)) { set_error("mdns_joint_set_running: nrun=%d", nrun); return 1; }
+	for (int i = 0; i < nrun; i++)
+		if (rows[i] < 0 || rows[i] >= j->ndata || (i > 0 && rows[i] <= rows[i - 1])) {
+			set_error("mdns_joint_set_running: rows must be ascending indices below %d", j->ndata);
+			return 1;
+		}
+	if (nrun > 0 && (!MDNS_HIP(hipMemcpyAsync(j->d_running, rows, (size_t) nrun * sizeof(int), hipMemcpyHostToDevice, c->stream)) ||
+	                 !joint_sync(c))) return 1;
+	j->nrun = nrun;
+	return 0;
+}
+
+extern "C" int mdns_joint_prepare_dev(mdns_joint *j)
+{
+	Context *c = ctx();
+	if (!c || !j) return 1;
+	const int kw = keep_words_of(j->cap);
+	const size_t need = (size_t) (j->nrun > 0 ? j->nrun : 1) * kw;
+	if (need > j->keep_cap) {
+		if (j->d_keep) { (void) hipStreamSynchronize(c->stream); (void) hipFree(j->d_keep); j->d_keep = nullptr; j->keep_cap = 0; }
+		const size_t want = (size_t) j->ndata * kw;
+		if (!MDNS_HIP(hipMalloc((void **) &j->d_keep, want * sizeof(unsigned long long)))) return 1;
+		j->keep_cap = want;
+	}
+	j->prepared = true;
+	if (j->nrun == 0) return 0;
+	hipLaunchKernelGGL(k_joint_prepare, dim3((j->nrun + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+	                   j->st, j->d_running, j->nrun, j->d_Lmin, j->d_argmin_run, j->d_argmin, j->d_keep, kw);
+	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_prepare(mdns_joint *j, double *Lmin, int *argmin, unsigned long long *keep)
+{
+	Context *c = ctx();
+	if (mdns_joint_prepare_dev(j) != 0) return 1;
+	const int kw = keep_words_of(j->cap);
+	const size_t n = (size_t) j->nrun;
+	if (n == 0) return 0;
+	// one pinned block, three copies, one wait
+	const size_t o1 = n * 8, o2 = o1 + ((n * 4 + 7) & ~(size_t) 7);
+	char *pin = joint_pin(j, o2 + n * kw * 8);
+	if (!pin) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(pin, j->d_Lmin, n * 8, hipMemcpyDeviceToHost, c->stream)) ||
+	    !MDNS_HIP(hipMemcpyAsync(pin + o1, j->d_argmin_run, n * 4, hipMemcpyDeviceToHost, c->stream)) ||
+	    !MDNS_HIP(hipMemcpyAsync(pin + o2, j->d_keep, n * kw * 8, hipMemcpyDeviceToHost, c->stream)) ||
+	    !joint_sync(c)) return 1;
+	if (Lmin) memcpy(Lmin, pin, n * 8);
+	if (argmin) memcpy(argmin, pin + o1, n * 4);
+	if (keep) memcpy(keep, pin + o2, n * kw * 8);
+	return 0;
+}
+
+extern "C" int mdns_joint_advance_dev(mdns_joint *j)
+{
+	Context *c = ctx();
+	if (!c || !j) return 1;
+	if (!j->prepared) { set_error("mdns_joint_advance: no prepare since the state was set"); return 1; }
+	if (j->nrun == 0) return 0;
+	hipLaunchKernelGGL(k_joint_advance, dim3((j->nrun + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+	                   j->st, j->d_running, j->nrun, j->d_argmin, j->d_status);
+	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_advance(mdns_joint *j)
+{
+	Context *c = ctx();
+	if (mdns_joint_advance_dev(j) != 0) return 1;
+	int status = 0;
+	if (!MDNS_HIP(hipMemcpyAsync(&status, j->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream)) || !joint_sync(c)) return 1;
+	if (status) { set_error("mdns_joint_advance: a running data set had an empty shelf"); return 1; }
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// the draw
+// ---------------------------------------------------------------------------------------
+static bool check_draw(const mdns_joint *j, int B, int M, const char *who)
+{
+	if (!j) { set_error("%s: null handle", who); return false; }
+	if (B < 0 || B > MDNS_JOINT_MAX_BATCH || M < 0 || M > j->ndata) {
+		set_error("%s: bad sizes B=%d (<= %d) M=%d (ndata=%d)", who, B, MDNS_JOINT_MAX_BATCH, M, j->ndata);
+		return false;
+	}
+	return true;
+}
+
+extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B, double noise_level,
+                                    const int *d_row_ids, int M)
+{
+	Context *c = ctx();
+	if (!c || !check_draw(j, B, M, "mdns_joint_score_dev")) return 1;
+	mdns_spectra *s = j->s;
+	j->last_B = 0;
+	if (B == 0 || M == 0) {
+		// nothing to score: no flag can be set; still hand commit a clean header
+		return MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kZeroInts * sizeof(int), c->stream)) ? 0 : 1;
+	}
+	const double scale = -0.5 / (noise_level * noise_level);
+	const int bt = gauss_cols_tile(M, B);
+	if (!ensure_model(s, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
+	if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_flags, kZeroInts)) return 1;
+	const double *yT = s->d_yT;
+	const int *gather = d_row_ids;
+	// a sparse selection, or many candidate tiles over a selection: first a compact replica of
+	// the selected spectra (one coalesced pass) instead of gathering columns in every tile
+	const bool sparse = (size_t) M * 8 < (size_t) s->ndata;
+	if (d_row_ids && (B >= 128 || sparse)) {
+		if (!ensure_selection(s, (size_t) ((M + 63) / 64) * 64 * cols_nx(s->nx))) return 1;
+		if (!launch_tile_columns(s->d_y, s->ld, M, s->nx, d_row_ids, s->d_sel)) return 1;
+		yT = s->d_sel;
+		gather = nullptr;
+	}
+	if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags)) return 1;
+	j->last_yT = yT; j->last_gather = gather; j->last_bt = bt; j->last_B = B; j->last_scale = scale;
+	return 0;
+}
+
+extern "C" int *mdns_joint_flags_dev(mdns_joint *j) { return j ? j->d_flags : nullptr; }
+extern "C" const void *mdns_joint_result_dev(mdns_joint *j) { return j ? j->d_result : nullptr; }
+
+extern "C" int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M)
+{
+	Context *c = ctx();
+	if (!c || !check_draw(j, 0, M, "mdns_joint_commit_dev")) return 1;
+	if (j->last_B == 0 || M == 0) {
+		// an empty chunk accepts nothing
+		static const JointHeader none = {-1, 0, 0};
+		return MDNS_HIP(hipMemcpyAsync(j->d_result, &none, sizeof none, hipMemcpyHostToDevice, c->stream)) ? 0 : 1;
+	}
+	char *base = j->d_result;
+	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
+	double *Lrow = (double *) (base + sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8);
+	return launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
+	                                d_row_ids, M, j->d_flags, j->st, base, bits, Lrow) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B, double noise_level,
+                                     const int *row_ids, int M, int *accepted, double *Lrow,
+                                     unsigned long long *fillbits)
+{
+	Context *c = ctx();
+	if (!c || !check_draw(j, B, M, "mdns_joint_draw_gauss")) return 1;
+	if (!accepted) { set_error("mdns_joint_draw_gauss: null output"); return 1; }
+	if (!j->prepared) { set_error("mdns_joint_draw_gauss: thresholds are not set (call mdns_joint_prepare first)"); return 1; }
+	*accepted = -1;
+	if (B == 0 || M == 0) return 0;
+	if (row_ids) {
+		for (int k = 0; k < M; k++)
+			if (row_ids[k] < 0 || row_ids[k] >= j->ndata || (k > 0 && row_ids[k] <= row_ids[k - 1])) {
+				set_error("mdns_joint_draw_gauss: row_ids must be ascending indices below %d (row_ids[%d]=%d)", j->ndata, k, row_ids[k]);
+				return 1;
+			}
+	} else if (M != j->ndata) {
+		set_error("mdns_joint_draw_gauss: M=%d without row_ids (ndata=%d)", M, j->ndata);
+		return 1;
+	}
+	const size_t pbytes = (size_t) B * 24, rbytes = row_ids ? (size_t) M * 4 : 0;
+	const size_t in_bytes = (pbytes + rbytes + 15) & ~(size_t) 15;
+	const size_t out_bytes = result_bytes(M);
+	char *pin = joint_pin(j, in_bytes + out_bytes);
+	if (!pin) return 1;
+	memcpy(pin, params, pbytes);
+	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	if (row_ids) {
+		memcpy(pin + pbytes, row_ids, rbytes);
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_rows, pin + pbytes, rbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	}
+	const int *d_rows = row_ids ? j->d_rows : nullptr;
+	if (mdns_joint_score_dev(j, j->d_params, B, noise_level, d_rows, M) != 0) return 1;
+	if (mdns_joint_commit_dev(j, d_rows, M) != 0) return 1;
+	char *out = pin + in_bytes;
+	// the header says whether the rest matters, but one copy of at most 80 KB costs less than a
+	// second round trip
+	if (!MDNS_HIP(hipMemcpyAsync(out, j->d_result, out_bytes, hipMemcpyDeviceToHost, c->stream)) || !joint_sync(c)) return 1;
+	const JointHeader *h = (const JointHeader *) out;
+	if (h->status) { set_error("mdns_joint_draw_gauss: a shelf overflowed its capacity %d (mdns_joint_reserve)", j->cap); return 1; }
+	*accepted = h->accepted;
+	if (h->accepted >= 0) {
+		const size_t nb = (size_t) ((M + 63) / 64) * 8;
+		if (fillbits) memcpy(fillbits, out + sizeof(JointHeader), nb);
+		if (Lrow) memcpy(Lrow, out + sizeof(JointHeader) + nb, (size_t) M * 8);
+	}
+	return 0;
+}

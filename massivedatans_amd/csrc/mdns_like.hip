@@ -111,9 +111,12 @@ __global__ void k_gauss_model(const double *__restrict__ x, int nx, const double
 // for the padding channels j >= nx (one thread per element).  A wave of k_gauss_cols walks one
 // tile front to back, so its template stream is contiguous.
 __global__ void k_gauss_model_t(const double *__restrict__ x, int nx, int nxp, const double *__restrict__ params,
-                                int B, int bt_size, int ntile, double *__restrict__ model_t)
+                                int B, int bt_size, int ntile, double *__restrict__ model_t,
+                                int *__restrict__ zero, int nzero)
 {
 	const int e = blockIdx.x * blockDim.x + threadIdx.x;
+	// first kernel of a draw chunk: also clears the accept flags and the result header
+	if (e < nzero) zero[e] = 0;
 	if (e >= ntile * nxp * bt_size) return;
 	const int bin = e % bt_size;
 	const int j = (e / bt_size) % nxp;
@@ -317,20 +320,15 @@ __global__ __launch_bounds__(kBlock) void k_gauss_rows(
 // channel, spectrum).  Work items are (spectrum tile, candidate tile) pairs, one per wave.
 // SP = spectra per lane (1 or 2): with 2 every template value read through the scalar cache
 // feeds two v_add/v_fmac pairs.
-template <int BT, int SP>
-__global__ __launch_bounds__(kBlock) void k_gauss_cols(
-    const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
-    double scale, const int *__restrict__ rows, int M, int ntiles, int nq_xcd, int nbt, int cu_slots, double *__restrict__ out)
+// Which (spectrum tile, candidate tile) a wave works on -- see the comments in k_gauss_cols.
+// Returns false when the wave has nothing to do.
+__device__ __forceinline__ bool cols_item(int ntiles, int nq_xcd, int nbt, int cu_slots, int &tile, int &bt)
 {
-	constexpr int CH = 8;                     // channels per software-pipeline stage (nxp % CH == 0)
-	const int lane = threadIdx.x & 63;
-	// Work item of a wave = (spectrum tile, candidate tile), a spectrum tile being 64*SP
-	// spectra.  A workgroup takes 4 adjacent spectrum tiles (a "quad") of ONE candidate tile,
-	// so its waves pull the same template values through the scalar cache.  Workgroups are
-	// dealt round-robin over the 8 XCDs (blockIdx % 8 shares an XCD): quad q is always given
-	// to XCD q % 8, for every candidate tile, so each XCD re-reads only its own eighth of the
-	// spectra from its own L2.  This is a speed-only mapping; any placement gives the same
-	// results.
+	// A workgroup takes 4 adjacent spectrum tiles (a "quad") of ONE candidate tile, so its
+	// waves pull the same template values through the scalar cache.  Workgroups are dealt
+	// round-robin over the 8 XCDs (blockIdx % 8 shares an XCD): quad q is always given to XCD
+	// q % 8, for every candidate tile, so each XCD re-reads only its own eighth of the spectra
+	// from its own L2.  This is a speed-only mapping; any placement gives the same results.
 	const int xcd = blockIdx.x & 7;
 	const int local = blockIdx.x >> 3;
 	// Within an XCD the dispatcher deals workgroups round-robin over the CUs (measured: `local`
@@ -342,16 +340,31 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 	const int nitems = nbt * nq_xcd;
 	const int first = (int) ((long long) slot * nitems / cu_slots);
 	const int next = (int) ((long long) (slot + 1) * nitems / cu_slots);
-	if (first + round >= next) return;
-	const int bt = (first + round) / nq_xcd;
+	if (first + round >= next) return false;
+	bt = (first + round) / nq_xcd;
 	const int quad = ((first + round) % nq_xcd) * 8 + xcd;
-	const int tile = quad * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	if (tile >= ntiles) return;
+	tile = quad * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	return tile < ntiles;
+}
+
+// The sums of one wave: acc[s][b] = sum over the channels, in ascending order, of
+// (template b - spectrum)^2 for the lane's spectrum (positions k[s] of the selection).
+// MS = distance in doubles between the template values of consecutive channels: BT for a
+// wave that scores a whole candidate tile (compile time), or, with RUNTIME_STRIDE, the tile
+// width the templates were laid out for while the wave scores ONE candidate of it (BT == 1).
+// Every (candidate, spectrum) sum is the same chain of v_add_f64 / v_fma_f64 whatever BT is,
+// so the likelihood of a pair does not depend on the tile shape it was computed in.
+template <int BT, int SP, bool RUNTIME_STRIDE>
+__device__ __forceinline__ void cols_accumulate(const double *__restrict__ YT, int nxp,
+                                                const double *mp, int mstride,
+                                                const int *__restrict__ rows, int M, int tile, int lane,
+                                                int (&k)[SP], double (&acc)[SP][BT])
+{
+	constexpr int CH = 8;                     // channels per software-pipeline stage (nxp % CH == 0)
 	// YT is stored in tiles of 64 spectra: element (channel j, spectrum i) at
 	// ((i / 64) * nxp + j) * 64 + i % 64.  Whatever column a lane owns (its own tile when all
 	// spectra are selected, a gathered one otherwise), consecutive channels are exactly 512
 	// bytes apart, so the eight loads of a stage are immediate offsets of one pointer.
-	int k[SP];                                // positions in the (compacted) output
 	const double *yp[SP];
 #pragma unroll
 	for (int s = 0; s < SP; s++) {
@@ -361,9 +374,6 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 		else if (col >= ((M + 63) & ~63)) col = M - 1;
 		yp[s] = YT + ((size_t) (col >> 6) * nxp << 6) + (col & 63);
 	}
-	const double *mp = model_t + (size_t) bt * nxp * BT;     // wave-uniform: CH*BT contiguous doubles per stage
-
-	double acc[SP][BT];
 #pragma unroll
 	for (int s = 0; s < SP; s++)
 #pragma unroll
@@ -377,6 +387,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 	for (int s = 0; s < SP; s++)
 #pragma unroll
 		for (int c = 0; c < CH; c++) ya[s][c] = yp[s][c * 64];
+	const int ms = RUNTIME_STRIDE ? mstride : BT;
 	auto stage = [&](const double (&cur)[SP][CH], double (&nxt)[SP][CH], bool last) {
 #pragma unroll
 		for (int s = 0; s < SP; s++) {
@@ -390,7 +401,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 			// it costs 34 VGPRs = three waves per SIMD)
 #pragma unroll
 			for (int b = 0; b < BT; b++) {
-				const double mv = mp[c * BT + b];
+				const double mv = mp[c * ms + b];
 #pragma unroll
 				for (int s = 0; s < SP; s++) {
 					const double d = mv - cur[s][c];
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 				}
 			}
 		}
-		mp += CH * BT;
+		mp += CH * ms;
 	};
 	int st = nxp / CH;
 #pragma unroll 1
@@ -407,6 +418,22 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 		stage(yb, ya, st == 2);
 	}
 	if (st == 1) stage(ya, yb, true);
+}
+
+template <int BT, int SP>
+__global__ __launch_bounds__(kBlock) void k_gauss_cols(
+    const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
+    double scale, const int *__restrict__ rows, int M, int ntiles, int nq_xcd, int nbt, int cu_slots, double *__restrict__ out)
+{
+	const int lane = threadIdx.x & 63;
+	// Work item of a wave = (spectrum tile, candidate tile), a spectrum tile being 64*SP
+	// spectra, one per workgroup wave (cols_item).
+	int tile, bt;
+	if (!cols_item(ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
+	const double *mp = model_t + (size_t) bt * nxp * BT;     // wave-uniform: CH*BT contiguous doubles per stage
+	int k[SP];                                // positions in the (compacted) output
+	double acc[SP][BT];
+	cols_accumulate<BT, SP, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
 #pragma unroll
 	for (int s = 0; s < SP; s++) {
 		if (k[s] < M) {
@@ -415,6 +442,103 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 				if (bt * BT + b < B) out[(size_t) (bt * BT + b) * M + k[s]] = acc[s][b] * scale;
 		}
 	}
+}
+
+// The same sums with the accept test of the constrained draw as epilogue
+// (hiermetriclearn.py:193 `any(L > Lmins)`): nothing but one flag per candidate leaves the
+// kernel.  `thr_rows` names the data set behind every position of the selection (NULL: the
+// position itself), `higher` holds the thresholds of all data sets (multi_nested_sampler.py:438-447).
+template <int BT>
+__global__ __launch_bounds__(kBlock) void k_gauss_cols_accept(
+    const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
+    double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
+    int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, int *__restrict__ flags)
+{
+	const int lane = threadIdx.x & 63;
+	int tile, bt;
+	if (!cols_item(ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
+	const double *mp = model_t + (size_t) bt * nxp * BT;
+	int k[1];
+	double acc[1][BT];
+	cols_accumulate<BT, 1, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
+	const bool live = k[0] < M;
+	const int kk = live ? k[0] : M - 1;
+	// a quiet NaN compares false with everything: lanes past the selection never vote
+	const double thr = live ? higher[thr_rows ? thr_rows[kk] : kk] : __builtin_nan("");
+#pragma unroll
+	for (int b = 0; b < BT; b++) {
+		const bool beats = acc[0][b] * scale > thr;
+		if (__ballot(beats) != 0ull && lane == 0 && bt * BT + b < B) flags[bt * BT + b] = 1;
+	}
+}
+
+// Second half of a draw chunk: the first flagged candidate is THE accepted point
+// (hiermetriclearn.py:193-196).  Its likelihood row is computed again -- the same chain of
+// operations as in k_gauss_cols_accept, so the same bits -- and compared with the thresholds
+// per data set (multi_nested_sampler.py:482-485): the row, one fill bit per selected data set,
+// and, for the data sets it beats, the append to their shelf and their next threshold.
+//   live   [nlive][ndata]  live-point likelihoods, slot p of data set d at p * ndata + d
+//   shelfL [cap][ndata]    likelihoods waiting, entry e of data set d at e * ndata + d
+//   shelfn [ndata]         how many are waiting
+//   higher [ndata]         threshold = (n+1)-th smallest of live + shelf with n waiting
+// One wave = 64 positions of the selection, one lane per data set: no two lanes share state.
+__global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
+    const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int mstride, int B,
+    double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
+    int ntiles, int nq_xcd, int cu_slots, const int *__restrict__ flags, JointArrays st,
+    JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits, double *__restrict__ Lrow)
+{
+	__shared__ int s_first;
+	if (threadIdx.x == 0) s_first = 0x7fffffff;
+	__syncthreads();
+	for (int b = threadIdx.x; b < B; b += kBlock)
+		if (flags[b]) { atomicMin(&s_first, b); break; }      // ascending per thread: its first is its lowest
+	__syncthreads();
+	const int bstar = s_first;
+	if (blockIdx.x == 0 && threadIdx.x == 0) header->accepted = bstar < B ? bstar : -1;
+	if (bstar >= B) return;
+	const int lane = threadIdx.x & 63;
+	int tile, bt_unused;
+	if (!cols_item(ntiles, nq_xcd, 1, cu_slots, tile, bt_unused)) return;
+	// templates are laid out [candidate tile][channel][mstride candidates]
+	const double *mp = model_t + (size_t) (bstar / mstride) * nxp * mstride + bstar % mstride;
+	int k[1];
+	double acc[1][1];
+	cols_accumulate<1, 1, true>(YT, nxp, mp, mstride, rows, M, tile, lane, k, acc);
+	const bool live = k[0] < M;
+	const double L = acc[0][0] * scale;
+	bool beats = false;
+	if (live) {
+		const int d = thr_rows ? thr_rows[k[0]] : k[0];
+		Lrow[k[0]] = L;
+		const double thr = st.higher[d];
+		beats = L > thr;
+		if (beats) {
+			const int n = st.shelfn[d];
+			if (n >= st.cap) {
+				atomicOr(&header->status, 1);
+			} else {
+				// With n waiting the threshold was the (n+1)-th smallest of live + shelf, and L lies
+				// above it: the (n+2)-th smallest of the enlarged set is the old threshold again when
+				// it occurs more than once, else the smaller of L and the next value above it.
+				int at_most = 0;
+				double next = INFINITY;
+				for (int p = 0; p < st.nlive; p++) {
+					const double v = st.live[(size_t) p * st.ndata + d];
+					if (v <= thr) at_most++; else next = fmin(next, v);
+				}
+				for (int e = 0; e < n; e++) {
+					const double v = st.shelfL[(size_t) e * st.ndata + d];
+					if (v <= thr) at_most++; else next = fmin(next, v);
+				}
+				st.shelfL[(size_t) n * st.ndata + d] = L;
+				st.shelfn[d] = n + 1;
+				st.higher[d] = at_most >= n + 2 ? thr : fmin(L, next);
+			}
+		}
+	}
+	const unsigned long long word = __ballot(beats);
+	if (lane == 0) fillbits[tile] = word;
 }
 
 // any nx: channels walked in chunks of 128, templates re-read per chunk (L2 resident)
@@ -685,6 +809,16 @@ bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B
 	return launched("k_gauss_model");
 }
 
+// grid of the lane kernels for `ntiles` spectrum tiles and `nbt` candidate tiles (see cols_item)
+static int cols_grid(const Context *c, int ntiles, int nbt, int &nq_xcd, int &cu_slots)
+{
+	const int nquads = (ntiles + 3) / 4;
+	nq_xcd = (nquads + 7) / 8;                              // quads per XCD (some may be empty)
+	cu_slots = c->num_cus >= 8 ? c->num_cus / 8 : 1;
+	const int rounds = (nbt * nq_xcd + cu_slots - 1) / cu_slots;
+	return 8 * cu_slots * rounds;
+}
+
 int gauss_cols_tile(int M, int B)
 {
 	Context *c = ctx();
@@ -706,14 +840,16 @@ int gauss_cols_tile(int M, int B)
 	return bt;
 }
 
-bool launch_gauss_model_t(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t)
+bool launch_gauss_model_t(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t,
+                          int *d_zero, int nzero)
 {
 	Context *c = ctx();
 	const int nxp = cols_nx(nx);
 	const int ntile = (B + bt - 1) / bt;
 	const int n = ntile * nxp * bt;
-	hipLaunchKernelGGL(k_gauss_model_t, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-	                   d_x, nx, nxp, d_params, B, bt, ntile, d_model_t);
+	const int threads = n > nzero ? n : nzero;
+	hipLaunchKernelGGL(k_gauss_model_t, dim3((threads + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+	                   d_x, nx, nxp, d_params, B, bt, ntile, d_model_t, d_zero, d_zero ? nzero : 0);
 	return launched("k_gauss_model_t");
 }
 
@@ -726,14 +862,11 @@ bool launch_gauss_cols(const mdns_spectra *s, const double *d_yT, const double *
 	constexpr int sp = 1;
 	const int ntiles = (M + 64 * sp - 1) / (64 * sp);
 	const int nbt = (B + bt - 1) / bt;
-	const int nquads = (ntiles + 3) / 4;
-	const int nq_xcd = (nquads + 7) / 8;                      // quads per XCD (some may be empty)
-	// per XCD: nbt * nq_xcd items dealt to cu_slots CUs in contiguous runs (see the kernel).
+	// per XCD: nbt * nq_xcd items dealt to cu_slots CUs in contiguous runs (see cols_item).
 	// Against the plain order (item = local) measured on one box: 49.4 vs 54.7 us at B = 256,
 	// 31.8 vs 36.1 at B = 128, 391 vs 432 at 100 000 x 256; only 10 000 x 1024 lost (184 vs 176).
-	const int cu_slots = c->num_cus >= 8 ? c->num_cus / 8 : 1;
-	const int rounds = (nbt * nq_xcd + cu_slots - 1) / cu_slots;
-	const int blocks = 8 * cu_slots * rounds;
+	int nq_xcd, cu_slots;
+	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots);
 	ProfileScope prof(0);
 	note_kernel(0, "k_gauss_cols<%d, %d>", bt, (int) sp);
 #define COLS_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols<BT, sp>), dim3(blocks), dim3(kBlock), 0, c->stream, \
@@ -747,6 +880,44 @@ bool launch_gauss_cols(const mdns_spectra *s, const double *d_yT, const double *
 	}
 #undef COLS_LAUNCH
 	return launched("k_gauss_cols");
+}
+
+bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
+                              double scale, const int *d_rows, const int *d_thr_rows, int M,
+                              const double *d_higher, int *d_flags)
+{
+	Context *c = ctx();
+	const int ntiles = (M + 63) / 64;
+	const int nbt = (B + bt - 1) / bt;
+	int nq_xcd, cu_slots;
+	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots);
+	ProfileScope prof(0);
+	note_kernel(0, "k_gauss_cols_accept<%d>", bt);
+#define ACCEPT_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols_accept<BT>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+	d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags)
+	switch (bt) {
+	case 16: ACCEPT_LAUNCH(16); break;
+	case 8: ACCEPT_LAUNCH(8); break;
+	case 4: ACCEPT_LAUNCH(4); break;
+	case 2: ACCEPT_LAUNCH(2); break;
+	default: ACCEPT_LAUNCH(1); break;
+	}
+#undef ACCEPT_LAUNCH
+	return launched("k_gauss_cols_accept");
+}
+
+bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,
+                              double scale, const int *d_rows, const int *d_thr_rows, int M, const int *d_flags,
+                              const JointArrays &st, void *d_header, unsigned long long *d_fillbits, double *d_Lrow)
+{
+	Context *c = ctx();
+	const int ntiles = (M + 63) / 64;
+	int nq_xcd, cu_slots;
+	const int blocks = cols_grid(c, ntiles, 1, nq_xcd, cu_slots);
+	hipLaunchKernelGGL(k_gauss_cols_commit, dim3(blocks), dim3(kBlock), 0, c->stream,
+	                   d_yT, cols_nx(s->nx), d_model_t, mstride, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, cu_slots,
+	                   d_flags, st, (JointHeader *) d_header, d_fillbits, d_Lrow);
+	return launched("k_gauss_cols_commit");
 }
 
 bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B, double *d_model, int ldm)

@@ -180,6 +180,46 @@ class MetricLearningFriendsConstrainer(object):
         self._ahead_L, self._ahead_lo, self._ahead_key = Ls, pos, mask_key
         return x, Ls[0]
 
+    def _draw_chunks(self, draw_batch, live_pointsu, ndim, region_rebuilt, metric_rebuilt):
+        """The accept loop of hiermetriclearn.py:181-211 with the candidates handed over in
+        chunks: ``draw_batch(us) -> (index of the first acceptable candidate or -1, x, L, number
+        of candidates looked at)`` scores a run of ALREADY proposed candidates and takes the
+        accept decision where the thresholds are (the GPU).  A chunk never reaches past the
+        candidate after which the reference would rebuild its region (hiermetriclearn.py:198-211),
+        so regions, RNG draws and results are those of the one-candidate-at-a-time loop."""
+        tries = 0
+        while True:
+            if self._buf is None or self._buf_pos >= len(self._buf):
+                self._buf, self._buf_ntotal = next(self.generator)      # consumes RNG, exactly on demand
+                self._buf_pos = 0
+                self._ahead_L = None
+                if self._buf_ntotal > 100000:
+                    self.direct_draws_efficient = False
+            room = len(self._buf) - self._buf_pos
+            # candidates that may be consumed before a rebuild condition can become true
+            if not region_rebuilt:
+                room = min(room, max(1, self.rebuild_every - self.ndraws_since_rebuild + 1))
+            if not metric_rebuilt:
+                room = min(room, max(1, 201 - tries))
+            chunk = self._buf[self._buf_pos:self._buf_pos + room]
+            idx, x, L, nscored = draw_batch(chunk)
+            used = idx + 1 if idx >= 0 else nscored
+            assert 0 < used <= room
+            tries += used
+            self.ndraws_since_rebuild += used
+            self._buf_pos += used
+            if idx >= 0:
+                self._last_ntoaccept = tries
+                return chunk[idx], x, L, tries
+            if not region_rebuilt and self.ndraws_since_rebuild > self.rebuild_every:
+                region_rebuilt = True
+                self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=True)
+                self.ndraws_since_rebuild = 0
+            elif not metric_rebuilt and tries > 200:
+                metric_rebuilt = True
+                self.rebuild(numpy.asarray(live_pointsu), ndim, keepMetric=False)
+                self.iter_since_metric_rebuild = 0
+
     # ---- the draw -----------------------------------------------------------------------
     def _draw_constrained_prepare(self, Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs):
         """Rebuild policy at the start of a draw (hiermetriclearn.py:152-166): a new region
@@ -206,6 +246,8 @@ class MetricLearningFriendsConstrainer(object):
         self.iter_since_metric_rebuild += 1
         region_rebuilt, metric_rebuilt = self._draw_constrained_prepare(
             Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs)
+        if kwargs.get('draw_batch') is not None:
+            return self._draw_chunks(kwargs['draw_batch'], live_pointsu, ndim, region_rebuilt, metric_rebuilt)
         lookahead = min(self.MAX_LOOKAHEAD, max(1, getattr(self, '_last_ntoaccept', 1)))
         tries = 0
         while True:

@@ -1,0 +1,260 @@
+"""The floating-point state of the joint sampler behind one interface, twice.
+
+The reference keeps the likelihoods of all live points (``live_pointsL[nlive, ndata]``,
+multi_nested_sampler.py:111) and of the accepted points waiting on the shelves (:117) in
+Python, and derives from them on every draw the thresholds ``Lmins_higher`` (:438-447), the
+accept test ``any(L > Lmins)`` (hiermetriclearn.py:193) and the shelf fill (:482-485).  The
+sampler of this package can hand all of that to a *joint state* object and keep only the
+integer side (point ids, queues of ids, the data-set graph):
+
+* :class:`GaussJointState` -- the state lives in HBM (``mdns_joint_*`` of include/mdns.h); a
+  draw chunk is scored, decided and committed on the GPU and only the accepted candidate's
+  index, likelihood row and fill bits come back.
+* :class:`HostJointState` -- the same interface in numpy over any ``loglike_batch`` scorer.  It
+  is the statement the device implementation is tested against (tests/), and what the CPU
+  tests run the orchestration with.
+
+Interface (``rows`` are ORIGINAL data-set indices, ascending; ``running`` likewise):
+
+    init(xs)                     score the initial live points (physical parameter rows)
+    set_running(running)         the data sets still being sampled (cut_down)
+    prepare() -> Lmin, argmin, keep     start of an iteration; keep[r, e] = shelf entry e of the
+                                        r-th running data set stays (bool matrix as wide as the
+                                        longest shelf; None when nothing was dropped anywhere)
+    draw(xs, rows) -> idx, Lrow, beats, nscored
+                                 first acceptable candidate of the chunk (or -1), its
+                                 likelihoods over ``rows``, which of them it beats; the state
+                                 takes the point in; ``nscored`` candidates were looked at
+    advance()                    end of an iteration
+    live_matrix() -> L[nlive, nrunning]
+"""
+import ctypes as C
+
+import numpy
+
+from . import _host, _lib
+
+
+class HostJointState(object):
+    """numpy statement of the joint state over ``scorer.loglike_batch(params[B, 3], mask)``
+    (``params`` rows are (A, mu, sig), ``mask`` a bool array over all data sets)."""
+
+    #: candidates scored at once grow 1, 2, 4 ... up to this (a CPU scorer pays per candidate)
+    MAX_CHUNK = 64
+
+    def __init__(self, scorer, nlive, ndata, to_kernel_params):
+        self.scorer = scorer
+        self.nlive, self.ndata = int(nlive), int(ndata)
+        self.to_kernel_params = to_kernel_params
+        self.live = None                                  # [nlive, ndata], all data sets ever
+        self.shelfL = [[] for _ in range(self.ndata)]
+        self.higher = numpy.full(self.ndata, numpy.nan)
+        self.running = numpy.arange(self.ndata)
+        self.argmin = numpy.zeros(self.ndata, dtype=int)
+        self.nevals_scored = 0
+        self.ncalls = 0
+
+    def init(self, xs):
+        self.live = numpy.array(self.scorer.loglike_batch(self.to_kernel_params(xs), numpy.ones(self.ndata, dtype=bool)))
+        self.nevals_scored += self.live.size
+        self.ncalls += 1
+        assert self.live.shape == (self.nlive, self.ndata)
+
+    def set_running(self, running):
+        self.running = numpy.asarray(running, dtype=int)
+
+    def _threshold(self, d):
+        n = len(self.shelfL[d])
+        merged = numpy.concatenate((self.live[:, d], self.shelfL[d]))
+        return numpy.partition(merged, n)[n]              # find_nsmallest, multi_nested_sampler.py:44-47
+
+    def prepare(self):
+        run = self.running
+        cols = self.live[:, run]
+        Lmin = cols.min(axis=0)
+        arg = cols.argmin(axis=0)
+        self.argmin[run] = arg
+        width = max([len(self.shelfL[d]) for d in run] + [0])
+        keep = numpy.zeros((len(run), width), dtype=bool)
+        dropped = False
+        for r, d in enumerate(run):
+            k = [L > Lmin[r] for L in self.shelfL[d]]
+            dropped = dropped or not all(k)
+            keep[r, :len(k)] = k
+            self.shelfL[d] = [L for L, kk in zip(self.shelfL[d], k) if kk]
+            self.higher[d] = self._threshold(d) if self.shelfL[d] else Lmin[r]
+        return Lmin, arg, (keep if dropped else None)
+
+    def draw(self, xs, rows):
+        rows = numpy.arange(self.ndata) if rows is None else numpy.asarray(rows, dtype=int)
+        mask = numpy.zeros(self.ndata, dtype=bool)
+        mask[rows] = True
+        thr = self.higher[rows]
+        params = self.to_kernel_params(xs)
+        pos, chunk = 0, 1
+        while pos < len(params):
+            Ls = self.scorer.loglike_batch(params[pos:pos + chunk], mask)
+            self.nevals_scored += Ls.size
+            self.ncalls += 1
+            ok = (Ls > thr).any(axis=1)
+            if ok.any():
+                i = int(numpy.argmax(ok))
+                Lrow = Ls[i]
+                beats = Lrow > thr
+                for d, L in zip(rows[beats], Lrow[beats]):
+                    self.shelfL[d].append(L)
+                    self.higher[d] = self._threshold(d)
+                return pos + i, Lrow, beats, pos + i + 1
+            pos += len(Ls)
+            chunk = min(self.MAX_CHUNK, 2 * chunk)
+        return -1, None, None, len(params)
+
+    def advance(self):
+        for d in self.running:
+            self.live[self.argmin[d], d] = self.shelfL[d].pop(0)
+
+    def live_matrix(self):
+        return self.live[:, self.running]
+
+    def thresholds(self):
+        return self.higher.copy(), numpy.array([len(s) for s in self.shelfL])
+
+
+class GaussJointState(object):
+    """The joint state of the Gaussian-line problem on the GPU, bound to a
+    :class:`massivedatans_amd.like.GaussLineSpectra` (include/mdns.h Part 2b)."""
+
+    #: (candidate, spectrum) pairs scored per chunk at most: ~50 us of GPU time
+    EVAL_BUDGET = 2560000
+    MIN_CHUNK = 32
+
+    def __init__(self, spectra, nlive, to_kernel_params, shelf_cap=64):
+        self._lib = _lib.require_device()
+        self.spectra = spectra                             # keeps the spectra handle alive
+        self.nlive, self.ndata = int(nlive), int(spectra.ndata)
+        self.noise_level = float(spectra.noise_level)
+        self.to_kernel_params = to_kernel_params
+        self._h = self._lib.mdns_joint_create(spectra.handle, self.nlive, int(shelf_cap))
+        if not self._h:
+            raise _lib.MdnsError("mdns_joint_create failed: " + _lib.last_error())
+        self.running = numpy.arange(self.ndata, dtype=numpy.int32)
+        self.shelf_n = numpy.zeros(self.ndata, dtype=numpy.int64)     # mirror of the device's shelf sizes
+        self.cap = self._lib.mdns_joint_shelf_cap(self._h)
+        self._Lrow = numpy.empty(self.ndata)
+        self._bits = numpy.zeros((self.ndata + 63) // 64, dtype=numpy.uint64)
+        self._accepted = C.c_int(-1)
+        self.nevals_scored = 0
+        self.ncalls = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mdns_joint_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise _lib.MdnsError("%s failed: %s" % (what, _lib.last_error()))
+
+    def init(self, xs):
+        params = _lib.as_f64(self.to_kernel_params(xs))
+        if params.shape != (self.nlive, 3):
+            raise ValueError("initial points must be [nlive, 3]")
+        self._check(self._lib.mdns_joint_init_gauss(self._h, _lib.ptr(params), self.noise_level), "mdns_joint_init_gauss")
+        self.shelf_n[:] = 0
+        self.nevals_scored += self.nlive * self.ndata
+        self.ncalls += 1
+
+    def set_running(self, running):
+        self.running = numpy.ascontiguousarray(running, dtype=numpy.int32)
+        self._check(self._lib.mdns_joint_set_running(self._h, _lib.ptr(self.running), len(self.running)),
+                    "mdns_joint_set_running")
+
+    def prepare(self):
+        n = len(self.running)
+        kw = self._lib.mdns_joint_keep_words(self._h)
+        Lmin = numpy.empty(n)
+        arg = numpy.empty(n, dtype=numpy.int32)
+        keepw = numpy.empty((n, kw), dtype=numpy.uint64)
+        self._check(self._lib.mdns_joint_prepare(self._h, _lib.ptr(Lmin), _lib.ptr(arg), _lib.ptr(keepw)),
+                    "mdns_joint_prepare")
+        counts = self.shelf_n[self.running]
+        keep = None
+        if counts.any():
+            # kept entries per data set = set bits; anything dropped shows as a smaller count
+            kept = numpy.zeros(n, dtype=numpy.int64)
+            for w in range(kw):
+                kept += _popcount(keepw[:, w])
+            if (kept != counts).any():
+                width = int(counts.max())
+                keep = numpy.zeros((n, width), dtype=bool)
+                for e in range(width):
+                    keep[:, e] = (keepw[:, e // 64] >> numpy.uint64(e % 64)) & numpy.uint64(1)
+                self.shelf_n[self.running] = kept
+        return Lmin, arg.astype(int), keep
+
+    def chunk_size(self, offered, M):
+        """How many of the offered candidates one launch scores."""
+        budget = max(self.MIN_CHUNK, self.EVAL_BUDGET // max(1, M))
+        return int(min(offered, budget, _lib.JOINT_MAX_BATCH))
+
+    def draw(self, xs, rows):
+        M = self.ndata if rows is None else len(rows)
+        B = self.chunk_size(len(xs), M)
+        params = _lib.as_f64(self.to_kernel_params(xs[:B]))
+        if rows is not None:
+            rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
+            nmax = int(self.shelf_n[rows].max()) if M else 0
+        else:
+            nmax = int(self.shelf_n.max())
+        if nmax + 1 > self.cap:
+            self._check(self._lib.mdns_joint_reserve(self._h, nmax + 1), "mdns_joint_reserve")
+            self.cap = self._lib.mdns_joint_shelf_cap(self._h)
+        self._check(self._lib.mdns_joint_draw_gauss(
+            self._h, _lib.ptr(params), B, self.noise_level, _lib.ptr(rows) if rows is not None else None, M,
+            C.byref(self._accepted), _lib.ptr(self._Lrow), _lib.ptr(self._bits)), "mdns_joint_draw_gauss")
+        self.ncalls += 1
+        idx = self._accepted.value
+        if idx < 0:
+            self.nevals_scored += B * M
+            return -1, None, None, B
+        self.nevals_scored += B * M
+        beats = numpy.unpackbits(self._bits[:(M + 63) // 64].view(numpy.uint8), bitorder='little')[:M].astype(bool)
+        if rows is None:
+            self.shelf_n[beats] += 1
+        else:
+            self.shelf_n[rows[beats]] += 1
+        return idx, self._Lrow[:M].copy(), beats, B
+
+    def advance(self):
+        self._check(self._lib.mdns_joint_advance(self._h), "mdns_joint_advance")
+        self.shelf_n[self.running] -= 1
+
+    def live_matrix(self):
+        full = numpy.empty((self.nlive, self.ndata))
+        self._check(self._lib.mdns_joint_get_live(self._h, _lib.ptr(full)), "mdns_joint_get_live")
+        if len(self.running) == self.ndata:
+            return full
+        return full[:, self.running]
+
+    def thresholds(self):
+        higher = numpy.empty(self.ndata)
+        n = numpy.empty(self.ndata, dtype=numpy.int32)
+        self._check(self._lib.mdns_joint_get_thresholds(self._h, _lib.ptr(higher), _lib.ptr(n)), "mdns_joint_get_thresholds")
+        return higher, n.astype(int)
+
+
+_POP8 = numpy.array([bin(i).count("1") for i in range(256)], dtype=numpy.int64)
+
+
+def _popcount(words):
+    """Set bits of every uint64 of ``words``."""
+    return _POP8[numpy.ascontiguousarray(words).view(numpy.uint8).reshape(len(words), 8)].sum(axis=1)
+
+
+__all__ = ['HostJointState', 'GaussJointState']

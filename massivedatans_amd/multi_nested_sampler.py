@@ -25,33 +25,19 @@ set the wall-clock.  None of this changes a single value (tests/test_orchestrati
 """
 import ctypes
 import logging
-import os
 from collections import defaultdict
 
 import numpy
 
 log = logging.getLogger("massivedatans_amd")
 
-_HOST_LIB = None
+from . import _host
 
 
 def _host_lib():
     """``libmdns_host.so`` (csrc/host_groups.c, plain C): the grouping walk as native host code.
     Optional -- without it the same walk runs in Python (``_walk_python``), 10-30x slower."""
-    global _HOST_LIB
-    if _HOST_LIB is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdns_host.so")
-        try:
-            lib = ctypes.CDLL(path)
-            lib.mdns_host_group_walk.restype = ctypes.c_int
-            lib.mdns_host_group_walk.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
-                                                 ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
-                                                 ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]
-            _HOST_LIB = lib
-        except OSError:
-            _HOST_LIB = False
-    return _HOST_LIB or None
+    return _host.lib()
 
 
 def find_nsmallest(n, arr1, arr2):
@@ -84,6 +70,19 @@ class _Shelves(object):
         keep = valid & (self.L > Lmins[:, None])
         if keep.sum() == valid.sum():
             return
+        self._compact(keep)
+
+    def purge_kept(self, kept):
+        """The same with the decision made elsewhere (the joint state on the device):
+        ``kept[d, e]`` says whether entry e of data set d stays."""
+        cap = self.p.shape[1]
+        valid = numpy.arange(cap)[None, :] < self.n[:, None]
+        keep = numpy.zeros((len(self.n), cap), dtype=bool)
+        keep[:, :kept.shape[1]] = kept[:, :cap]
+        self._compact(keep & valid)
+
+    def _compact(self, keep):
+        cap = self.p.shape[1]
         order = numpy.argsort(~keep, axis=1, kind='stable')       # kept entries first, in order
         self.p = numpy.take_along_axis(self.p, order, axis=1)
         self.L = numpy.take_along_axis(self.L, order, axis=1)
@@ -125,7 +124,7 @@ class MultiNestedSampler(object):
     def __init__(self, priortransform, multi_loglikelihood, superset_draw_constrained,
                  individual_draw_constrained, draw_constrained, ndata, ndim, nlive_points=200,
                  draw_global_uniform=None, nsuperset_draws=10, use_graph=False,
-                 multi_loglikelihood_batch=None):
+                 multi_loglikelihood_batch=None, joint_state=None, priortransform_batch=None):
         self.nlive_points = nlive_points
         self.nsuperset_draws = nsuperset_draws
         self.priortransform = priortransform
@@ -143,13 +142,23 @@ class MultiNestedSampler(object):
         self.point_data_map = None          # point id -> set of data sets holding it (lazy)
         #: likelihood evaluations = (candidate, data set) pairs actually scored
         self.nevals = 0
+        #: optional: an object keeping live_pointsL, the shelves' likelihoods and the thresholds
+        #: (massivedatans_amd.jointstate); a constrained draw is then scored AND decided there
+        self.joint = joint_state
+        self.priortransform_batch = priortransform_batch
+        self._live_cache = None
+        self.ndraw_calls = 0                # constrained draws made (accepted points)
+        self.ndraw_chunks = 0               # chunks of candidates handed to the joint state
 
         # nlive prior draws, every data set starts from the same points: all are superpoints
         # (multi_nested_sampler.py:88-103).  RNG: nlive x uniform(0, 1, ndim).
         all_mask = numpy.ones(ndata) == 1
         us = [self.draw_global_uniform() for _ in range(nlive_points)]
         xs = [priortransform(u) for u in us]
-        if multi_loglikelihood_batch is not None:
+        if self.joint is not None:
+            self.joint.init(numpy.array(xs))            # the matrix is computed where it stays
+            Ls = None
+        elif multi_loglikelihood_batch is not None:
             Ls = list(multi_loglikelihood_batch(numpy.array(xs), all_mask))
         else:
             Ls = [multi_loglikelihood(x, data_mask=all_mask) for x in xs]
@@ -161,13 +170,11 @@ class MultiNestedSampler(object):
         self.pointpile = self._pile_u
         self.pointpilex = self._pile_x
         self.live_pointsp = numpy.array([[p] * ndata for p in range(nlive_points)])
-        self.live_pointsL = numpy.array(Ls)
+        self._live_pointsL = numpy.array(Ls) if Ls is not None else None
         self.superpoints = set(range(nlive_points))
         # how many (live slot, data set) cells hold each point id: the distinct live points of
         # ALL data sets are the ids with a positive count (replaces numpy.unique over the matrix)
         self._refcount = numpy.full(nlive_points, ndata, dtype=int)
-        self.Lmax = self.live_pointsL.max(axis=0)
-        assert self.Lmax.shape == (ndata,)
         self.data_mask_all = numpy.ones(self.ndata) == 1
         self.real_data_mask_all = numpy.ones(self.ndata) == 1
         self.ndraws = nlive_points
@@ -183,6 +190,25 @@ class MultiNestedSampler(object):
     def shelves(self):
         return self._shelves.as_lists(self.pointpile, self.pointpilex)
 
+    @property
+    def live_pointsL(self):
+        """Likelihoods of the live points, [nlive, running data sets].  With a joint state the
+        matrix lives there (on the device) and is fetched when somebody asks."""
+        if self.joint is None:
+            return self._live_pointsL
+        if self._live_cache is None:
+            self._live_cache = self.joint.live_matrix()
+        return self._live_cache
+
+    @live_pointsL.setter
+    def live_pointsL(self, value):
+        self._live_pointsL = value
+
+    @property
+    def Lmax(self):
+        """Highest live likelihood per data set (multi_nested_sampler.py:112,532)."""
+        return self.live_pointsL.max(axis=0)
+
     def draw_global_uniform(self):
         return numpy.random.uniform(0, 1, size=self.ndim)
 
@@ -194,12 +220,17 @@ class MultiNestedSampler(object):
     def prepare(self):
         """Thresholds of this iteration and shelves purged of entries that no longer beat them
         (multi_nested_sampler.py:130-143)."""
-        L = self.live_pointsL
-        Lmins = L.min(axis=0)
-        Lmini = L.argmin(axis=0)
-        self._shelves.purge(Lmins)
+        if self.joint is not None:
+            Lmins, Lmini, kept = self.joint.prepare()
+            if kept is not None:
+                self._shelves.purge_kept(kept)
+        else:
+            L = self.live_pointsL
+            Lmins = L.min(axis=0)
+            Lmini = L.argmin(axis=0)
+            self._shelves.purge(Lmins)
         allp = numpy.flatnonzero(self._refcount[:len(self.pointpile)])
-        return self.pointpile[allp], allp, L.min(), Lmins, Lmini
+        return self.pointpile[allp], allp, Lmins.min(), Lmins, Lmini
 
     def cut_down(self, surviving):
         """Drop the data sets that finished (multi_nested_sampler.py:148-173)."""
@@ -208,14 +239,17 @@ class MultiNestedSampler(object):
             self._refcount -= numpy.bincount(dropped.ravel(), minlength=len(self._refcount))
         self.live_pointsp = self.live_pointsp[:, surviving]
         self._lpT = None
-        self.live_pointsL = self.live_pointsL[:, surviving]
+        if self.joint is None:
+            self._live_pointsL = self._live_pointsL[:, surviving]
+        self._live_cache = None
         self._shelves.select(surviving)
         self.ndata = surviving.sum()
-        self.Lmax = self.live_pointsL.max(axis=0)
         self.data_mask_all = numpy.ones(self.ndata) == 1
         # in place: constrainer caches hold a reference to this array
         self.real_data_mask_all[self.real_data_mask_all] = surviving
         self._real_indices = None
+        if self.joint is not None:
+            self.joint.set_running(numpy.flatnonzero(self.real_data_mask_all))
 
         def expand(mask):
             full = self.real_data_mask_all.copy()
@@ -485,7 +519,7 @@ class MultiNestedSampler(object):
             empty = self._shelves.empty()
             if not empty.any():
                 return
-            if passes == 1:
+            if passes == 1 and self.joint is None:
                 # thresholds of this iteration (only needed when something has to be drawn)
                 self._higher = Lmins.copy()
                 self._low = None
@@ -515,7 +549,7 @@ class MultiNestedSampler(object):
                 max_draws = 100000 if (njoints == 1 and self._shelves.n[firstd] == 0) else 1000
                 if len(groups) > 1 and not focussed and (self._shelves.n[joint_indices] > 0).all():
                     continue                      # this group needs nothing
-                Lmins_higher = self._higher[joint_indices].copy()
+                Lmins_higher = self._higher[joint_indices].copy() if self.joint is None else None
                 if self._real_indices is None:        # original index of every running data set
                     self._real_indices = numpy.where(self.real_data_mask_all)[0]
                 real_indices = self._real_indices
@@ -528,7 +562,13 @@ class MultiNestedSampler(object):
                     draw = self.superset_draw_constrained
 
                 extra = {}
-                if self.multi_loglikelihood_batch is not None:
+                if self.joint is not None:
+                    # the whole chunk of proposed candidates goes to the joint state, which
+                    # answers with the first acceptable one (thresholds and accept test there)
+                    rows = None if njoints == len(real_indices) == self.joint.ndata else real_indices[joint_indices]
+                    last = {}
+                    extra['draw_batch'] = lambda us, rows=rows, last=last: self._draw_batch(us, rows, last)
+                elif self.multi_loglikelihood_batch is not None:
                     extra['loglikelihood_batch'] = \
                         lambda ps, m=joint_data_mask: self.multi_loglikelihood_batch(ps, m)
                     extra['mask_key'] = (self.ndata, joint_data_mask.tobytes())
@@ -540,6 +580,7 @@ class MultiNestedSampler(object):
                     iter=self.global_iter, nlive_points=self.nlive_points, **extra)
 
                 self.ndraws += int(n)
+                self.ndraw_calls += 1
                 self.nevals += int(n) * njoints
                 ppi = len(self.pointpile)
                 if ppi == len(self._pile_u):
@@ -550,15 +591,34 @@ class MultiNestedSampler(object):
                 self._pile_x[ppi] = xj
                 self.pointpile = self._pile_u[:ppi + 1]
                 self.pointpilex = self._pile_x[:ppi + 1]
-                beats = Lj > Lmins_higher
-                self._shelves.append(joint_indices[beats], ppi, Lj[beats])
-                self._refresh_thresholds(joint_indices[beats])
+                if self.joint is not None:
+                    beats = last['beats']             # decided where the thresholds are
+                    self._shelves.append(joint_indices[beats], ppi, Lj[beats])
+                else:
+                    beats = Lj > Lmins_higher
+                    self._shelves.append(joint_indices[beats], ppi, Lj[beats])
+                    self._refresh_thresholds(joint_indices[beats])
                 nfilled = int(beats.sum())
                 if len(self._refcount) <= ppi:
                     self._refcount = numpy.concatenate((self._refcount, numpy.zeros(max(1024, ppi), dtype=int)))
                 if nfilled == self.ndata:
                     self.superpoints.add(ppi)
                 log.debug('iteration %d: accepted after %d tries, filled %d shelves', self.global_iter, n, nfilled)
+
+    def _draw_batch(self, us, rows, last):
+        """One chunk of proposed unit-cube candidates through the joint state: returns
+        (index of the first acceptable one or -1, its physical parameters, its likelihood row,
+        how many candidates were looked at)."""
+        if self.priortransform_batch is not None:
+            xs = self.priortransform_batch(us)
+        else:
+            xs = numpy.array([self.priortransform(u) for u in us])
+        idx, Lrow, beats, nscored = self.joint.draw(xs, rows)
+        self.ndraw_chunks += 1
+        if idx < 0:
+            return -1, None, None, nscored
+        last['beats'] = beats
+        return idx, xs[idx], Lrow, nscored
 
     def __next__(self):
         allu, allp, _, Lmins, Lmini = self.prepare()
@@ -570,7 +630,7 @@ class MultiNestedSampler(object):
         dead = self.live_pointsp[Lmini, every]
         uis = self.pointpile[dead]
         xis = self.pointpilex[dead]
-        Lis = self.live_pointsL[Lmini, every]
+        Lis = Lmins if self.joint is not None else self.live_pointsL[Lmini, every]
         if self.point_data_map is not None:
             for d, pj in enumerate(dead):
                 self.point_data_map[pj].remove(d)
@@ -579,14 +639,16 @@ class MultiNestedSampler(object):
         newp, newL = self._shelves.pop_heads()
         self.live_pointsp[Lmini, every] = newp
         self._lpT = None
-        self.live_pointsL[Lmini, every] = newL
+        if self.joint is not None:
+            self.joint.advance()
+            self._live_cache = None
+        else:
+            self._live_pointsL[Lmini, every] = newL
         self._refcount -= numpy.bincount(dead, minlength=len(self._refcount))
         self._refcount += numpy.bincount(newp, minlength=len(self._refcount))
         if self.point_data_map is not None:
             for d, pj in enumerate(newp):
                 self.point_data_map[pj].add(d)
-        self.Lmax = self.live_pointsL.max(axis=0)
-        assert self.Lmax.shape == (self.ndata,)
         return numpy.asarray(uis), numpy.asarray(xis), numpy.asarray(Lis)
 
     next = __next__

@@ -22,7 +22,7 @@ import time
 
 import numpy
 
-from . import cachedconstrainer
+from . import _host, cachedconstrainer
 from .cachedconstrainer import CachedConstrainer, generate_individual_constrainer
 from .multi_nested_integrator import multi_nested_integrator
 from .multi_nested_sampler import MultiNestedSampler
@@ -40,6 +40,26 @@ def priortransform(cube):
     cube[1] = cube[1] * 400 + 400
     cube[2] = cube[2] * 2
     return cube
+
+
+def priortransform_batch(cubes):
+    """``priortransform`` for the rows of ``cubes[B, 3]``, value for value (the products and sums
+    are single IEEE operations either way; the powers go through the same C ``pow`` as the
+    scalar ``**``, tests/test_sampler_units.py)."""
+    cubes = numpy.asarray(cubes, dtype=float)
+    out = numpy.empty_like(cubes)
+    out[:, 0] = _host.pow10(cubes[:, 0] * 2 - 2)
+    out[:, 1] = cubes[:, 1] * 400 + 400
+    out[:, 2] = cubes[:, 2] * 2
+    return out
+
+
+def kernel_params(xs):
+    """Rows (A, mu, log10 sig) after the prior transform -> (A, mu, sig) as the kernels take
+    them: ``sig = 10**log_sig`` of sample.py:103."""
+    p = numpy.array(xs, dtype=float)
+    p[:, 2] = _host.pow10(p[:, 2])
+    return p
 
 
 class GaussLineProblem(object):
@@ -69,18 +89,30 @@ class GaussLineProblem(object):
 
     def multi_loglikelihood_batch(self, params, data_mask):
         """Rows of ``params`` are (A, mu, log10 sig) after priortransform."""
-        p = numpy.array(params, dtype=float)
-        # scalar pow per row: numpy's vectorised power may differ from the scalar one (which
-        # sample.py:103 uses) in the last bit
-        p[:, 2] = [10 ** v for v in p[:, 2]]
-        L = self.backend.loglike_batch(p, data_mask)
+        # (C pow per row: numpy's vectorised power may differ from the scalar one, which
+        # sample.py:103 uses, in the last bit)
+        L = self.backend.loglike_batch(kernel_params(params), data_mask)
         self.ncalls += 1
         self.nevals += L.size
         return L
 
 
-def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False, seed=1, batched=True):
-    """Constrainers + sampler wired as sample.py:131-194 (CONSTRAINER=MLFRIENDS)."""
+    def joint_state(self, nlive_points):
+        """The sampler's floating-point state next to the spectra: on the GPU for the HIP
+        backend (accept test and shelf fill there), in numpy over any other
+        scorer."""
+        from . import jointstate
+        from .like import GaussLineSpectra
+        if isinstance(self.backend, GaussLineSpectra):
+            return jointstate.GaussJointState(self.backend, nlive_points, kernel_params)
+        return jointstate.HostJointState(self.backend, nlive_points, self.ndata, kernel_params)
+
+
+def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False, seed=1, batched=True,
+                  fused=False):
+    """Constrainers + sampler wired as sample.py:131-194 (CONSTRAINER=MLFRIENDS).  ``fused``: the
+    likelihood matrix, the shelves' likelihoods and the thresholds live in a joint state
+    (``problem.joint_state``) and whole chunks of candidates are scored and decided there."""
     cachedconstrainer.generate_fresh_constrainer = cachedconstrainer.generate_fresh_constrainer_mlfriends
     superset_constrainer = cachedconstrainer.generate_fresh_constrainer_mlfriends()
     cc = CachedConstrainer()
@@ -92,18 +124,23 @@ def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False
         superset_draw_constrained=superset_constrainer.draw_constrained,
         individual_draw_constrained=individual_draw_constrained,
         draw_constrained=cc.get, nsuperset_draws=nsuperset_draws, use_graph=use_graph,
-        multi_loglikelihood_batch=problem.multi_loglikelihood_batch if batched else None)
+        multi_loglikelihood_batch=problem.multi_loglikelihood_batch if batched else None,
+        joint_state=problem.joint_state(nlive_points) if fused else None,
+        priortransform_batch=priortransform_batch if fused else None)
     superset_constrainer.sampler = sampler
     cc.sampler = sampler
     return sampler
 
 
 def run(x, y, nlive_points=400, nsuperset_draws=10, use_graph=False, max_samples=0, min_samples=0,
-        tolerance=0.5, seed=1, backend=None, batched=True):
-    """The whole analysis; returns ``(results, sampler, problem, duration)``."""
+        tolerance=0.5, seed=1, backend=None, batched=True, fused=None):
+    """The whole analysis; returns ``(results, sampler, problem, duration)``.  ``fused`` defaults to
+    True on the GPU (MDNS_FUSED=0 turns it off)."""
     problem = GaussLineProblem(x, y, backend=backend)
+    if fused is None:
+        fused = backend is None and os.environ.get('MDNS_FUSED', '1') != '0'
     start = time.time()
-    sampler = build_sampler(problem, nlive_points, nsuperset_draws, use_graph, seed, batched)
+    sampler = build_sampler(problem, nlive_points, nsuperset_draws, use_graph, seed, batched, fused)
     results = multi_nested_integrator(tolerance=tolerance, multi_sampler=sampler,
                                       min_samples=min_samples, max_samples=max_samples)
     return results, sampler, problem, time.time() - start

@@ -271,13 +271,15 @@ def test_geometry_full_size_properties(nb):
 
 
 # ---------------------------------------------------------------- end to end ---------------
+@pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("case", ["nothing4", "horns3", "horns12", "horns100"])
-def test_end_to_end_against_reference_trace(case):
+def test_end_to_end_against_reference_trace(case, fused):
     """The whole analysis on the GPU (HIP likelihood + HIP geometry + host orchestration) against
     the trace recorded from the reference's Python + C.  Geometry is bit-exact and likelihoods
     agree to ~1e-15, so the integer bookkeeping is expected to coincide (a last-bit tie in an
     accept test could fork a run; none occurs in these cases) and the evidences must agree within
-    the 1e-6 relative bar of BASELINE.json."""
+    the 1e-6 relative bar of BASELINE.json.  ``fused``: live-point likelihoods, shelves, thresholds,
+    accept test and shelf fill on the device (mdns_joint_*), one launch sequence per draw chunk."""
     import os
     from massivedatans_amd import sample
     from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
@@ -288,10 +290,12 @@ def test_end_to_end_against_reference_trace(case):
     data = (gen.horns if "horns" in case else gen.nothing)(ndata)
     problem = sample.GaussLineProblem(data["x"], data["y"])          # HIP backend
     sampler = sample.build_sampler(problem, nlive_points=nlive, nsuperset_draws=int(g["nsuperset_draws"]),
-                                   use_graph=False, seed=1, batched=True)
+                                   use_graph=False, seed=1, batched=True, fused=fused)
     with np.errstate(all="ignore"):
         results = multi_nested_integrator(tolerance=0.5, multi_sampler=sampler, min_samples=0,
                                           max_samples=int(g["max_samples"]))
+    if fused:
+        assert type(sampler.joint).__name__ == "GaussJointState"
     assert sampler.ndraws == int(g["ndraws"])
     assert np.array_equal(sampler.live_pointsp, g["final_live_pointsp"])
     assert rel_err(sampler.live_pointsL, g["final_live_pointsL"]) < 1e-12

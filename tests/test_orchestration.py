@@ -34,33 +34,37 @@ class Recorder(object):
         return u, x, L
 
 
-def run_case(g, oracle, batched):
+def run_case(g, oracle, batched, fused=False):
     from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
     ndata, nlive = int(g["ndata"]), int(g["nlive"])
     name = "horns" if "horns" in g["_name"] else "nothing"
     data = (gen.horns if name == "horns" else gen.nothing)(ndata)
     problem = sample.GaussLineProblem(data["x"], data["y"], backend=OracleSpectra(oracle, data["x"], data["y"]))
     sampler = sample.build_sampler(problem, nlive_points=nlive, nsuperset_draws=int(g["nsuperset_draws"]),
-                                   use_graph=False, seed=1, batched=batched)
+                                   use_graph=False, seed=1, batched=batched, fused=fused)
     rec = Recorder(sampler)
     results = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0,
                                       max_samples=int(g["max_samples"]))
     return results, sampler, rec, np.random.uniform()
 
 
+# "fused": the likelihood matrix, the shelves' likelihoods, thresholds, accept test and shelf fill
+# sit in a joint state (jointstate.HostJointState here: the numpy statement of what the GPU
+# does) and the constrainers hand over whole chunks of candidates
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("batched", [False, True])
-def test_trace_bit_exact(case, batched, oracle, monkeypatch):
+@pytest.mark.parametrize("mode", ["single", "batched", "fused"])
+def test_trace_bit_exact(case, mode, oracle, monkeypatch):
     with np.load(os.path.join(ROOT, "tests", "golden", "trace_%s.npz" % case)) as f:
         g = {k: f[k] for k in f.files}
     g["_name"] = case
-    if case == "horns6" and batched:
+    batched = mode != "single"
+    if case == "horns6" and mode != "single":
         pytest.skip("242k draws: run once, unbatched")
-    if case == "horns100" and not batched:
-        pytest.skip("44k draws: run once, batched")
+    if case == "horns100" and mode == "single":
+        pytest.skip("44k draws: run batched and fused")
     patch_neighbors(monkeypatch, oracle)
     with np.errstate(all="ignore"):
-        results, sampler, rec, rng_probe = run_case(g, oracle, batched)
+        results, sampler, rec, rng_probe = run_case(g, oracle, batched, fused=(mode == "fused"))
     # integer bookkeeping
     assert np.array_equal(np.array([len(L) for L in rec.Ls]), g["iter_nrunning"])
     assert np.array_equal(np.array(rec.ndraws_after), g["iter_ndraws"])

@@ -188,11 +188,11 @@ def test_native_grouping_walk_equals_python_walk():
             mask[:2] = True
         s = _fake_sampler(lp, npoints, nlive)
         native = [(m.copy(), np.asarray(p).copy()) for m, p in s.generate_subsets_nograph(mask, None)]
-        lib, mns._HOST_LIB = mns._HOST_LIB, False                              # force the Python walk
+        lib, mns._host._LIB = mns._host._LIB, False                            # force the Python walk
         try:
             python = [(m.copy(), np.asarray(p).copy()) for m, p in s.generate_subsets_nograph(mask, None)]
         finally:
-            mns._HOST_LIB = lib
+            mns._host._LIB = lib
         assert len(native) == len(python)
         for (m1, p1), (m2, p2) in zip(native, python):
             assert np.array_equal(m1, m2)
