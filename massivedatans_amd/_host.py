@@ -22,6 +22,16 @@ def lib():
                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]
+            L.mdns_host_walk_create.restype = ctypes.c_void_p
+            L.mdns_host_walk_create.argtypes = []
+            L.mdns_host_walk_destroy.restype = None
+            L.mdns_host_walk_destroy.argtypes = [ctypes.c_void_p]
+            L.mdns_host_walk_reset.restype = ctypes.c_int
+            L.mdns_host_walk_reset.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64]
+            L.mdns_host_walk_groups.restype = ctypes.c_int
+            L.mdns_host_walk_groups.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                                ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                                ctypes.c_int64]
             L.mdns_host_bootstrap_masks.restype = ctypes.c_int
             L.mdns_host_bootstrap_masks.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_void_p]
             L.mdns_host_pow10.restype = None

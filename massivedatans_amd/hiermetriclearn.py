@@ -182,7 +182,7 @@ class MetricLearningFriendsConstrainer(object):
 
     def _draw_chunks(self, draw_batch, live_pointsu, ndim, region_rebuilt, metric_rebuilt):
         """The accept loop of hiermetriclearn.py:181-211 with the candidates handed over in
-        chunks: ``draw_batch(us) -> (index of the first acceptable candidate or -1, x, L, number
+        chunks: ``draw_batch(us, expected_tries) -> (index of the first acceptable candidate or -1, x, L, number
         of candidates looked at)`` scores a run of ALREADY proposed candidates and takes the
         accept decision where the thresholds are (the GPU).  A chunk never reaches past the
         candidate after which the reference would rebuild its region (hiermetriclearn.py:198-211),
@@ -202,7 +202,9 @@ class MetricLearningFriendsConstrainer(object):
             if not metric_rebuilt:
                 room = min(room, max(1, 201 - tries))
             chunk = self._buf[self._buf_pos:self._buf_pos + room]
-            idx, x, L, nscored = draw_batch(chunk)
+            # (how many of them are looked at at once is the scorer's choice: it is told how many
+            # tries the previous draw of this constrainer needed)
+            idx, x, L, nscored = draw_batch(chunk, max(1, getattr(self, '_last_ntoaccept', 1)))
             used = idx + 1 if idx >= 0 else nscored
             assert 0 < used <= room
             tries += used

@@ -85,6 +85,9 @@ class HostJointState(object):
             self.higher[d] = self._threshold(d) if self.shelfL[d] else Lmin[r]
         return Lmin, arg, (keep if dropped else None)
 
+    def chunk_size(self, offered, M, hint=None):
+        return offered
+
     def draw(self, xs, rows):
         rows = numpy.arange(self.ndata) if rows is None else numpy.asarray(rows, dtype=int)
         mask = numpy.zeros(self.ndata, dtype=bool)
@@ -198,14 +201,17 @@ class GaussJointState(object):
                 self.shelf_n[self.running] = kept
         return Lmin, arg.astype(int), keep
 
-    def chunk_size(self, offered, M):
-        """How many of the offered candidates one launch scores."""
+    def chunk_size(self, offered, M, hint=None):
+        """How many of the offered candidates one launch scores: four times the tries the last
+        draw needed (``hint``), within a budget of (candidate, spectrum) pairs."""
         budget = max(self.MIN_CHUNK, self.EVAL_BUDGET // max(1, M))
+        if hint is not None:
+            budget = min(budget, max(self.MIN_CHUNK, 4 * int(hint)))
         return int(min(offered, budget, _lib.JOINT_MAX_BATCH))
 
     def draw(self, xs, rows):
         M = self.ndata if rows is None else len(rows)
-        B = self.chunk_size(len(xs), M)
+        B = min(len(xs), _lib.JOINT_MAX_BATCH)
         params = _lib.as_f64(self.to_kernel_params(xs[:B]))
         if rows is not None:
             rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)

@@ -182,9 +182,18 @@ class MultiNestedSampler(object):
         self._real_indices = None
         self._lpT = None                    # live_pointsp relabelled + transposed, for the native grouping walk
         self._alive = None
-        self._label = numpy.zeros(1024, dtype=numpy.int64)
+        self._label = numpy.zeros(1024, dtype=numpy.int32)
+        self._walk = None                   # native incremental grouping walk (csrc/host_groups.c)
         self._low = None                    # smallest live likelihoods per data set (_refresh_thresholds)
         self._low_cap = -1
+
+    def __del__(self):
+        try:
+            if self._walk:
+                _host.lib().mdns_host_walk_destroy(self._walk)
+                self._walk = None
+        except Exception:
+            pass
 
     @property
     def shelves(self):
@@ -304,7 +313,7 @@ class MultiNestedSampler(object):
         is one component of a thousand data sets and tens of thousands of points, of which a
         few hundred bring somebody in."""
         lib = _host_lib()
-        if lib is not None and self.live_pointsp.dtype == numpy.int64:
+        if lib is not None:
             for g in self._groups_native(lib, data_mask):
                 yield g
             return
@@ -317,8 +326,10 @@ class MultiNestedSampler(object):
             yield g
 
     def _groups_native(self, lib, data_mask):
-        """One call of the native walk gives the distinct ids AND the groups; the cases that
-        need no decomposition (multi_nested_sampler.py:206-235) are decided afterwards."""
+        """The native walk (csrc/host_groups.c), incremental over the passes of an iteration:
+        the id -> holders index is built for the first selection of the iteration and re-used
+        while the selections shrink.  The cases that need no decomposition
+        (multi_nested_sampler.py:206-235) are decided there from the number of distinct ids."""
         nsel = int(numpy.count_nonzero(data_mask))
         if nsel == 1:
             yield data_mask, self.live_pointsp[:, numpy.flatnonzero(data_mask)[0]]
@@ -330,40 +341,76 @@ class MultiNestedSampler(object):
             # arrays must be as long as the ids in use, not as the pile.
             self._alive = numpy.flatnonzero(self._refcount[:len(self.pointpile)])
             if len(self._label) < len(self.pointpile):
-                self._label = numpy.zeros(max(2 * len(self._label), len(self.pointpile) + 1024), dtype=numpy.int64)
-            self._label[self._alive] = numpy.arange(len(self._alive))
+                self._label = numpy.zeros(max(2 * len(self._label), len(self.pointpile) + 1024), dtype=numpy.int32)
+            self._label[self._alive] = numpy.arange(len(self._alive), dtype=numpy.int32)
             self._lpT = numpy.ascontiguousarray(self._label[self.live_pointsp.T])
-            # per-id work arrays of the walk: it hands them back zeroed after every call
-            self._walk_work = (numpy.zeros(len(self._alive), dtype=numpy.int32),
-                               numpy.empty(len(self._alive), dtype=numpy.int64),
-                               numpy.zeros(len(self._alive), dtype=numpy.uint8),
-                               numpy.empty(len(self._alive), dtype=numpy.int64))
+            if self._walk is None:
+                self._walk = lib.mdns_host_walk_create()
+                if not self._walk:
+                    raise MemoryError("mdns_host_walk_create")
+            if lib.mdns_host_walk_reset(self._walk, self._lpT.ctypes.data, self._lpT.shape[1], self._lpT.shape[0],
+                                        len(self._alive)) != 0:
+                raise MemoryError("mdns_host_walk_reset")
         lp = self._lpT
         alive = self._alive
+        ndata, nlive = lp.shape
+        mask8 = numpy.ascontiguousarray(data_mask, dtype=numpy.uint8)
+        group_of = numpy.empty(ndata, dtype=numpy.int32)
+        offsets = numpy.empty(ndata + 1, dtype=numpy.int64)
+        ndistinct = ctypes.c_int64(0)
+        cap = min(len(alive), nsel * nlive) + nlive
+        trivial = 1 if len(self.superpoints) > 0 else 0
+        while True:
+            points = numpy.empty(cap, dtype=numpy.int32)
+            n = lib.mdns_host_walk_groups(self._walk, mask8.ctypes.data, group_of.ctypes.data, points.ctypes.data, cap,
+                                          offsets.ctypes.data, ctypes.byref(ndistinct), trivial, 2 * self.nlive_points)
+            if n != -2:
+                break
+            cap = nsel * nlive                        # columns with repeated ids: the safe bound
+        if n < 0:
+            raise MemoryError("mdns_host_walk_groups")
+        if n == 0:
+            # some points are shared by all, or there are few of them: one group, ids ascending
+            # (labels ascend with the ids)
+            yield data_mask, alive[points[:ndistinct.value]]
+        elif n == 1:
+            yield data_mask.copy(), alive[points[:offsets[1]]]
+        else:
+            for g in range(n):
+                yield group_of == g, alive[points[offsets[g]:offsets[g + 1]]]
+
+    def _groups_native_stateless(self, lib, data_mask):
+        """The same through the stateless entry point (one index build per call); kept as the
+        statement the incremental walk is tested against."""
+        nsel = int(numpy.count_nonzero(data_mask))
+        if nsel == 1:
+            yield data_mask, self.live_pointsp[:, numpy.flatnonzero(data_mask)[0]]
+            return
+        alive = numpy.flatnonzero(self._refcount[:len(self.pointpile)])
+        label = numpy.zeros(len(self.pointpile) + 1, dtype=numpy.int64)
+        label[alive] = numpy.arange(len(alive))
+        lp = numpy.ascontiguousarray(label[self.live_pointsp.T])
         ndata, nlive = lp.shape
         npoints = len(alive)
         mask8 = numpy.ascontiguousarray(data_mask, dtype=numpy.uint8)
         group_of = numpy.empty(ndata, dtype=numpy.int32)
         offsets = numpy.empty(ndata + 1, dtype=numpy.int64)
-        cnt, first, known, distinct = self._walk_work
+        cnt = numpy.zeros(npoints, dtype=numpy.int32)
+        first = numpy.empty(npoints, dtype=numpy.int64)
+        known = numpy.zeros(npoints, dtype=numpy.uint8)
+        distinct = numpy.empty(npoints, dtype=numpy.int64)
         ndistinct = ctypes.c_int64(0)
-        cap = min(npoints, nsel * nlive) + nlive
+        cap = nsel * nlive + nlive
         want_sorted = 1 if len(self.superpoints) > 0 else 0
-        while True:
-            points = numpy.empty(cap, dtype=numpy.int64)
-            n = lib.mdns_host_group_walk(lp.ctypes.data, nlive, ndata, mask8.ctypes.data, npoints,
-                                         cnt.ctypes.data, first.ctypes.data, known.ctypes.data,
-                                         group_of.ctypes.data, points.ctypes.data, cap, offsets.ctypes.data,
-                                         distinct.ctypes.data, ctypes.byref(ndistinct), want_sorted,
-                                         2 * self.nlive_points)
-            if n != -2:
-                break
-            cap = nsel * nlive                        # columns with repeated ids: the safe bound
+        points = numpy.empty(cap, dtype=numpy.int64)
+        n = lib.mdns_host_group_walk(lp.ctypes.data, nlive, ndata, mask8.ctypes.data, npoints,
+                                     cnt.ctypes.data, first.ctypes.data, known.ctypes.data,
+                                     group_of.ctypes.data, points.ctypes.data, cap, offsets.ctypes.data,
+                                     distinct.ctypes.data, ctypes.byref(ndistinct), want_sorted,
+                                     2 * self.nlive_points)
         if n < 0:
             raise MemoryError("mdns_host_group_walk")
         if ndistinct.value < 2 * self.nlive_points or len(self.superpoints) > 0:
-            # some points are shared by all: one group, ids ascending (the walk sorted them for
-            # exactly these two cases; labels ascend with the ids)
             yield data_mask, alive[distinct[:ndistinct.value]]
         elif n == 1:
             yield data_mask.copy(), alive[points[:offsets[1]]]
@@ -567,7 +614,7 @@ class MultiNestedSampler(object):
                     # answers with the first acceptable one (thresholds and accept test there)
                     rows = None if njoints == len(real_indices) == self.joint.ndata else real_indices[joint_indices]
                     last = {}
-                    extra['draw_batch'] = lambda us, rows=rows, last=last: self._draw_batch(us, rows, last)
+                    extra['draw_batch'] = lambda us, hint, rows=rows, last=last: self._draw_batch(us, rows, last, hint)
                 elif self.multi_loglikelihood_batch is not None:
                     extra['loglikelihood_batch'] = \
                         lambda ps, m=joint_data_mask: self.multi_loglikelihood_batch(ps, m)
@@ -605,10 +652,11 @@ class MultiNestedSampler(object):
                     self.superpoints.add(ppi)
                 log.debug('iteration %d: accepted after %d tries, filled %d shelves', self.global_iter, n, nfilled)
 
-    def _draw_batch(self, us, rows, last):
+    def _draw_batch(self, us, rows, last, hint):
         """One chunk of proposed unit-cube candidates through the joint state: returns
         (index of the first acceptable one or -1, its physical parameters, its likelihood row,
         how many candidates were looked at)."""
+        us = us[:self.joint.chunk_size(len(us), self.joint.ndata if rows is None else len(rows), hint)]
         if self.priortransform_batch is not None:
             xs = self.priortransform_batch(us)
         else:

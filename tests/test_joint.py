@@ -68,6 +68,7 @@ def _drive(dev, host, ndata, rng, iterations, exact):
             assert np.array_equal(hn[running], hm[running])
             assert np.array_equal(ha[running], hb[running]) if exact else np.allclose(ha[running], hb[running], rtol=1e-12)
             sel = None if len(rows) == ndata else rows
+            xs = xs[:dev.chunk_size(len(xs), len(rows), hint=int(rng.randint(1, 80)))]
             ia, La, ba, na = dev.draw(xs, sel)
             ib, Lb, bb, nb_ = host.draw(xs[:na], sel)
             assert ia == ib, (it, passes, ia, ib)

@@ -155,8 +155,8 @@ def _fake_sampler(lp, npoints, nlive):
     s.ndata = lp.shape[1]
     s._lpT = None
     s._alive = None
-    s._walk_work = None
-    s._label = np.zeros(16, dtype=np.int64)
+    s._walk = None
+    s._label = np.zeros(16, dtype=np.int32)
     s._refcount = np.bincount(lp.ravel(), minlength=npoints)
     return s
 
@@ -218,3 +218,53 @@ def test_bootstrap_choice_consumes_the_rng_like_the_reference():
             masks = draw_bootstrap_masks(n, B)
             assert np.random.uniform() == after_want
             assert np.array_equal(unpack_bootstrap_masks(masks, B), want)
+
+
+def test_incremental_grouping_walk_on_shrinking_selections():
+    """The passes of one iteration ask for the groups of smaller and smaller selections of the
+    same id matrix: the incremental native walk (one holder index per iteration, counts kept up
+    to date) against the stateless one and against the Python statement, pass by pass --
+    including selections that are NOT subsets of the previous one (a new base) and the cases
+    without decomposition (few distinct ids; superpoints)."""
+    from massivedatans_amd import multi_nested_sampler as mns
+    lib = mns._host_lib()
+    if lib is None:
+        import pytest
+        pytest.skip("libmdns_host.so not built")
+    rng = np.random.RandomState(8)
+    splits = 0
+    for trial in range(30):
+        nlive = int(rng.randint(2, 9))
+        ndata = int(rng.randint(4, 90))
+        nclusters = int(rng.randint(1, 6))
+        pools = [np.arange(c * 60, c * 60 + rng.randint(nlive, 60)) for c in range(nclusters)]
+        lp = np.empty((nlive, ndata), dtype=np.int64)
+        for d in range(ndata):
+            pool = pools[rng.randint(nclusters)]
+            if rng.uniform() < 0.15:
+                pool = np.arange(2000 + 10 * d, 2000 + 10 * d + nlive)
+            lp[:, d] = rng.choice(pool, size=nlive, replace=False)
+        s = _fake_sampler(lp, int(lp.max()) + 1, nlive)
+        if trial % 7 == 3:
+            s.superpoints = {int(lp[0, 0])}                  # "some points are shared by all"
+        mask = np.ones(ndata, dtype=bool)
+        for step in range(25):
+            if mask.sum() < 2:
+                break
+            inc = [(m.copy(), np.asarray(p).copy()) for m, p in s._groups_native(lib, mask)]
+            ref = [(m.copy(), np.asarray(p).copy()) for m, p in s._groups_native_stateless(lib, mask)]
+            held = None
+            triv, allp, held = s._trivial_groups(mask, None)
+            py = triv if triv is not None else list(s._walk_python(mask, held))
+            assert len(inc) == len(ref) == len(py)
+            for (m1, p1), (m2, p2), (m3, p3) in zip(inc, ref, py):
+                assert np.array_equal(m1, m2) and np.array_equal(p1, p2)
+                assert np.array_equal(m1, m3) and np.array_equal(p1, np.asarray(p3))
+            splits += len(inc) > 1
+            if step % 9 == 8:
+                mask = rng.uniform(size=ndata) < 0.8         # not a subset: a new base
+            else:
+                leave = rng.choice(np.flatnonzero(mask), size=max(1, int(mask.sum() * rng.choice([0.05, 0.3]))), replace=False)
+                mask = mask.copy()
+                mask[leave] = False
+    assert splits > 10

@@ -28,7 +28,8 @@ def _beat():
 threading.Thread(target=_beat, daemon=True).start()
 def _go():
     with np.errstate(all="ignore"):
-        return sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap, use_graph=False)
+        return sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap, use_graph=False,
+                          fused=os.environ.get("MDNS_FUSED", "1") != "0")
 if os.environ.get("MDNS_E2E_PROFILE") == "1":        # cProfile of the whole run, top entries on stderr
     import cProfile, pstats
     prof = cProfile.Profile()
@@ -40,6 +41,9 @@ _live["done"] = True
 print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nlive, cap), "wall_s": duration,
                   "setup_s": time.time() - t0 - duration, "iterations": int(results["nsamples"]),
                   "ndraws": int(sampler.ndraws), "evals_useful": int(sampler.nevals),
-                  "evals_scored": int(problem.nevals), "launches": int(problem.ncalls),
-                  "useful_evals_per_s": sampler.nevals / duration, "scored_evals_per_s": problem.nevals / duration,
+                  "evals_scored": int(problem.nevals + (sampler.joint.nevals_scored if sampler.joint is not None else 0)),
+                  "launches": int(problem.ncalls + (sampler.joint.ncalls if sampler.joint is not None else 0)),
+                  "fused": sampler.joint is not None, "constrained_draws": int(sampler.ndraw_calls),
+                  "draw_chunks": int(sampler.ndraw_chunks),
+                  "useful_evals_per_s": sampler.nevals / duration,
                   "logZ_first3": results["logZ"][:3].tolist()}))
