@@ -135,6 +135,11 @@ typedef struct mdns_region mdns_region;
 
 /* members f64[K, ndim] on the host (copied to the device) ... */
 mdns_region *mdns_region_create(const double *members, int K, int ndim);
+/* ... together with the packed bootstrap choice of its safe radius (bit b of packed[i]: point i
+ * is chosen in round b, as mdns_region_bootstrap_radius_packed): one upload, one launch; *radius
+ * receives the result (radfriendsregion.py:59-64 in one call). */
+mdns_region *mdns_region_create_bootstrapped(const double *members, int K, int ndim,
+                                             const unsigned *packed, int nbootstraps, double *radius);
 /* ... or already on the device (borrowed, not copied: e.g. an all-gathered pool). */
 mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int ndim);
 void mdns_region_destroy(mdns_region *r);

@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     "mdns_count_within_distance_of", "mdns_bootstrapped_maxdistance",
     "mdns_spectra_create", "mdns_spectra_destroy", "mdns_spectra_ndata", "mdns_spectra_nx",
     "mdns_gauss_loglike_batch", "mdns_muse_loglike_batch", "mdns_muse3_loglike_batch",
-    "mdns_region_create", "mdns_region_wrap_dev", "mdns_region_destroy",
+    "mdns_region_create", "mdns_region_create_bootstrapped", "mdns_region_wrap_dev", "mdns_region_destroy",
     "mdns_region_bootstrap_radius", "mdns_region_bootstrap_radius_dev", "mdns_region_bootstrap_radius_packed",
     "mdns_region_bootstrap_radius_async", "mdns_region_set_radius",
     "mdns_region_radius", "mdns_region_count", "mdns_region_count_dev",
@@ -74,6 +74,7 @@ def _declare(lib):
         "mdns_muse_loglike_batch": (i, [vp, vp, i, vp, i, vp]),
         "mdns_muse3_loglike_batch": (i, [vp, vp, i, vp, i, vp]),
         "mdns_region_create": (vp, [vp, i, i]),
+        "mdns_region_create_bootstrapped": (vp, [vp, i, i, vp, i, vp]),
         "mdns_region_wrap_dev": (vp, [vp, i, i]),
         "mdns_region_destroy": (None, [vp]),
         "mdns_region_bootstrap_radius": (d, [vp, vp, i]),

@@ -135,18 +135,39 @@ def find_rdistance(u, verbose=False, nbootstraps=15, metric='euclidean'):
     return bootstrapped_maxdistance(u, nbootstraps)
 
 
+def bounding_box(points):
+    """``(min, max)`` of the points along every axis (radfriendsregion.py:69-70 without the radius)."""
+    return _host.minmax(_pts(points, "points"))
+
+
 class MemberSet(object):
     """The members of one RadFriends region, resident on the device for the region's life
     (``mdns_region_*`` of include/mdns.h): the radius is computed and the many membership
     tests of ``RadFriendsRegion.generate`` run against the same HBM copy."""
 
-    def __init__(self, members):
+    def __init__(self, members, _handle=None):
         self._lib = _lib.require_device()
         members = _pts(members, "members")
         self.nmembers, self.ndim = members.shape
-        self._h = self._lib.mdns_region_create(_lib.ptr(members), self.nmembers, self.ndim)
+        self._h = _handle or self._lib.mdns_region_create(_lib.ptr(members), self.nmembers, self.ndim)
         if not self._h:
             raise _lib.MdnsError("mdns_region_create failed: " + _lib.last_error())
+
+    @classmethod
+    def bootstrapped(cls, members, masks, nbootstraps):
+        """Members and packed bootstrap choice uploaded together and K6 run in one call:
+        returns ``(member set, radius)``."""
+        lib = _lib.require_device()
+        members = _pts(members, "members")
+        masks = numpy.ascontiguousarray(masks, dtype=numpy.uint32)
+        if masks.shape != (len(members),):
+            raise ValueError("masks must be uint32[nmembers]")
+        radius = C.c_double(0)
+        h = lib.mdns_region_create_bootstrapped(_lib.ptr(members), members.shape[0], members.shape[1],
+                                                _lib.ptr(masks), int(nbootstraps), C.byref(radius))
+        if not h:
+            raise _lib.MdnsError("mdns_region_create_bootstrapped failed: " + _lib.last_error())
+        return cls(members, _handle=h), radius.value
 
     def bootstrap_radius(self, chosen):
         """K6 for a given chosen matrix; the result becomes the set's radius."""

@@ -23,42 +23,80 @@ class RadFriendsRegion(object):
         self.members = members
         self.metric = metric
         self.verbose = verbose
-        self._set = neighbors.MemberSet(members)         # members stay on the device
+        self._set = None                  # members on the device: uploaded when first needed
+        self._masks = self._chosen = None
+        self._box = None
+        self._nbootstraps = nbootstraps
+        self._maxdistance = maxdistance
         if maxdistance is None:
             # bootstrapped safe radius (radfriendsregion.py:62-64 -> neighbors.py:170-177):
-            # nbootstraps numpy.random.choice calls on the global stream, then K6
+            # nbootstraps numpy.random.choice calls on the global stream NOW -- the position of
+            # these draws in the stream is part of the results -- while K6 itself, which draws
+            # nothing, waits until somebody asks for the radius.  (The first region of a new
+            # constrainer is only ever asked whether it is larger than "no previous radius",
+            # hiermetriclearn.py:53-54, and is replaced: its K6 never runs.)
             if nbootstraps <= 16:
-                masks = neighbors.draw_bootstrap_masks(len(members), nbootstraps)
-                maxdistance = self._set.bootstrap_radius_packed(masks, nbootstraps)
+                self._masks = neighbors.draw_bootstrap_masks(len(members), nbootstraps)
             else:
-                chosen = neighbors.draw_bootstrap_choice(len(members), nbootstraps)
-                maxdistance = self._set.bootstrap_radius(chosen)
-        else:
-            self._set.set_radius(maxdistance)
-        self.maxdistance = maxdistance
-        self._update_box()
+                self._chosen = neighbors.draw_bootstrap_choice(len(members), nbootstraps)
 
-    def _update_box(self):
-        self.lo = numpy.min(self.members, axis=0) - self.maxdistance
-        self.hi = numpy.max(self.members, axis=0) + self.maxdistance
+    @property
+    def maxdistance(self):
+        if self._maxdistance is None:
+            if self._masks is not None:
+                self._set, self._maxdistance = neighbors.MemberSet.bootstrapped(self.members, self._masks, self._nbootstraps)
+            else:
+                self._set = neighbors.MemberSet(self.members)
+                self._maxdistance = self._set.bootstrap_radius(self._chosen)
+            self._masks = self._chosen = None
+        return self._maxdistance
+
+    @maxdistance.setter
+    def maxdistance(self, value):
+        self._maxdistance = value
+        self._box = None
+        if self._set is not None:
+            self._set.set_radius(value)
+
+    def _member_set(self):
+        radius = self.maxdistance                        # may create the set on its way
+        if self._set is None:
+            self._set = neighbors.MemberSet(self.members)
+            self._set.set_radius(radius)
+        return self._set
+
+    def _bounds(self):
+        if self._box is None:
+            lo, hi = neighbors.bounding_box(self.members)
+            self._box = (lo - self.maxdistance, hi + self.maxdistance)
+        return self._box
+
+    @property
+    def lo(self):
+        return self._bounds()[0]
+
+    @property
+    def hi(self):
+        return self._bounds()[1]
 
     def add_members(self, us):
+        radius = self.maxdistance
         self.members = numpy.vstack((self.members, us))
-        self._set = neighbors.MemberSet(self.members)
-        self._set.set_radius(self.maxdistance)
-        self._update_box()
+        self._set = None
+        self._box = None
+        self._maxdistance = radius
 
     # ---- membership ------------------------------------------------------------------
     def count_nearby_members(self, us):
-        return self._set.count(us)
+        return self._member_set().count(us)
 
     def are_inside(self, us):
-        return self._set.any(us)
+        return self._member_set().any(us)
 
     def is_inside(self, u):
         if not ((u >= self.lo).all() and (u <= self.hi).all()):
             return False
-        return bool(self._set.any(numpy.asarray(u, dtype=float).reshape((1, -1)))[0])
+        return bool(self._member_set().any(numpy.asarray(u, dtype=float).reshape((1, -1)))[0])
 
     def are_near_members(self, us):
         """Boolean [nmembers, npoints] proximity matrix (diagnostics; not on the hot path)."""

@@ -956,6 +956,44 @@ extern "C" mdns_region *mdns_region_create(const double *members, int K, int ndi
 	return r;
 }
 
+// Members and packed bootstrap choice staged together, K6 launched, radius waited for: what
+// RadFriendsRegion.__init__ (radfriendsregion.py:59-70) needs from the device, in ONE call --
+// one pinned staging copy, one H2D, one launch, one poll of the mapped result.
+extern "C" mdns_region *mdns_region_create_bootstrapped(const double *members, int K, int ndim,
+                                                        const unsigned *packed, int nbootstraps, double *radius)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (!members || !packed || !radius || K <= 0 || ndim <= 0 || nbootstraps <= 0 || nbootstraps > 16) {
+		set_error("mdns_region_create_bootstrapped: bad arguments (K=%d ndim=%d rounds=%d)", K, ndim, nbootstraps);
+		return nullptr;
+	}
+	const size_t mbytes = (size_t) K * ndim * sizeof(double), pbytes = (size_t) K * sizeof(unsigned);
+	const size_t poff = (mbytes + 255) & ~(size_t) 255;
+	size_t got = 0;
+	char *d = (char *) pool_take(poff + pbytes, &got);
+	if (!d) return nullptr;
+	char *pin = (char *) pinned_scratch(poff + pbytes);
+	if (!pin) { pool_give(d, got); return nullptr; }
+	memcpy(pin, members, mbytes);
+	memcpy(pin + poff, packed, pbytes);
+	if (!MDNS_HIP(hipMemcpyAsync(d, pin, poff + pbytes, hipMemcpyHostToDevice, c->stream))) { pool_give(d, got); return nullptr; }
+	mdns_region *r = region_new((const double *) d, (double *) d, K, ndim);
+	if (!r) { (void) hipStreamSynchronize(c->stream); pool_give(d, got); return nullptr; }
+	r->owned_bytes = got;
+	const BootstrapFinish fin = {r->d_counter, r->d_res, r->h_res_dev, ++r->seq};
+	if (!launch_bootstrap_packed(r->d_members, K, ndim, (const unsigned *) (d + poff), nbootstraps, r->d_round, &fin)) {
+		(void) hipStreamSynchronize(c->stream);
+		mdns_region_destroy(r);
+		return nullptr;
+	}
+	r->on_device = true;
+	r->pending = true;
+	*radius = mdns_region_radius(r);          // waits: the pinned staging block is free again
+	if (*radius != *radius) { mdns_region_destroy(r); return nullptr; }
+	return r;
+}
+
 extern "C" mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int ndim)
 {
 	if (!ctx()) return nullptr;
@@ -981,6 +1019,8 @@ extern "C" void mdns_region_destroy(mdns_region *r)
 extern "C" int mdns_region_set_radius(mdns_region *r, double maxdistance)
 {
 	if (!r) { set_error("null region"); return 1; }
+	// a radius computation still in flight writes this handle's result slot: let it land first
+	if (r->pending && ctx()) (void) region_fetch(r);
 	r->radius = maxdistance;
 	r->thresh_sq = sqrt_threshold(maxdistance);
 	r->on_device = false;

@@ -45,6 +45,11 @@ def patch_neighbors(monkeypatch, oracle):
             self.members = np.ascontiguousarray(members, dtype=float)
             self.radius = None
 
+        @classmethod
+        def bootstrapped(cls, members, masks, nbootstraps):
+            s = cls(members)
+            return s, s.bootstrap_radius_packed(masks, nbootstraps)
+
         def bootstrap_radius(self, chosen):
             self.radius = boot(self.members, chosen)
             return self.radius
