@@ -1,26 +1,50 @@
 #!/usr/bin/env python3
 """Constrained-draw likelihood throughput on MI355X (BASELINE.json metric).
 
-One STEP = one constrained-draw pass of the hot path over one batch of synthetic input, with
-everything resident in HBM when the timed region starts:
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload horns|nothing|muse] [--batch B]
 
-  1. (N > 1 only) RCCL all-gather of the shared live-point pool, K/N points per rank
-  2. K6  RadFriends safe radius of the pool (10 bootstrap rounds)      -> 10 doubles to the host
-  3. K3  membership count of 1000 box candidates against the pool
-  4. K1  B candidate lines x every spectrum of this rank's shard        -> L[B, ndata]
+Workload horns / nothing (BASELINE.json configs[1] / configs[2]; default horns)
+-------------------------------------------------------------------------------
+One STEP = one nested-sampling iteration with ONE superset constrained draw, everything
+resident in HBM when the timed region starts and every decision taken on the device:
 
-Workload at N = 1: config C2 of BASELINE.json, gensimple_horns 10 000 spectra x 200 channels,
-nlive 100 (pool of 4*nlive unique live points).  N > 1: weak scaling, 10 000 spectra per GPU
-cut from horns(10 000 * N), one process per GPU, no data-path collective besides (1).
+  0. the live-likelihood matrix [100, 10 000] is put back to its saved state (8 MB device copy:
+     extra work, it makes every step the same iteration)
+  1. prepare     per data set: lowest live likelihood + slot, shelf purge, threshold
+                 (multi_nested_sampler.py:130-143, 438-447)
+  2. (N > 1)     RCCL all-gather of the shared live-point pool, K/N points per rank
+  3. K6          RadFriends safe radius of the pool, 10 bootstrap rounds (cneighbors.c:125-179);
+                 radius and membership threshold finished on the device
+  4. K3          membership count of 1000 box candidates (cneighbors.c:95-119)
+  5. K1 + accept B = 256 candidate lines x every spectrum of this rank, `any(L > Lmins)` per
+                 candidate in the kernel epilogue (clike.c:34-89 + hiermetriclearn.py:193); no
+                 likelihood leaves the kernel, one flag per candidate does
+  6. (N > 1)     RCCL all-reduce(MAX) of the 256 flags: every rank learns the accepted candidate
+  7. commit      the first flagged candidate (the LAST of the batch here: all 256 are scored
+                 whichever is accepted): its likelihood row, one fill bit per data set, shelf
+                 appends, next thresholds (multi_nested_sampler.py:482-485)
+  8. advance     worst live point of every data set replaced by its shelf head (:494-534)
+  9. host        fetches the radius (polled mapped memory) and {accepted index, fill bits,
+                 likelihood row} (one 80 KB copy) -- the round trip a real draw makes
 
-`value` = likelihood evaluations (candidate, spectrum pairs) per second over all ranks.
+`value` = (candidate, spectrum) likelihood evaluations per second over all ranks.  N > 1: weak
+scaling, 10 000 spectra per GPU cut from horns(10 000 N), one process per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+The same run also reports (N = 1): `e2e` -- a complete analysis of the same 10 000 spectra capped
+at 400 iterations through the real host orchestration, i.e. SURVEY 8(d)'s "evals inside
+draw_constrained / wall time of those draws"; `roofline_hbm_regime` -- K1 one pass over 1.6 GB;
+`cpu_baseline` -- the reference's own clike.so on the host cores.
+
+Workload muse (BASELINE.json configs[4], one GPU's share: 6 250 spectra x 4096 channels)
+-----------------------------------------------------------------------------------------
+One STEP = B templates (default 1) scored against the 6 250 spectra with per-pixel variances
+(cmuselike.c:45-64): 410 MB of y and 1/v streamed from HBM (beyond the 256 MiB Infinity Cache).
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -31,11 +55,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak (spec sheet; = half the fp32 vector rate)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
 NDIM = 3
 NLIVE = 100
 NBOOT = 10                     # clustering/radfriendsregion.py:59
 NCAND = 1000                   # clustering/radfriendsregion.py:124
+METRIC = "likelihood evals/sec across N datasets per constrained draw"
 
 
 def priortransform(cube):
@@ -43,10 +68,32 @@ def priortransform(cube):
     return np.column_stack([10 ** (cube[:, 0] * 2 - 2), cube[:, 1] * 400 + 400, 10 ** (cube[:, 2] * 2)])
 
 
-def cpu_baseline(data, params, budget_s=12.0):
-    """Reference CPU path for K1 on the host cores of this box, bounded sample.
-    Uses the compiled reference (oracle/_ref) when it travelled with the snapshot, else our
-    C restatement.  Serial, like the reference (sample.py:81 never loads clike-parallel)."""
+def host_cores():
+    """Cores this process may use, and what lscpu says about the host."""
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info = {}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in ("Model name", "CPU(s)", "Thread(s) per core", "Core(s) per socket", "Socket(s)"):
+                info[k.strip()] = v.strip()
+    except Exception:      # noqa: BLE001
+        pass
+    return usable, info
+
+
+def ref_provenance():
+    from oracle.oracle import have_reference
+    if have_reference():
+        return ("oracle/_ref/*.so: the reference's own C compiled by oracle/Makefile where /root/reference exists "
+                "(the build container), shipped prebuilt to this box -- NOT built here")
+    return "oracle/liboracle.so: our C restatement (bit-identical to the reference C in tests/test_oracle.py)"
+
+
+def cpu_baseline_gauss(data, params, budget_s=12.0):
+    """Reference CPU path for K1 on the host cores of this box, bounded sample.  Serial, like
+    the reference (sample.py:81 never loads clike-parallel)."""
     from oracle.oracle import Oracle, have_reference
     kind = "reference" if have_reference() else "port"
     orc = Oracle(kind)
@@ -65,13 +112,13 @@ def cpu_baseline(data, params, budget_s=12.0):
         el = time.perf_counter() - t0
         if el > budget_s or n >= 20000:
             break
+    usable, info = host_cores()
     res = {"value": n * nd / el, "unit": "likelihood evals/s", "cores": 1, "kind": kind,
-           "sample": "%d candidates x %d spectra x 200 channels, full mask, serial clike loop, %.1f s" % (n, nd, el)}
+           "sample": "%d candidates x %d spectra x 200 channels, full mask, serial clike loop, %.1f s" % (n, nd, el),
+           "binary": ref_provenance(), "host": info, "cores_usable": usable}
     # best-effort multi-threaded form (dataset-parallel OpenMP restatement), for context only
     try:
-        # the GPU box gives this job a 16-core share however many cores the host reports
-        ncores = min(os.cpu_count() or 1, 16)
-        os.environ.setdefault("OMP_NUM_THREADS", str(ncores))
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable))
         omp = Oracle("port-omp")
         t0 = time.perf_counter()
         m = 0
@@ -81,7 +128,7 @@ def cpu_baseline(data, params, budget_s=12.0):
             omp.gauss_like(x, y, p[0], p[1], p[2], 0.01, mask, Lout=out)
             m += 1
         res["value_openmp"] = m * nd / (time.perf_counter() - t0)
-        res["cores_openmp"] = int(os.environ.get("OMP_NUM_THREADS", ncores))
+        res["cores_openmp"] = int(os.environ.get("OMP_NUM_THREADS", usable))
     except Exception as e:      # noqa: BLE001
         res["openmp_error"] = str(e)
     return res
@@ -123,21 +170,49 @@ def hbm_regime_leg(lib, _lib, ndata=1000000, nx=200, reps=20):
             "frac": gbs / HBM_PEAK_GBS, "evals_per_s": ndata / (us * 1e-6)}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=256, help="candidates scored per step (B)")
-    ap.add_argument("--ndata", type=int, default=10000, help="spectra per GPU")
-    ap.add_argument("--pool", type=int, default=4 * NLIVE, help="unique live points in the pool (K)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1.6 GB one-pass HBM-regime measurement")
-    ap.add_argument("--event-every", type=int, default=4, help="time every n-th launch of the dominant kernel")
-    ap.add_argument("--no-events", action="store_true", help="no per-launch events in the timed loop (roofline empty)")
-    ap.add_argument("--workload", default="horns", choices=["horns", "nothing"])
-    args = ap.parse_args()
+def e2e_leg(data, iterations):
+    """SURVEY 8(d)'s metric as it is defined: a real analysis (sampler + integrator + constrainers
+    on the host, every kernel and the accept / fill decisions on the device) of the same spectra,
+    capped after `iterations` nested-sampling iterations; useful (candidate, data set) evaluations
+    of the constrained draws divided by the wall-clock spent inside draw_constrained."""
+    from massivedatans_amd import sample
+    t0 = time.perf_counter()
+    with np.errstate(all="ignore"):
+        results, sampler, problem, duration = sample.run(data["x"], data["y"], nlive_points=NLIVE,
+                                                         max_samples=iterations, use_graph=False)
+    joint = sampler.joint
+    evals_draws = int(sampler.nevals) - NLIVE * data["y"].shape[1]          # without the initial live points
+    out = {"workload": "complete analysis of the same spectra, capped at %d iterations (tolerance 0.5, nlive %d)"
+                       % (iterations, NLIVE),
+           "wall_s": duration, "iterations": int(results["nsamples"]), "ndraws": int(sampler.ndraws),
+           "constrained_draws": int(sampler.ndraw_calls), "draw_chunks": int(sampler.ndraw_chunks),
+           "launch_sequences": int((joint.ncalls if joint is not None else 0) + problem.ncalls),
+           "evals_useful": evals_draws,
+           "evals_scored": int((joint.nevals_scored if joint is not None else 0) + problem.nevals),
+           "draw_constrained_wall_s": sampler.draw_seconds,
+           "evals_per_s_in_draw_constrained": evals_draws / sampler.draw_seconds if sampler.draw_seconds else None,
+           "evals_per_s_whole_run": int(sampler.nevals) / duration,
+           "fused": joint is not None, "logZ_first3": [float(v) for v in results["logZ"][:3]]}
+    if joint is not None:
+        joint.close()
+    return out
 
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this command
+    (profiles/pmc_latest.json: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section)."""
+    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    if not os.path.exists(pmc):
+        return None, None
+    try:
+        doc = json.load(open(pmc))
+        return doc["kernels"]["mdns::" + kernel]["hbm_bytes"], "profiles/pmc_latest.json (committed; tag %s)" % doc.get("tag")
+    except Exception:      # noqa: BLE001
+        return None, None
+
+
+# ------------------------------------------------------------------------------------------
+def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -145,9 +220,7 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
         args.gpus = world
-
-    dist = None
-    torch = None
+    torch = dist = None
     # MDNS_BENCH_FORCE_DIST=1 exercises the collective path with a single rank (1-GPU boxes)
     use_dist = world > 1 or os.environ.get("MDNS_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -155,39 +228,80 @@ def main():
         # becomes the one runtime of the process, which libmdns_hip.so then binds to as well
         import torch
         import torch.distributed as dist
-        # one visible device per rank (HIP_VISIBLE_DEVICES set by a launcher) or all of them
         device_index = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(device_index)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
     else:
         device_index = local_rank
-
-    from massivedatans_amd import _lib, gen
+    from massivedatans_amd import _lib
     os.environ.setdefault("MDNS_DEVICE", str(device_index))
     lib = _lib.require_device()
     if use_dist:
-        # The kernels go on torch's CURRENT stream, which the (synchronous-API) RCCL collective
-        # orders itself against on both sides: K6 of a step cannot start before that step's
-        # all-gather has delivered the pool.  A stream of our own, because torch's default
+        # The kernels go on torch's CURRENT stream, which the (synchronous-API) RCCL collectives
+        # order themselves against on both sides.  A stream of our own, because torch's default
         # stream is the null stream (handle 0), which mdns_set_stream reads as "library stream".
         bench_stream = torch.cuda.Stream()
         torch.cuda.set_stream(bench_stream)
         assert bench_stream.cuda_stream != 0
         _lib.check(lib.mdns_set_stream(C.c_void_p(bench_stream.cuda_stream)), "mdns_set_stream")
+    return world, rank, use_dist, torch, dist, lib, _lib
+
+
+def timed(step, fence, args, use_dist, torch, dist, lib, _lib):
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    _lib.check(lib.mdns_sync(), "sync")
+    if use_dist:
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    fence()
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def read_profile(lib, which):
+    n, ms = C.c_longlong(0), C.c_double(0)
+    lib.mdns_profile_read(which, C.byref(n), C.byref(ms))
+    return int(n.value), (1e3 * ms.value / n.value if n.value else 0.0)
+
+
+def bench_gauss(args):
+    world, rank, use_dist, torch, dist, lib, _lib = setup_dist(args)
+    from massivedatans_amd import gen
 
     # ---- synthetic input, resident before the timed region --------------------------------
     nd, B, K = args.ndata, args.batch, args.pool
+    if B < 2 or B > _lib.JOINT_MAX_BATCH:
+        sys.exit("--batch must be in [2, %d]" % _lib.JOINT_MAX_BATCH)
     make = gen.horns if args.workload == "horns" else gen.nothing
     full = make(nd * world)
     shard = np.ascontiguousarray(full["y"][:, rank * nd:(rank + 1) * nd])
     data = {"x": full["x"], "y": shard}
-    spectra = lib.mdns_spectra_create(_lib.ptr(data["x"]), _lib.ptr(shard), None, nd, shard.shape[0], 0)
+    nx = shard.shape[0]
+    spectra = lib.mdns_spectra_create(_lib.ptr(data["x"]), _lib.ptr(shard), None, nd, nx, 0)
     if not spectra:
         raise _lib.MdnsError(_lib.last_error())
-    nx = shard.shape[0]
+    joint = lib.mdns_joint_create(spectra, NLIVE, 8)
+    if not joint:
+        raise _lib.MdnsError(_lib.last_error())
 
     rng = np.random.RandomState(1)                      # sample.py:162
-    params = priortransform(rng.uniform(size=(B, NDIM)))
+    live_params = priortransform(rng.uniform(size=(NLIVE, NDIM)))
+    _lib.check(lib.mdns_joint_init_gauss(joint, _lib.ptr(live_params), 0.01), "init")
+    d_saved = lib.mdns_dev_alloc(NLIVE * nd * 8)
+    _lib.check(lib.mdns_d2d(d_saved, lib.mdns_joint_live_dev(joint), NLIVE * nd * 8), "save live")
+    # B - 1 candidates no data set accepts (lines ten times brighter than the prior allows, as
+    # broad as it allows), then one that beats the worst live point of every data set (a line at
+    # the faint end of the prior) -- checked after the timed region
+    params = np.column_stack([np.full(B, 10.0), rng.uniform(400, 800, size=B), np.full(B, 100.0)])
+    params[B - 1] = (0.01, 790.0, 1.0)
     pool = rng.uniform(0.3, 0.7, size=(K, NDIM))        # live points (unit cube coordinates)
     chosen = np.zeros((K, NBOOT))
     for b in range(NBOOT):
@@ -203,30 +317,62 @@ def main():
         return p
 
     d_params, d_chosen, d_cands = dev(params), dev(chosen), dev(cands)
-    d_L = lib.mdns_dev_alloc(B * nd * 8)
     d_counts = lib.mdns_dev_alloc(NCAND * 4)
+    nres = lib.mdns_joint_result_bytes(nd)
+    result = np.zeros(nres, dtype=np.uint8)
+    d_flags = lib.mdns_joint_flags_dev(joint)
+    d_result = lib.mdns_joint_result_dev(joint)
     if use_dist:
-        assert K % world == 0, "pool size must divide over the ranks"
-        t_pool = torch.empty((K, NDIM), dtype=torch.float64, device="cuda")
-        t_mine = torch.from_numpy(pool[rank * (K // world):(rank + 1) * (K // world)].copy()).cuda()
+        share = (K + world - 1) // world                 # the last rank may hold fewer: padded gather
+        t_pool = torch.zeros((world * share, NDIM), dtype=torch.float64, device="cuda")
+        mine = np.zeros((share, NDIM))
+        part = pool[rank * share:(rank + 1) * share]
+        mine[:len(part)] = part
+        mine[len(part):] = pool[0]                       # padding repeats a pool point: same region
+        t_mine = torch.from_numpy(mine).cuda()
         d_pool = t_pool.data_ptr()
+        Kdev = world * share
+        # the bootstrap choice must cover the padded pool
+        if Kdev != K:
+            ch = np.zeros((Kdev, NBOOT))
+            ch[:K] = chosen
+            d_chosen = dev(ch)
+        t_flags = torch.zeros(_lib.JOINT_MAX_BATCH, dtype=torch.int32, device="cuda")
+        nbits = (nd + 63) // 64
+        t_bits = torch.zeros(nbits, dtype=torch.int64, device="cuda")
+        t_allbits = torch.zeros(world * nbits, dtype=torch.int64, device="cuda")
     else:
         d_pool = dev(pool)
-    region = lib.mdns_region_wrap_dev(d_pool, K, NDIM)     # the pool buffer is refilled in place
+        Kdev = K
+    region = lib.mdns_region_wrap_dev(d_pool, Kdev, NDIM)     # the pool buffer is refilled in place
     if not region:
         raise _lib.MdnsError(_lib.last_error())
 
     def step():
+        _lib.check(lib.mdns_joint_restore_live_dev(joint, d_saved), "restore")
+        _lib.check(lib.mdns_joint_prepare_dev(joint), "prepare")
         if use_dist:
             dist.all_gather_into_tensor(t_pool, t_mine)
         # K6, then radius + membership threshold finished on the device: K3 follows in stream order
         _lib.check(lib.mdns_region_bootstrap_radius_async(region, d_chosen, NBOOT), "K6")
         _lib.check(lib.mdns_region_count_dev(region, d_cands, NCAND, d_counts), "K3")
-        _lib.check(lib.mdns_gauss_loglike_batch_dev(spectra, d_params, B, 0.01, None, nd, d_L), "K1")
-        # the host needs the radius (bounding box of the next proposals): fetched while K1 runs
+        _lib.check(lib.mdns_joint_score_dev(joint, d_params, B, 0.01, None, nd), "K1 + accept")
+        if use_dist:
+            # every rank learns which candidates ANY rank's data sets accept: B flags, not L[B, M]
+            _lib.check(lib.mdns_d2d(C.c_void_p(t_flags.data_ptr()), d_flags, 4 * B), "flags out")
+            dist.all_reduce(t_flags, op=dist.ReduceOp.MAX)
+            _lib.check(lib.mdns_d2d(d_flags, C.c_void_p(t_flags.data_ptr()), 4 * B), "flags in")
+        _lib.check(lib.mdns_joint_commit_dev(joint, None, nd), "commit")
+        _lib.check(lib.mdns_joint_advance_dev(joint), "advance")
+        if use_dist:
+            # the host bookkeeping of every rank needs the fill bits of all data sets
+            _lib.check(lib.mdns_d2d(C.c_void_p(t_bits.data_ptr()), C.c_void_p(d_result + 16), 8 * nbits), "bits out")
+            dist.all_gather_into_tensor(t_allbits, t_bits)
+        # the host needs the radius (bounding box of the next proposals) and the outcome of the draw
         radius = lib.mdns_region_radius(region)
         if radius != radius:
             raise _lib.MdnsError(_lib.last_error())
+        _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nres), "result")
 
     def fence():
         _lib.check(lib.mdns_sync(), "sync")
@@ -235,100 +381,221 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
     # events only around the dominant kernel (every timed launch adds two event records), and its
     # launches are sampled (every 4th), which keeps the cost of measuring out of `value`
     lib.mdns_profile_every(args.event_every)
     lib.mdns_profile(1 if not args.no_events else 0)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    _lib.check(lib.mdns_sync(), "sync")
-    if use_dist:
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    fence()
-
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # per-launch duration of the dominant kernel, HIP events on the launch stream
-    n_launch, tot_ms = C.c_longlong(0), C.c_double(0)
-    lib.mdns_profile_read(0, C.byref(n_launch), C.byref(tot_ms))
-    k1_ms = tot_ms.value / max(1, n_launch.value)
-    kernel = (lib.mdns_profile_kernel(0) or b"").decode()      # e.g. "k_gauss_cols<8, 1>"
+    elapsed = timed(step, fence, args, use_dist, torch, dist, lib, _lib)
+    n_launch, k1_us = read_profile(lib, 0)
+    kernel = (lib.mdns_profile_kernel(0) or b"").decode()      # e.g. "k_gauss_cols_accept<8>"
     # the geometry kernels of the step, timed in a few extra (unreported) steps
     lib.mdns_profile_every(1)
     lib.mdns_profile(4 | 8)
     for _ in range(min(args.steps, 50)):
         step()
-    other = {}
-    for which, name in ((2, "count_within"), (3, "bootstrap")):
-        n2, ms2 = C.c_longlong(0), C.c_double(0)
-        lib.mdns_profile_read(which, C.byref(n2), C.byref(ms2))
-        other[name + "_us"] = 1e3 * ms2.value / max(1, n2.value)
+    other = {"count_within_us": read_profile(lib, 2)[1], "bootstrap_us": read_profile(lib, 3)[1]}
     lib.mdns_profile(0)
     fence()
 
-    # sanity: the timed launches produced the right numbers (first candidate, a few spectra)
-    L = np.empty(B * nd)
-    _lib.check(lib.mdns_d2h(_lib.ptr(L), d_L, B * nd * 8), "d2h")
-    L = L.reshape(B, nd)
-    ypred = params[0, 0] * np.exp(-0.5 * ((params[0, 1] - data["x"]) / params[0, 2]) ** 2)
+    # sanity: the timed steps decided what they were built to decide, with the right numbers
+    accepted = int(result[:4].view(np.int32)[0])
+    status = int(result[4:8].view(np.int32)[0])
+    nbw = (nd + 63) // 64
+    bits = np.unpackbits(result[16:16 + 8 * nbw], bitorder="little")[:nd]
+    Lrow = result[16 + 8 * nbw:].view(np.float64)
+    ypred = params[B - 1, 0] * np.exp(-0.5 * ((params[B - 1, 1] - data["x"]) / params[B - 1, 2]) ** 2)
     want = -0.5 * (((ypred.reshape((-1, 1)) - shard[:, :64]) / 0.01) ** 2).sum(axis=0)
-    assert np.allclose(L[0, :64], want, rtol=1e-10), "bench output check failed"
+    assert accepted == B - 1 and status == 0, ("bench draw: accepted %d status %d" % (accepted, status))
+    assert bits.all(), "bench draw: the accepted candidate must fill every shelf"
+    assert np.allclose(Lrow[:64], want, rtol=1e-10), "bench output check failed"
 
     if rank == 0:
         evals_per_step = B * nd * world
         value = evals_per_step * args.steps / elapsed
-        bytes_per_eval = 8 * nx + 8                       # y row read + L written
-        alg_bytes = bytes_per_eval * B * nd               # per launch (one rank)
-        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9 if k1_ms > 0 else 0.0
-        phys_bytes = 8 * nx * nd + 8 * B * nd + 8 * B * 512   # spectra once + L + templates
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:       # HBM bytes per launch of that kernel, from the committed --pmc passes
-                traffic = json.load(open(pmc))["kernels"]["mdns::" + kernel]["hbm_bytes"]
-            except Exception:      # noqa: BLE001
-                traffic = None
+        flops = 3.0 * nx * B * nd                         # per launch: subtract, multiply, add
+        tflops = flops / (k1_us * 1e-6) / 1e12 if k1_us > 0 else 0.0
+        alg_bytes = (8 * nx + 8) * B * nd                 # 1608 B per eval
+        phys_bytes = 8 * nx * nd + 8 * nd + 8 * B * nx    # spectra once + thresholds + templates; flags
+        traffic, traffic_source = pmc_traffic(kernel)
         res = {
-            "metric": "likelihood evals/sec across N datasets per constrained draw",
+            "metric": METRIC,
             "value": value, "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "gensimple_%s %d spectra x %d channels per GPU, nlive %d, pool %d live points, "
-                                   "%d candidates per draw step (BASELINE.json configs[1])"
-                                   % (args.workload, nd, nx, NLIVE, K, B),
+            "config": {"workload": "gensimple_%s %d spectra x %d channels per GPU, nlive %d: one nested-sampling iteration "
+                                   "per step = prepare + K6 on a pool of %d live points + K3 on %d candidates + %d "
+                                   "candidates scored and accept-tested against every spectrum + commit + advance, "
+                                   "all on the device (BASELINE.json configs[%d])"
+                                   % (args.workload, nd, nx, NLIVE, K, NCAND, B, 1 if args.workload == "horns" else 2),
                        "spectra_per_gpu": nd, "channels": nx, "candidates_per_step": B, "pool_points": K,
                        "parallelism": "datasets sharded x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "launch_us": 1e3 * k1_ms, "launches_timed": int(n_launch.value),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         "physical_bytes_per_launch": phys_bytes,
-                         "frac_physical": (phys_bytes / (k1_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if k1_ms > 0 else 0.0,
-                         "fp64_valu_frac": (3.0 * nx * B * nd / (k1_ms * 1e-3) / 1e12) / FP64_VALU_PEAK_TFLOPS if k1_ms > 0 else 0.0,
-                         "note": "algorithmic bytes = 1608 B per (candidate, spectrum) eval; with B candidates scored per "
-                                 "pass each spectrum is read once and reused B times, so frac can exceed 1 "
-                                 "(effective, not physical, bandwidth); frac_physical counts bytes actually moved"},
+            "roofline": {"bound": "fp64_valu", "kernel": kernel, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "launch_us": k1_us, "launches_timed": n_launch,
+                         "flops_per_launch": flops,
+                         "note": "B candidates are scored per pass over the spectra, so every spectrum byte is used B "
+                                 "times and the kernel is bound by fp64 vector issue (v_add_f64 + v_fma_f64 per "
+                                 "candidate, channel and spectrum: at most 0.75 of the FMA peak), not by HBM; "
+                                 "flops = 3 x channels x candidates x spectra",
+                         "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
+                                 "frac_effective": (alg_bytes / (k1_us * 1e-6) / 1e9) / HBM_PEAK_GBS if k1_us > 0 else 0.0,
+                                 "physical_bytes_per_launch": phys_bytes,
+                                 "frac_physical": (phys_bytes / (k1_us * 1e-6) / 1e9) / HBM_PEAK_GBS if k1_us > 0 else 0.0,
+                                 "note": "frac_effective = 1608 algorithmic bytes per eval / launch time / 8 TB/s (exceeds 1 "
+                                         "because of the B-fold reuse: NOT a roofline fraction); frac_physical counts the "
+                                         "bytes that have to move once"}},
         }
         res.update(other)
-        if not args.no_hbm_leg and world == 1:
+        if world == 1 and not args.no_e2e:
+            res["e2e"] = e2e_leg(data, args.e2e_iterations)
+        if world == 1 and not args.no_hbm_leg:
             res["roofline_hbm_regime"] = hbm_regime_leg(lib, _lib)
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(data, params)
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline_gauss(data, priortransform(np.random.RandomState(2).uniform(size=(64, NDIM))))
         print(json.dumps(res))
 
     lib.mdns_region_destroy(region)
+    lib.mdns_joint_destroy(joint)
     lib.mdns_spectra_destroy(spectra)
     if use_dist:
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------
+def cpu_baseline_muse(y_t, v_t, templates, budget_s=15.0):
+    """cmuselike on the host: the reference's OpenMP build (musefuse.py:505-508 loads it when
+    OMP_NUM_THREADS > 1) on a bounded number of templates over the same spectra."""
+    from oracle.oracle import Oracle, have_reference
+    usable, info = host_cores()
+    os.environ.setdefault("OMP_NUM_THREADS", str(usable))
+    kind = "reference" if have_reference() else "port"
+    orc = Oracle("reference-omp" if have_reference() else "port-omp")
+    nd = y_t.shape[1]
+    mask = np.ones(nd, dtype=np.bool_)
+    out = np.zeros(nd)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        orc.muse_like(y_t, v_t, templates[n % len(templates)], mask, Lout=out)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 200:
+            break
+    return {"value": n * nd / el, "unit": "likelihood evals/s", "cores": int(os.environ.get("OMP_NUM_THREADS", usable)),
+            "kind": kind, "sample": "%d templates x %d spectra x %d channels, full mask, cmuselike OpenMP build, %.1f s"
+                                    % (n, nd, y_t.shape[0], el),
+            "binary": ref_provenance(), "host": info, "cores_usable": usable}, out.copy(), (n - 1) % len(templates)
+
+
+def bench_muse(args):
+    world, rank, use_dist, torch, dist, lib, _lib = setup_dist(args)
+    from massivedatans_amd import gen
+    nd, nx, B = args.muse_ndata, 4096, max(1, args.batch if args.batch_given else 1)
+    cube = gen.muse_like(nd * world, nx)
+    y_t = np.ascontiguousarray(cube["y"][:, rank * nd:(rank + 1) * nd])       # reference layout [nx, ndata]
+    v_t = np.ascontiguousarray(cube["v"][:, rank * nd:(rank + 1) * nd])
+    x = cube["x"]
+    spectra = lib.mdns_spectra_create(_lib.ptr(x), _lib.ptr(y_t), _lib.ptr(v_t), nd, nx, 0)
+    if not spectra:
+        raise _lib.MdnsError(_lib.last_error())
+    rng = np.random.RandomState(3)
+    # template parameters (log_amp, z, log_width_scale, ratio1, ratio3) around the truth of the cube
+    p5 = np.column_stack([rng.uniform(-0.3, 0.3, B), rng.uniform(0.0, 0.02, B), rng.uniform(-0.2, 0.2, B),
+                          rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
+    templates = np.array([gen.muse_template(x, p) for p in p5])
+    d_t = lib.mdns_dev_alloc(templates.nbytes)
+    _lib.check(lib.mdns_h2d(d_t, _lib.ptr(templates), templates.nbytes), "h2d")
+    d_L = lib.mdns_dev_alloc(B * nd * 8)
+
+    def step():
+        _lib.check(lib.mdns_muse_loglike_batch_dev(spectra, d_t, B, None, nd, d_L), "K2")
+
+    def fence():
+        _lib.check(lib.mdns_sync(), "sync")
+        if use_dist:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    lib.mdns_profile_every(1)
+    lib.mdns_profile(2)
+    elapsed = timed(step, fence, args, use_dist, torch, dist, lib, _lib)
+    n_launch, k2_us = read_profile(lib, 1)
+    lib.mdns_profile(0)
+    kernel = (lib.mdns_profile_kernel(1) or b"").decode()
+    L = np.empty(B * nd)
+    _lib.check(lib.mdns_d2h(_lib.ptr(L), d_L, B * nd * 8), "d2h")
+    L = L.reshape(B, nd)
+
+    if rank == 0:
+        value = B * nd * world * args.steps / elapsed
+        alg_bytes = (16 * nx + 8) * B * nd                # SURVEY 8(d): 65 544 B per eval
+        phys_bytes = 16 * nx * nd + 8 * B * nd + 8 * B * nx
+        # per candidate, channel and spectrum: y w m, m m w, then (y - s m)^2 w = 4 multiplies + 3 fused
+        flops = 10.0 * nx * B * nd
+        gbs = phys_bytes / (k2_us * 1e-6) / 1e9 if k2_us > 0 else 0.0
+        tflops = flops / (k2_us * 1e-6) / 1e12 if k2_us > 0 else 0.0
+        hbm_bound = B < 8
+        traffic, traffic_source = pmc_traffic(kernel)
+        res = {
+            "metric": METRIC, "value": value, "unit": "likelihood evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "MUSE-style cmuselike: %d spectra x %d channels with per-pixel variances per GPU (one GPU's "
+                                   "share of BASELINE.json configs[4]: 50 000 over 8), %d template%s per pass; y and 1/v = "
+                                   "%.0f MB streamed from HBM" % (nd, nx, B, "" if B == 1 else "s", 16 * nx * nd / 1e6),
+                       "spectra_per_gpu": nd, "channels": nx, "candidates_per_step": B,
+                       "parallelism": "datasets sharded x%d" % world},
+            "roofline": ({"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                          "launch_us": k2_us, "launches_timed": n_launch, "bytes_per_launch": phys_bytes,
+                          "algorithmic_bytes_per_launch": alg_bytes,
+                          "note": "one fused pass over y and 1/v (the reference makes two strided passes): 65 544 B per eval "
+                                  "at B = 1; with B templates the rows are read once, bytes_per_launch is what moves"}
+                         if hbm_bound else
+                         {"bound": "fp64_valu", "kernel": kernel, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+                          "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS, "traffic": traffic,
+                          "traffic_source": traffic_source, "launch_us": k2_us, "launches_timed": n_launch,
+                          "flops_per_launch": flops, "hbm_frac_physical": gbs / HBM_PEAK_GBS,
+                          "note": "10 flops per (template, channel, spectrum): two dot products and the residual sum"}),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"], ref_L, which = cpu_baseline_muse(y_t, v_t, templates)
+            err = np.max(np.abs(L[which] - ref_L) / np.abs(ref_L))
+            assert err < 1e-9, ("K2 bench output differs from the CPU path", err)
+            res["parity_vs_cpu_max_rel"] = float(err)
+        print(json.dumps(res))
+    lib.mdns_spectra_destroy(spectra)
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=None, help="candidates scored per step (B): default 256 (horns/nothing), 1 (muse)")
+    ap.add_argument("--ndata", type=int, default=10000, help="spectra per GPU (horns / nothing)")
+    ap.add_argument("--muse-ndata", type=int, default=6250, help="spectra per GPU (muse)")
+    ap.add_argument("--pool", type=int, default=4 * NLIVE, help="unique live points in the pool (K)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1.6 GB one-pass HBM-regime measurement")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the capped complete analysis")
+    ap.add_argument("--e2e-iterations", type=int, default=400)
+    ap.add_argument("--event-every", type=int, default=4, help="time every n-th launch of the dominant kernel")
+    ap.add_argument("--no-events", action="store_true", help="no per-launch events in the timed loop (roofline empty)")
+    ap.add_argument("--workload", default="horns", choices=["horns", "nothing", "muse"])
+    args = ap.parse_args()
+    args.batch_given = args.batch is not None
+    if args.batch is None:
+        args.batch = 256
+    if args.workload == "muse":
+        bench_muse(args)
+    else:
+        bench_gauss(args)
 
 
 if __name__ == "__main__":

@@ -241,6 +241,7 @@ void *mdns_dev_alloc(size_t bytes);
 void mdns_dev_free(void *p);
 int mdns_h2d(void *dst, const void *src, size_t bytes);   /* synchronous */
 int mdns_d2h(void *dst, const void *src, size_t bytes);   /* synchronous */
+int mdns_d2d(void *dst, const void *src, size_t bytes);   /* asynchronous, library stream */
 int mdns_sync(void);                                      /* wait for the library stream */
 /* Run on a caller-owned hipStream_t (e.g. the stream of an RCCL collective); NULL restores
  * the library's own stream. */

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "mdns_region_bootstrap_radius", "mdns_region_bootstrap_radius_dev", "mdns_region_bootstrap_radius_packed",
     "mdns_region_bootstrap_radius_async", "mdns_region_set_radius",
     "mdns_region_radius", "mdns_region_count", "mdns_region_count_dev",
-    "mdns_dev_alloc", "mdns_dev_free", "mdns_h2d", "mdns_d2h", "mdns_sync", "mdns_set_stream",
+    "mdns_dev_alloc", "mdns_dev_free", "mdns_h2d", "mdns_d2h", "mdns_d2d", "mdns_sync", "mdns_set_stream",
     "mdns_event_create", "mdns_event_destroy", "mdns_event_record", "mdns_event_elapsed_ms",
     "mdns_profile", "mdns_profile_every", "mdns_profile_read", "mdns_profile_kernel",
     "mdns_gauss_loglike_batch_dev", "mdns_muse_loglike_batch_dev", "mdns_muse3_loglike_batch_dev",
@@ -89,6 +89,7 @@ def _declare(lib):
         "mdns_dev_free": (None, [vp]),
         "mdns_h2d": (i, [vp, vp, sz]),
         "mdns_d2h": (i, [vp, vp, sz]),
+        "mdns_d2d": (i, [vp, vp, sz]),
         "mdns_sync": (i, []),
         "mdns_set_stream": (i, [vp]),
         "mdns_event_create": (vp, []),

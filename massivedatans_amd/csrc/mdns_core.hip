@@ -270,6 +270,12 @@ extern "C" int mdns_d2h(void *dst, const void *src, size_t bytes)
 	if (!MDNS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream))) return 1;
 	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
 }
+extern "C" int mdns_d2d(void *dst, const void *src, size_t bytes)
+{
+	Context *c = ctx();
+	if (!c) return 1;
+	return MDNS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream)) ? 0 : 1;
+}
 extern "C" int mdns_sync(void)
 {
 	Context *c = ctx();

@@ -142,6 +142,10 @@ class MuseSpectra(_Spectra):
         """musefuse.py:534-535 given the template: masked likelihoods; ``jitter`` (e.g.
         ``numpy.random.normal``) reproduces the reference's N(0, 1e-5) tie-breaker and its RNG
         consumption."""
+        if not np.any(ypred):
+            # "give low probability to solutions with no stars" (musefuse.py:527-529): no kernel
+            # call and -- unlike the regular path -- no random numbers drawn
+            return np.ones(_rows_from_mask(data_mask, self.ndata)[1]) * -1e100
         L = self.loglike_batch(ypred, data_mask)[0]
         if jitter is not None:
             L = L + jitter(0, 1e-5, size=len(L))

@@ -25,6 +25,7 @@ set the wall-clock.  None of this changes a single value (tests/test_orchestrati
 """
 import ctypes
 import logging
+import time
 from collections import defaultdict
 
 import numpy
@@ -149,6 +150,7 @@ class MultiNestedSampler(object):
         self._live_cache = None
         self.ndraw_calls = 0                # constrained draws made (accepted points)
         self.ndraw_chunks = 0               # chunks of candidates handed to the joint state
+        self.draw_seconds = 0.0             # wall-clock spent inside the constrainers' draw_constrained
 
         # nlive prior draws, every data set starts from the same points: all are superpoints
         # (multi_nested_sampler.py:88-103).  RNG: nlive x uniform(0, 1, ndim).
@@ -482,9 +484,22 @@ class MultiNestedSampler(object):
     def generate_subsets_graph(self, data_mask, allp):
         """Connected components of the bipartite (data set, live point) graph, as the
         reference obtains from igraph (multi_nested_sampler.py:268-355): components in order of
-        their lowest data-set index, point ids ascending.  igraph is not available in this
-        image, so this ordering is restated from igraph's documented behaviour and is NOT pinned
-        against a reference run (the pinned path is ``use_graph=False``)."""
+        their lowest data-set index, point ids ascending (igraph numbers the vertices of a
+        subgraph in the order they had in the graph -- data sets first, then points by id -- and
+        lists a cluster's vertices in that order).  igraph is not available in this image, so the
+        ORDER is restated from igraph's documented behaviour and is not pinned against a
+        reference run; the PARTITION is that of the pinned walk (the components come from the
+        same native code) and is cross-checked against networkx in tests/test_sampler_units.py."""
+        lib = _host_lib()
+        if lib is not None:
+            groups = list(self._groups_native(lib, data_mask))
+            if len(groups) == 1:
+                mask, points = groups[0]
+                yield mask, (points if int(numpy.count_nonzero(data_mask)) == 1 else numpy.sort(points))
+                return
+            for mask, points in groups:
+                yield mask, numpy.sort(points)
+            return
         groups, allp, _ = self._trivial_groups(data_mask, allp)
         if groups is not None:
             for g in groups:
@@ -522,7 +537,7 @@ class MultiNestedSampler(object):
         for dsets, points in ordered:
             member_mask = numpy.zeros(len(data_mask), dtype=bool)
             member_mask[dsets] = True
-            yield member_mask, sorted(points)
+            yield member_mask, numpy.array(sorted(points))
 
     # ---- one nested-sampling iteration ---------------------------------------------------
     def _refresh_thresholds(self, rows):
@@ -619,12 +634,14 @@ class MultiNestedSampler(object):
                     extra['loglikelihood_batch'] = \
                         lambda ps, m=joint_data_mask: self.multi_loglikelihood_batch(ps, m)
                     extra['mask_key'] = (self.ndata, joint_data_mask.tobytes())
+                t_draw = time.perf_counter()
                 uj, xj, Lj, n = draw(
                     Lmins=Lmins_higher, priortransform=self.priortransform,
                     loglikelihood=lambda params, m=joint_data_mask: self.multi_loglikelihood(params, m),
                     ndim=self.ndim, draw_global_uniform=self.draw_global_uniform,
                     live_pointsu=self.pointpile[joint_live_pointsp], max_draws=max_draws,
                     iter=self.global_iter, nlive_points=self.nlive_points, **extra)
+                self.draw_seconds += time.perf_counter() - t_draw
 
                 self.ndraws += int(n)
                 self.ndraw_calls += 1

@@ -657,3 +657,17 @@ def test_full_run_matches_the_cpu_path(kind):
     assert np.max(np.abs(results["logZ"] - want["logZ"])) < 1e-9
     assert np.max(np.abs(results["logZ"] - want["logZ"]) / np.abs(want["logZ"])) < 1e-6
     assert np.allclose(results["logZerr"], want["logZerr"], rtol=1e-6, atol=1e-9)
+
+
+def test_muse_multi_loglikelihood_with_jitter(oracle):
+    """The K2 caller on the GPU (like.MuseSpectra.multi_loglikelihood, musefuse.py:520-535): values
+    against the oracle + the reference's N(0, 1e-5) tie-breaker, and the global RNG stream left
+    where the reference leaves it (one normal deviate per selected spectrum, none for a
+    template without stars)."""
+    from massivedatans_amd.like import MuseSpectra
+    from test_sampler_units import _check_muse_jitter, _muse_case
+    for nd, nx in ((23, 61), (300, 4096)):
+        x, y, v, ypred, mask = _muse_case(seed=nd, nd=nd, nx=nx)
+        spectra = MuseSpectra(x, y, v)
+        _check_muse_jitter(spectra, oracle, y, v, ypred, mask, rtol=1e-11)
+        spectra.close()

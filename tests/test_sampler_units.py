@@ -268,3 +268,126 @@ def test_incremental_grouping_walk_on_shrinking_selections():
                 mask = mask.copy()
                 mask[leave] = False
     assert splits > 10
+
+
+def test_graph_grouping_against_networkx():
+    """``generate_subsets_graph`` against an independent implementation: connected components of
+    the bipartite (data set, live point) graph from networkx (the cross-check recipe of the
+    reference's profile_generate_subsets.py:140-161), put in igraph's documented order --
+    components by lowest data-set index, point ids ascending."""
+    import pytest
+    nx = pytest.importorskip("networkx")
+    rng = np.random.RandomState(17)
+    multi = 0
+    for trial in range(40):
+        nlive = int(rng.randint(2, 8))
+        ndata = int(rng.randint(3, 50))
+        nclusters = int(rng.randint(1, 6))
+        pools = [np.arange(c * 40, c * 40 + rng.randint(nlive, 40)) for c in range(nclusters)]
+        lp = np.empty((nlive, ndata), dtype=np.int64)
+        for d in range(ndata):
+            lp[:, d] = rng.choice(pools[rng.randint(nclusters)], size=nlive, replace=False)
+        s = _fake_sampler(lp, int(lp.max()) + 1, nlive)
+        mask = rng.uniform(size=ndata) < rng.choice([0.5, 1.0])
+        if mask.sum() < 2:
+            mask[:2] = True
+        got = [(np.flatnonzero(m).tolist(), [int(p) for p in pts]) for m, pts in s.generate_subsets_graph(mask, None)]
+        G = nx.Graph()
+        for d in np.flatnonzero(mask):
+            for p in lp[:, d]:
+                G.add_edge(("n", int(d)), ("p", int(p)))
+        comps = sorted(([sorted(v for k, v in c if k == "n"), sorted(v for k, v in c if k == "p")]
+                        for c in nx.connected_components(G)), key=lambda c: c[0][0])
+        allp = sorted(set(int(p) for p in lp[:, mask].ravel()))
+        if len(comps) == 1 or len(allp) < 2 * nlive:
+            want = [(np.flatnonzero(mask).tolist(), allp)]          # multi_nested_sampler.py:283-300,333-335
+        else:
+            want = [(c[0], c[1]) for c in comps]
+        assert got == want
+        multi += len(want) > 1
+    assert multi > 5
+
+
+def _muse_case(seed=4, nd=23, nx=61):
+    rng = np.random.RandomState(seed)
+    x = np.linspace(4750, 9350, nx)
+    y = rng.normal(1.0, 0.1, size=(nx, nd))
+    v = rng.uniform(0.5, 2.0, size=(nx, nd)) * 1e-2
+    ypred = 1.0 + 0.3 * np.exp(-0.5 * ((x - 6000.) / 300.) ** 2)
+    mask = rng.uniform(size=nd) < 0.6
+    mask[0] = True
+    return x, np.ascontiguousarray(y), np.ascontiguousarray(v), ypred, mask
+
+
+def _check_muse_jitter(spectra, oracle, y, v, ypred, mask, rtol):
+    """musefuse.py:534-535: ``Lout[data_mask] + numpy.random.normal(0, 1e-5, size=data_mask.sum())``
+    -- the values AND the position of the global RNG stream afterwards."""
+    Lout = np.zeros(y.shape[1])
+    oracle.muse_like(y, v, ypred, mask, Lout=Lout)
+    np.random.seed(77)
+    want = Lout[mask] + np.random.normal(0, 1e-5, size=mask.sum())
+    probe_want = np.random.uniform()
+    np.random.seed(77)
+    got = spectra.multi_loglikelihood(ypred, mask, jitter=np.random.normal)
+    assert np.random.uniform() == probe_want, "the jitter must consume exactly mask.sum() normal deviates"
+    assert got.shape == want.shape
+    assert np.max(np.abs(got - want) / np.abs(want)) < rtol
+    # without jitter: the bare likelihoods, no RNG consumed
+    np.random.seed(78)
+    bare = spectra.multi_loglikelihood(ypred, mask)
+    np.random.seed(78)
+    assert np.max(np.abs(bare - Lout[mask]) / np.abs(Lout[mask])) < rtol
+    # "no stars" (musefuse.py:527-529): constant -1e100, and NO random numbers drawn
+    np.random.seed(79)
+    probe = np.random.uniform()
+    np.random.seed(79)
+    flat = spectra.multi_loglikelihood(np.zeros_like(ypred), mask, jitter=np.random.normal)
+    assert np.array_equal(flat, np.ones(mask.sum()) * -1e100) and np.random.uniform() == probe
+
+
+def test_muse_multi_loglikelihood_jitter_host_logic(oracle):
+    """The K2 caller (like.MuseSpectra.multi_loglikelihood, musefuse.py:520-535) with the oracle
+    standing in for the kernel: tie-breaking jitter, its RNG consumption, the no-stars case."""
+    from massivedatans_amd.like import MuseSpectra
+    x, y, v, ypred, mask = _muse_case()
+
+    class OracleMuse(MuseSpectra):
+        def __init__(self):                   # no device: only the host logic is under test
+            self.ndata, self.nx = y.shape[1], y.shape[0]
+
+        def loglike_batch(self, templates, data_mask=None):
+            out = np.zeros(self.ndata)
+            oracle.muse_like(y, v, np.ascontiguousarray(np.atleast_2d(templates)[0]), data_mask, Lout=out)
+            return out[data_mask][None, :]
+
+        def close(self):
+            pass
+
+    _check_muse_jitter(OracleMuse(), oracle, y, v, ypred, mask, rtol=1e-15)
+
+
+def test_hdf5_roundtrip_with_real_h5py(tmp_path):
+    """Input and output files through the real h5py where it is installed (it is not in the
+    build image: the test skips there): dataset names of gensimple_horns.py:61-67 and
+    sample.py:202-211, gzip + shuffle filters, values back bit for bit."""
+    import pytest
+    h5py = pytest.importorskip("h5py")
+    from massivedatans_amd import gen, sample
+    data = gen.horns(6)
+    path = str(tmp_path / "data_widths_6.hdf5")
+    gen.save(path, data)
+    with h5py.File(path, "r") as f:
+        assert {"x", "y", "z"} <= set(f.keys())
+        assert f["y"].compression == "gzip" and f["y"].shuffle
+        assert np.array_equal(f["y"][()], data["y"])
+    assert np.array_equal(gen.load(path, 4)["y"], data["y"][:, :4])
+
+    class S:
+        ndraws, nevals = 12, 48
+    w = [[np.zeros((6, 3)), np.ones((6, 3)), np.arange(6.), np.zeros(6), np.ones(6, bool)]] * 3
+    prefix = str(tmp_path / "out")
+    sample.save_results(prefix, dict(logZ=np.arange(6.), logZerr=np.ones(6), weights=w), S, 1.5, 6)
+    with h5py.File(prefix + ".hdf5", "r") as f:
+        assert set(f.keys()) == {"logZ", "logZerr", "u", "x", "L", "w", "mask", "ndraws"}
+        assert f["u"].shape == (3, 6, 3) and f["L"].compression == "gzip" and f["L"].shuffle
+        assert int(f["ndraws"][()]) == 12 and np.array_equal(f["logZ"][()], np.arange(6.))
