@@ -227,6 +227,14 @@ int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B, double noi
                           const int *row_ids, int M, int *accepted, double *Lrow,
                           unsigned long long *fillbits);
 #define MDNS_JOINT_MAX_BATCH 1024
+/* The two halves of that call for hosts that put something between them: `score` stages the
+ * candidates and leaves one accept flag per candidate on the device (mdns_joint_flags_dev); with
+ * the data sets sharded over several GPUs the ranks MAX-reduce those flags; `commit` then takes
+ * the first flagged candidate and returns its index, likelihood row and fill bits for the
+ * selection given to `score`. */
+int mdns_joint_score(mdns_joint *j, const double *params, int B, double noise_level,
+                     const int *row_ids, int M);
+int mdns_joint_commit(mdns_joint *j, int *accepted, double *Lrow, unsigned long long *fillbits);
 
 /* Current thresholds of all data sets, higher f64[ndata] (tests; NaN before the first prepare),
  * and the shelf sizes n int32[ndata]. */

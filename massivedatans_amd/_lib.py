@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "mdns_count_within_dev", "mdns_bootstrap_round_maxsq_dev",
     "mdns_joint_create", "mdns_joint_destroy", "mdns_joint_init_gauss", "mdns_joint_set_live",
     "mdns_joint_get_live", "mdns_joint_set_running", "mdns_joint_prepare", "mdns_joint_keep_words",
-    "mdns_joint_advance", "mdns_joint_reserve", "mdns_joint_shelf_cap", "mdns_joint_draw_gauss",
+    "mdns_joint_advance", "mdns_joint_reserve", "mdns_joint_shelf_cap", "mdns_joint_draw_gauss", "mdns_joint_score", "mdns_joint_commit",
     "mdns_joint_get_thresholds", "mdns_joint_score_dev", "mdns_joint_flags_dev", "mdns_joint_commit_dev",
     "mdns_joint_result_dev", "mdns_joint_result_bytes", "mdns_joint_prepare_dev", "mdns_joint_advance_dev",
     "mdns_joint_restore_live_dev", "mdns_joint_live_dev",
@@ -117,6 +117,8 @@ def _declare(lib):
         "mdns_joint_reserve": (i, [vp, i]),
         "mdns_joint_shelf_cap": (i, [vp]),
         "mdns_joint_draw_gauss": (i, [vp, vp, i, d, vp, i, vp, vp, vp]),
+        "mdns_joint_score": (i, [vp, vp, i, d, vp, i]),
+        "mdns_joint_commit": (i, [vp, vp, vp, vp]),
         "mdns_joint_get_thresholds": (i, [vp, vp, vp]),
         "mdns_joint_score_dev": (i, [vp, vp, i, d, vp, i]),
         "mdns_joint_flags_dev": (vp, [vp]),

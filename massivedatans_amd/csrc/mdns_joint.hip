@@ -142,6 +142,10 @@ struct mdns_joint {
 	int last_bt = 0, last_B = 0;
 	double last_scale = 0;
 	bool prepared = false;
+	// what mdns_joint_score staged for the commit that follows
+	bool staged_rows = false;
+	int staged_M = 0;
+	size_t staged_in_bytes = 0;
 };
 
 static size_t result_bytes(int M) { return sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8 + (size_t) M * 8; }
@@ -438,46 +442,56 @@ extern "C" int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M)
 	                                d_row_ids, M, j->d_flags, j->st, base, bits, Lrow) ? 0 : 1;
 }
 
-extern "C" int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B, double noise_level,
-                                     const int *row_ids, int M, int *accepted, double *Lrow,
-                                     unsigned long long *fillbits)
+// host-pointer halves of the draw: `score` stages candidates and selection and leaves the accept
+// flags on the device; `commit` finishes with whatever the flags say by then (a multi-GPU host
+// reduces them over the ranks in between) and copies the outcome back
+static int joint_stage_and_score(mdns_joint *j, const double *params, int B, double noise_level,
+                                 const int *row_ids, int M, const char *who)
 {
 	Context *c = ctx();
-	if (!c || !check_draw(j, B, M, "mdns_joint_draw_gauss")) return 1;
-	if (!accepted) { set_error("mdns_joint_draw_gauss: null output"); return 1; }
-	if (!j->prepared) { set_error("mdns_joint_draw_gauss: thresholds are not set (call mdns_joint_prepare first)"); return 1; }
-	*accepted = -1;
-	if (B == 0 || M == 0) return 0;
+	if (!c || !check_draw(j, B, M, who)) return 1;
+	if (!j->prepared) { set_error("%s: thresholds are not set (call mdns_joint_prepare first)", who); return 1; }
 	if (row_ids) {
 		for (int k = 0; k < M; k++)
 			if (row_ids[k] < 0 || row_ids[k] >= j->ndata || (k > 0 && row_ids[k] <= row_ids[k - 1])) {
-				set_error("mdns_joint_draw_gauss: row_ids must be ascending indices below %d (row_ids[%d]=%d)", j->ndata, k, row_ids[k]);
+				set_error("%s: row_ids must be ascending indices below %d (row_ids[%d]=%d)", who, j->ndata, k, row_ids[k]);
 				return 1;
 			}
-	} else if (M != j->ndata) {
-		set_error("mdns_joint_draw_gauss: M=%d without row_ids (ndata=%d)", M, j->ndata);
+	} else if (M != j->ndata && M != 0) {
+		set_error("%s: M=%d without row_ids (ndata=%d)", who, M, j->ndata);
 		return 1;
 	}
 	const size_t pbytes = (size_t) B * 24, rbytes = row_ids ? (size_t) M * 4 : 0;
 	const size_t in_bytes = (pbytes + rbytes + 15) & ~(size_t) 15;
-	const size_t out_bytes = result_bytes(M);
-	char *pin = joint_pin(j, in_bytes + out_bytes);
+	char *pin = joint_pin(j, in_bytes + result_bytes(j->ndata));
 	if (!pin) return 1;
-	memcpy(pin, params, pbytes);
-	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
-	if (row_ids) {
+	if (pbytes) {
+		memcpy(pin, params, pbytes);
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	}
+	if (rbytes) {
 		memcpy(pin + pbytes, row_ids, rbytes);
 		if (!MDNS_HIP(hipMemcpyAsync(j->d_rows, pin + pbytes, rbytes, hipMemcpyHostToDevice, c->stream))) return 1;
 	}
-	const int *d_rows = row_ids ? j->d_rows : nullptr;
-	if (mdns_joint_score_dev(j, j->d_params, B, noise_level, d_rows, M) != 0) return 1;
-	if (mdns_joint_commit_dev(j, d_rows, M) != 0) return 1;
-	char *out = pin + in_bytes;
+	j->staged_rows = row_ids != nullptr;
+	j->staged_M = M;
+	j->staged_in_bytes = in_bytes;
+	return mdns_joint_score_dev(j, j->d_params, B, noise_level, row_ids ? j->d_rows : nullptr, M);
+}
+
+static int joint_commit_and_fetch(mdns_joint *j, int *accepted, double *Lrow, unsigned long long *fillbits, const char *who)
+{
+	Context *c = ctx();
+	if (!c || !j) return 1;
+	const int M = j->staged_M;
+	if (mdns_joint_commit_dev(j, j->staged_rows ? j->d_rows : nullptr, M) != 0) return 1;
+	const size_t out_bytes = result_bytes(M);
+	char *out = j->h_pin + j->staged_in_bytes;
 	// the header says whether the rest matters, but one copy of at most 80 KB costs less than a
 	// second round trip
 	if (!MDNS_HIP(hipMemcpyAsync(out, j->d_result, out_bytes, hipMemcpyDeviceToHost, c->stream)) || !joint_sync(c)) return 1;
 	const JointHeader *h = (const JointHeader *) out;
-	if (h->status) { set_error("mdns_joint_draw_gauss: a shelf overflowed its capacity %d (mdns_joint_reserve)", j->cap); return 1; }
+	if (h->status) { set_error("%s: a shelf overflowed its capacity %d (mdns_joint_reserve)", who, j->cap); return 1; }
 	*accepted = h->accepted;
 	if (h->accepted >= 0) {
 		const size_t nb = (size_t) ((M + 63) / 64) * 8;
@@ -485,4 +499,29 @@ extern "C" int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B,
 		if (Lrow) memcpy(Lrow, out + sizeof(JointHeader) + nb, (size_t) M * 8);
 	}
 	return 0;
+}
+
+extern "C" int mdns_joint_score(mdns_joint *j, const double *params, int B, double noise_level,
+                                const int *row_ids, int M)
+{
+	return joint_stage_and_score(j, params, B, noise_level, row_ids, M, "mdns_joint_score");
+}
+
+extern "C" int mdns_joint_commit(mdns_joint *j, int *accepted, double *Lrow, unsigned long long *fillbits)
+{
+	if (!accepted) { set_error("mdns_joint_commit: null output"); return 1; }
+	*accepted = -1;
+	return joint_commit_and_fetch(j, accepted, Lrow, fillbits, "mdns_joint_commit");
+}
+
+extern "C" int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B, double noise_level,
+                                     const int *row_ids, int M, int *accepted, double *Lrow,
+                                     unsigned long long *fillbits)
+{
+	if (!accepted) { set_error("mdns_joint_draw_gauss: null output"); return 1; }
+	*accepted = -1;
+	if (!check_draw(j, B, M, "mdns_joint_draw_gauss")) return 1;
+	if (B == 0 || M == 0) return 0;
+	if (joint_stage_and_score(j, params, B, noise_level, row_ids, M, "mdns_joint_draw_gauss") != 0) return 1;
+	return joint_commit_and_fetch(j, accepted, Lrow, fillbits, "mdns_joint_draw_gauss");
 }

@@ -112,6 +112,33 @@ class HostJointState(object):
             chunk = min(self.MAX_CHUNK, 2 * chunk)
         return -1, None, None, len(params)
 
+    # the two halves of draw(), for a host that reduces the accept flags over several states
+    # (parallel.ShardedJointState) in between
+    def score(self, xs, rows):
+        """Accept flag of every candidate of the chunk against the selected data sets."""
+        rows = numpy.arange(self.ndata) if rows is None else numpy.asarray(rows, dtype=int)
+        self._scored_rows = rows
+        if len(rows) == 0 or len(xs) == 0:
+            self._scored_L = numpy.zeros((len(xs), 0))
+            return numpy.zeros(len(xs), dtype=numpy.int32)
+        mask = numpy.zeros(self.ndata, dtype=bool)
+        mask[rows] = True
+        self._scored_L = self.scorer.loglike_batch(self.to_kernel_params(xs), mask)
+        self.nevals_scored += self._scored_L.size
+        self.ncalls += 1
+        return (self._scored_L > self.higher[rows]).any(axis=1).astype(numpy.int32)
+
+    def commit(self, idx):
+        """Candidate ``idx`` of the scored chunk is the accepted point: its likelihoods over the
+        scored selection, which data sets it beats; those take it in."""
+        rows = self._scored_rows
+        Lrow = self._scored_L[idx]
+        beats = Lrow > self.higher[rows]
+        for d, L in zip(rows[beats], Lrow[beats]):
+            self.shelfL[d].append(L)
+            self.higher[d] = self._threshold(d)
+        return Lrow, beats
+
     def advance(self):
         for d in self.running:
             self.live[self.argmin[d], d] = self.shelfL[d].pop(0)
@@ -236,6 +263,62 @@ class GaussJointState(object):
         else:
             self.shelf_n[rows[beats]] += 1
         return idx, self._Lrow[:M].copy(), beats, B
+
+    # the two halves of draw() (include/mdns.h: mdns_joint_score / mdns_joint_commit)
+    def _reserve_for(self, rows):
+        nmax = int(self.shelf_n.max()) if rows is None else (int(self.shelf_n[rows].max()) if len(rows) else 0)
+        if nmax + 1 > self.cap:
+            self._check(self._lib.mdns_joint_reserve(self._h, nmax + 1), "mdns_joint_reserve")
+            self.cap = self._lib.mdns_joint_shelf_cap(self._h)
+
+    def score(self, xs, rows):
+        """Scores the chunk; the accept flags stay on the device (``flags`` / ``set_flags`` /
+        ``flags_address`` reach them)."""
+        B = len(xs)
+        if B > _lib.JOINT_MAX_BATCH:
+            raise ValueError("at most %d candidates per chunk" % _lib.JOINT_MAX_BATCH)
+        if rows is not None:
+            rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
+        M = self.ndata if rows is None else len(rows)
+        self._reserve_for(rows)
+        params = _lib.as_f64(self.to_kernel_params(xs)) if B else numpy.zeros((0, 3))
+        self._scored_rows, self._scored_B = rows, B
+        self._check(self._lib.mdns_joint_score(self._h, _lib.ptr(params), B, self.noise_level,
+                                               _lib.ptr(rows) if rows is not None and M else None, M), "mdns_joint_score")
+        self.nevals_scored += B * M
+        self.ncalls += 1
+
+    def flags_address(self):
+        return self._lib.mdns_joint_flags_dev(self._h)
+
+    def flags(self):
+        out = numpy.zeros(self._scored_B, dtype=numpy.int32)
+        if self._scored_B:
+            self._check(self._lib.mdns_d2h(_lib.ptr(out), self.flags_address(), out.nbytes), "mdns_d2h")
+        return out
+
+    def set_flags(self, flags):
+        flags = numpy.ascontiguousarray(flags, dtype=numpy.int32)
+        if len(flags):
+            self._check(self._lib.mdns_h2d(self.flags_address(), _lib.ptr(flags), flags.nbytes), "mdns_h2d")
+
+    def commit(self, idx=None):
+        """The first flagged candidate (``idx`` is only checked against it) is the accepted point."""
+        rows = self._scored_rows
+        M = self.ndata if rows is None else len(rows)
+        self._check(self._lib.mdns_joint_commit(self._h, C.byref(self._accepted), _lib.ptr(self._Lrow), _lib.ptr(self._bits)),
+                    "mdns_joint_commit")
+        got = self._accepted.value
+        if M == 0:
+            return numpy.zeros(0), numpy.zeros(0, dtype=bool)
+        if got < 0 or (idx is not None and got != idx):
+            raise _lib.MdnsError("mdns_joint_commit accepted candidate %d, expected %s" % (got, idx))
+        beats = numpy.unpackbits(self._bits[:(M + 63) // 64].view(numpy.uint8), bitorder='little')[:M].astype(bool)
+        if rows is None:
+            self.shelf_n[beats] += 1
+        else:
+            self.shelf_n[rows[beats]] += 1
+        return self._Lrow[:M].copy(), beats
 
     def advance(self):
         self._check(self._lib.mdns_joint_advance(self._h), "mdns_joint_advance")

@@ -142,3 +142,137 @@ class ShardedGaussLine(object):
         b = shard_bounds(self.ndata, self.world)
         counts = [int(data_mask[b[r]:b[r + 1]].sum()) for r in range(self.world)]
         return allgather_columns(block, counts)
+
+
+class ShardedJointState(object):
+    """The joint sampler state (``jointstate``) with the data sets sharded over the ranks: rank r
+    keeps live likelihoods, shelves and thresholds of ITS block next to its block of spectra.
+    Per draw chunk the ranks exchange
+
+    * one MAX all-reduce of the accept flags (B integers): every rank learns the first candidate
+      that ANY data set accepts -- not the likelihoods ``L[B, M]``;
+    * one all-gather of the accepted candidate's block: likelihoods + fill bits of the selected
+      data sets of each rank (M numbers in all), for the host bookkeeping every rank repeats.
+
+    Per iteration: the per-data-set minima / slots / purge decisions of ``prepare`` (an object
+    gather; once per iteration).  With the ``nccl`` backend the flags are reduced on the device
+    (the state's flag buffer is copied into a CUDA tensor on the library stream, RCCL reduces it
+    there); with ``gloo`` through the host.  Same interface as the single-process states."""
+
+    def __init__(self, local, ndata, lo, hi):
+        torch, dist = _dist()
+        self.local, self.ndata, self.lo, self.hi = local, int(ndata), int(lo), int(hi)
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.bounds = shard_bounds(self.ndata, self.world)
+        self.nlive = local.nlive
+        self.running = np.arange(self.ndata)
+        self._device_flags = dist.get_backend() == "nccl" and hasattr(local, "flags_address")
+        if self._device_flags:
+            from . import _lib
+            self._flags_t = torch.zeros(_lib.JOINT_MAX_BATCH, dtype=torch.int32, device=_device())
+        self.nevals_scored = 0
+        self.ncalls = 0
+
+    def close(self):
+        if hasattr(self.local, "close"):
+            self.local.close()
+
+    def _mine(self, rows):
+        """(local indices of the selected data sets of this rank, their number per rank)."""
+        if rows is None:
+            return None, np.diff(self.bounds)
+        rows = np.asarray(rows)
+        counts = np.diff(np.searchsorted(rows, self.bounds))
+        a = int(np.searchsorted(rows, self.lo))
+        return rows[a:a + counts[self.rank]] - self.lo, counts
+
+    def init(self, xs):
+        self.local.init(xs)
+        self.ncalls += 1
+
+    def set_running(self, running):
+        self.running = np.asarray(running, dtype=int)
+        mine, _ = self._mine(self.running)
+        self.local.set_running(mine)
+
+    def chunk_size(self, offered, M, hint=None):
+        return self.local.chunk_size(offered, M, hint)       # from global numbers: the same on every rank
+
+    def prepare(self):
+        torch, dist = _dist()
+        mine = self.local.prepare()
+        parts = [None] * self.world
+        dist.all_gather_object(parts, mine)
+        Lmin = np.concatenate([p[0] for p in parts])
+        arg = np.concatenate([p[1] for p in parts])
+        if all(p[2] is None for p in parts):
+            return Lmin, arg, None
+        width = max(p[2].shape[1] for p in parts if p[2] is not None)
+        keep = np.ones((len(Lmin), max(width, 1)), dtype=bool)      # a rank that dropped nothing keeps everything
+        at = 0
+        for p in parts:
+            n = len(p[0])
+            if p[2] is not None:
+                keep[at:at + n, :] = False
+                keep[at:at + n, :p[2].shape[1]] = p[2]
+            at += n
+        return Lmin, arg, keep
+
+    def _reduce_flags(self, B):
+        torch, dist = _dist()
+        if self._device_flags:
+            from . import _lib
+            lib = _lib.load()
+            _lib.check(lib.mdns_d2d(self._flags_t.data_ptr(), self.local.flags_address(), 4 * B), "mdns_d2d")
+            dist.all_reduce(self._flags_t, op=dist.ReduceOp.MAX)
+            _lib.check(lib.mdns_d2d(self.local.flags_address(), self._flags_t.data_ptr(), 4 * B), "mdns_d2d")
+            return self._flags_t[:B].cpu().numpy()
+        flags = torch.from_numpy(np.ascontiguousarray(self._local_flags, dtype=np.int32)).to(_device())
+        dist.all_reduce(flags, op=dist.ReduceOp.MAX)
+        flags = flags.cpu().numpy()
+        if hasattr(self.local, "set_flags"):
+            self.local.set_flags(flags)
+        return flags
+
+    def draw(self, xs, rows):
+        torch, dist = _dist()
+        mine, counts = self._mine(rows)
+        B = len(xs)
+        self._local_flags = self.local.score(xs, mine)
+        if self._local_flags is None and not self._device_flags:
+            self._local_flags = self.local.flags()
+        self.ncalls += 1
+        self.nevals_scored += B * int(counts.sum())
+        flags = self._reduce_flags(B)
+        hit = np.flatnonzero(flags)
+        if len(hit) == 0:
+            return -1, None, None, B
+        idx = int(hit[0])
+        Lrow, beats = self.local.commit(idx)
+        # the accepted candidate's block of every rank: likelihoods, then fill bits
+        width = int(counts.max())
+        block = np.zeros(2 * width)
+        block[:len(Lrow)] = Lrow
+        block[width:width + len(beats)] = beats
+        mine_t = torch.from_numpy(block).to(_device())
+        gathered = torch.empty(self.world * 2 * width, dtype=mine_t.dtype, device=_device())
+        dist.all_gather_into_tensor(gathered, mine_t)
+        g = gathered.cpu().numpy().reshape(self.world, 2, width)
+        L = np.concatenate([g[r, 0, :counts[r]] for r in range(self.world)])
+        b = np.concatenate([g[r, 1, :counts[r]] for r in range(self.world)]) != 0
+        return idx, L, b, B
+
+    def advance(self):
+        self.local.advance()
+
+    def live_matrix(self):
+        torch, dist = _dist()
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self.local.live_matrix())
+        return np.concatenate(parts, axis=1)
+
+    def thresholds(self):
+        torch, dist = _dist()
+        parts = [None] * self.world
+        dist.all_gather_object(parts, self.local.thresholds())
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])

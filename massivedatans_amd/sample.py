@@ -106,11 +106,19 @@ class GaussLineProblem(object):
         """The sampler's floating-point state next to the spectra: on the GPU for the HIP
         backend (accept test and shelf fill there), in numpy over any other
         scorer."""
-        from . import jointstate
+        from . import jointstate, parallel
         from .like import GaussLineSpectra
-        if isinstance(self.backend, GaussLineSpectra):
-            return jointstate.GaussJointState(self.backend, nlive_points, kernel_params)
-        return jointstate.HostJointState(self.backend, nlive_points, self.ndata, kernel_params)
+
+        def build(scorer, ndata):
+            if isinstance(scorer, GaussLineSpectra):
+                return jointstate.GaussJointState(scorer, nlive_points, kernel_params)
+            return jointstate.HostJointState(scorer, nlive_points, ndata, kernel_params)
+
+        if isinstance(self.backend, parallel.ShardedGaussLine):
+            # one process per GPU: every rank keeps the state of ITS block of data sets
+            b = self.backend
+            return parallel.ShardedJointState(build(b.local, b.hi - b.lo), self.ndata, b.lo, b.hi)
+        return build(self.backend, self.ndata)
 
 
 def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False, seed=1, batched=True,
@@ -143,7 +151,8 @@ def run(x, y, nlive_points=400, nsuperset_draws=10, use_graph=False, max_samples
     True on the GPU (MDNS_FUSED=0 turns it off)."""
     problem = GaussLineProblem(x, y, backend=backend)
     if fused is None:
-        fused = backend is None and os.environ.get('MDNS_FUSED', '1') != '0'
+        from .parallel import ShardedGaussLine
+        fused = (backend is None or isinstance(backend, ShardedGaussLine)) and os.environ.get('MDNS_FUSED', '1') != '0'
     start = time.time()
     sampler = build_sampler(problem, nlive_points, nsuperset_draws, use_graph, seed, batched, fused)
     results = multi_nested_integrator(tolerance=tolerance, multi_sampler=sampler,
@@ -192,8 +201,16 @@ def distributed_backend(x, y):
         else:
             dist.init_process_group(backend=backend)
     os.environ.setdefault('MDNS_DEVICE', str(device))
+    from . import _lib
     from .like import GaussLineSpectra
     from .parallel import ShardedGaussLine
+    if backend == 'nccl':
+        # kernels and RCCL collectives on ONE stream (torch's current one; its default is the null
+        # stream, which the library reads as "my own"): the accept flags are reduced on the device
+        import ctypes
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        _lib.check(_lib.require_device().mdns_set_stream(ctypes.c_void_p(stream.cuda_stream)), 'mdns_set_stream')
     return ShardedGaussLine(x, y, lambda xs, ys: GaussLineSpectra(xs, ys, noise_level=noise_level))
 
 
