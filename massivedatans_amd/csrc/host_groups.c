@@ -190,18 +190,29 @@ typedef struct mdns_walk {
 	int32_t *cnt;                   /* holders in the CURRENT selection */
 	int64_t *first;                 /* start of the id's holder list (ids with >= 2 holders in the base) */
 	int32_t *len;                   /* its length in the base */
-	int32_t *seen;                  /* call tag: listed / pending in this call */
+	uint64_t *listed;               /* bit per id: in the point list of this call (clean between calls) */
+	uint64_t *pending;              /* bit per id: found in the batch being assembled */
+	int32_t *pos;                   /* where a listed id stands in the point list (valid while its bit is set) */
+	int32_t *qbatch;                /* the batch an id was listed in, in the kept result */
 	int64_t cap_points;
 	/* per data set */
 	uint8_t *cur;                   /* in the current selection */
 	uint8_t *todo;
+	uint8_t *isnew;                 /* joined in the batch being assembled (clean between batches) */
+	int32_t *dbatch;                /* the batch a data set joined in, in the kept result */
+	int32_t *dgroup;                /* its group there (-1: not selected) */
 	int64_t cap_data;
 	/* base */
 	int32_t *holders;  int64_t cap_holders;
-	int32_t *touched;  int64_t ntouched, cap_touched;      /* ids with a holder in the base */
+	int32_t *touched;  int64_t ntouched, cap_touched;      /* ids with a holder in the base, ASCENDING */
+	int32_t *unlisted; int64_t cap_unlisted;               /* ids of the current selection not yet listed, ascending */
+	/* the result of the last walk, kept to derive the next one when only a few data sets left */
+	int32_t *res_points; int64_t res_used, cap_res;
+	int64_t *res_offsets; int32_t *res_lead; int64_t cap_groups;
+	int res_ngroups, have_result;
+	int32_t *gone; int64_t cap_gone;
 	int64_t base_nsel, cur_nsel, ndistinct;
 	int have_base;
-	int32_t tag;
 	/* scratch */
 	int32_t *sel;  int32_t *fresh;  int32_t *sort_tmp;  int64_t cap_scratch;
 } mdns_walk;
@@ -211,7 +222,9 @@ mdns_walk *mdns_host_walk_create(void) { return (mdns_walk *) calloc(1, sizeof(m
 void mdns_host_walk_destroy(mdns_walk *w)
 {
 	if (!w) return;
-	free(w->cnt); free(w->first); free(w->len); free(w->seen); free(w->cur); free(w->todo);
+	free(w->cnt); free(w->first); free(w->len); free(w->listed); free(w->pending); free(w->pos); free(w->cur);
+	free(w->todo); free(w->isnew); free(w->unlisted); free(w->qbatch); free(w->dbatch); free(w->dgroup);
+	free(w->res_points); free(w->res_offsets); free(w->res_lead); free(w->gone);
 	free(w->holders); free(w->touched); free(w->sel); free(w->fresh); free(w->sort_tmp);
 	free(w);
 }
@@ -231,61 +244,55 @@ static int walk_fit(void **p, int64_t *cap, int64_t need, size_t elem, int zero)
 int mdns_host_walk_reset(mdns_walk *w, const int32_t *lpT, int nlive, int ndata, int64_t npoints)
 {
 	if (!w) return -1;
-	/* counts and tags of the ids the old base touched go back to zero */
-	for (int64_t t = 0; t < w->ntouched; t++) { w->cnt[w->touched[t]] = 0; w->seen[w->touched[t]] = 0; }
-	w->ntouched = 0; w->have_base = 0; w->tag = 0;
+	/* counts of the ids the old base touched go back to zero */
+	for (int64_t t = 0; t < w->ntouched; t++) w->cnt[w->touched[t]] = 0;
+	w->ntouched = 0; w->have_base = 0; w->have_result = 0;
 	w->lpT = lpT; w->nlive = nlive; w->ndata = ndata; w->npoints = npoints;
 	if (npoints > w->cap_points) {
-		int64_t c1 = w->cap_points, c2 = w->cap_points, c3 = w->cap_points, c4 = w->cap_points;
+		/* (the bit maps are clean between calls, so fresh zeroed ones are as good as the old) */
+		int64_t c1 = w->cap_points, c2 = w->cap_points, c3 = w->cap_points, c6 = w->cap_points, c7 = w->cap_points;
+		int64_t c4 = (w->cap_points + 63) / 64, c5 = (w->cap_points + 63) / 64;
 		if (!walk_fit((void **) &w->cnt, &c1, npoints, sizeof(int32_t), 1) ||
 		    !walk_fit((void **) &w->first, &c2, npoints, sizeof(int64_t), 0) ||
 		    !walk_fit((void **) &w->len, &c3, npoints, sizeof(int32_t), 0) ||
-		    !walk_fit((void **) &w->seen, &c4, npoints, sizeof(int32_t), 1)) return -1;
+		    !walk_fit((void **) &w->pos, &c6, npoints, sizeof(int32_t), 0) ||
+		    !walk_fit((void **) &w->qbatch, &c7, npoints, sizeof(int32_t), 0) ||
+		    !walk_fit((void **) &w->listed, &c4, (npoints + 63) / 64 + 1, sizeof(uint64_t), 1) ||
+		    !walk_fit((void **) &w->pending, &c5, (npoints + 63) / 64 + 1, sizeof(uint64_t), 1)) return -1;
 		w->cap_points = c1 < c2 ? c1 : c2;
 		if (c3 < w->cap_points) w->cap_points = c3;
-		if (c4 < w->cap_points) w->cap_points = c4;
+		if (c6 < w->cap_points) w->cap_points = c6;
+		if (c7 < w->cap_points) w->cap_points = c7;
+		if ((c4 - 1) * 64 < w->cap_points) w->cap_points = (c4 - 1) * 64;
+		if ((c5 - 1) * 64 < w->cap_points) w->cap_points = (c5 - 1) * 64;
 	}
 	if (ndata > w->cap_data) {
-		int64_t c1 = w->cap_data, c2 = w->cap_data;
-		if (!walk_fit((void **) &w->cur, &c1, ndata, 1, 1) || !walk_fit((void **) &w->todo, &c2, ndata, 1, 1)) return -1;
+		int64_t c1 = w->cap_data, c2 = w->cap_data, c3 = w->cap_data, c4 = w->cap_data, c5 = w->cap_data;
+		int64_t c6 = w->cap_groups, c7 = w->cap_groups, c8 = w->cap_gone;
+		if (!walk_fit((void **) &w->cur, &c1, ndata, 1, 1) || !walk_fit((void **) &w->todo, &c2, ndata, 1, 1) ||
+		    !walk_fit((void **) &w->isnew, &c3, ndata, 1, 1) ||
+		    !walk_fit((void **) &w->dbatch, &c4, ndata, sizeof(int32_t), 0) ||
+		    !walk_fit((void **) &w->dgroup, &c5, ndata, sizeof(int32_t), 0) ||
+		    !walk_fit((void **) &w->res_offsets, &c6, ndata + 1, sizeof(int64_t), 0) ||
+		    !walk_fit((void **) &w->res_lead, &c7, ndata + 1, sizeof(int32_t), 0) ||
+		    !walk_fit((void **) &w->gone, &c8, ndata, sizeof(int32_t), 0)) return -1;
 		w->cap_data = c1 < c2 ? c1 : c2;
+		if (c3 < w->cap_data) w->cap_data = c3;
+		if (c4 < w->cap_data) w->cap_data = c4;
+		if (c5 < w->cap_data) w->cap_data = c5;
+		w->cap_groups = c6 < c7 ? c6 : c7;
+		w->cap_gone = c8;
 	}
 	memset(w->cur, 0, (size_t) ndata);
 	return 0;
-}
-
-static void sort_i32(int32_t *v, int64_t n, int32_t *tmp)
-{
-	if (n < 2) return;
-	if (n < 64) {                                   /* insertion sort */
-		for (int64_t i = 1; i < n; i++) {
-			const int32_t x = v[i];
-			int64_t j = i;
-			while (j > 0 && v[j - 1] > x) { v[j] = v[j - 1]; j--; }
-			v[j] = x;
-		}
-		return;
-	}
-	int32_t top = 0;
-	for (int64_t i = 0; i < n; i++) if (v[i] > top) top = v[i];
-	int32_t *src = v, *dst = tmp;
-	for (int shift = 0; shift < 32 && (top >> shift) != 0; shift += 8) {
-		int64_t count[257];
-		memset(count, 0, sizeof count);
-		for (int64_t i = 0; i < n; i++) count[((src[i] >> shift) & 255) + 1]++;
-		for (int b = 0; b < 256; b++) count[b + 1] += count[b];
-		for (int64_t i = 0; i < n; i++) dst[count[(src[i] >> shift) & 255]++] = src[i];
-		int32_t *t = src; src = dst; dst = t;
-	}
-	if (src != v) memcpy(v, src, (size_t) n * sizeof(int32_t));
 }
 
 /* make `mask` the base: holder index over exactly these data sets */
 static int walk_rebase(mdns_walk *w, const uint8_t *mask, int64_t nsel)
 {
 	const int nlive = w->nlive;
-	for (int64_t t = 0; t < w->ntouched; t++) { w->cnt[w->touched[t]] = 0; w->seen[w->touched[t]] = 0; }
-	w->ntouched = 0; w->tag = 0;
+	for (int64_t t = 0; t < w->ntouched; t++) w->cnt[w->touched[t]] = 0;
+	w->ntouched = 0;
 	if (!walk_fit((void **) &w->holders, &w->cap_holders, nsel * nlive, sizeof(int32_t), 0)) return 0;
 	{
 		const int64_t bound = nsel * nlive < w->npoints ? nsel * nlive : w->npoints;
@@ -307,6 +314,23 @@ static int walk_rebase(mdns_walk *w, const uint8_t *mask, int64_t nsel)
 		for (int k = 0; k < nlive; k++) if (w->cnt[ids[k]]++ == 0) w->touched[nt++] = ids[k];
 	}
 	w->ntouched = nt; w->ndistinct = nt;
+	if (!walk_fit((void **) &w->unlisted, &w->cap_unlisted, nt, sizeof(int32_t), 0)) return 0;
+	/* the touched ids ascending: through the (clean) bit map */
+	if (nt > 0) {
+		int32_t lo = INT32_MAX, hi = -1;
+		for (int64_t t = 0; t < nt; t++) {
+			const int32_t q = w->touched[t];
+			w->listed[q >> 6] |= 1ull << (q & 63);
+			if (q < lo) lo = q;
+			if (q > hi) hi = q;
+		}
+		int64_t n = 0;
+		for (int64_t wd = lo >> 6; wd <= hi >> 6; wd++) {
+			uint64_t bits = w->listed[wd];
+			w->listed[wd] = 0;
+			while (bits) { w->touched[n++] = (int32_t) (wd * 64 + __builtin_ctzll(bits)); bits &= bits - 1; }
+		}
+	}
 	int64_t at = 0;
 	for (int64_t t = 0; t < nt; t++) {
 		const int32_t p = w->touched[t];
@@ -316,11 +340,16 @@ static int walk_rebase(mdns_walk *w, const uint8_t *mask, int64_t nsel)
 	for (int d = 0; d < w->ndata; d++) {                       /* ascending data sets: lists come out sorted */
 		if (!w->cur[d]) continue;
 		const int32_t *ids = w->lpT + (size_t) d * nlive;
-		for (int k = 0; k < nlive; k++) if (w->len[ids[k]] >= 2) w->holders[w->first[ids[k]]++] = d;
+		for (int k = 0; k < nlive; k++) {
+			const int32_t q = ids[k];
+			if (w->len[q] >= 2) w->holders[w->first[q]++] = d;
+			else w->first[q] = d;                               /* a single holder: kept instead of a list */
+		}
 	}
 	for (int64_t t = 0; t < nt; t++) { const int32_t p = w->touched[t]; if (w->len[p] >= 2) w->first[p] -= w->len[p]; }
 	w->base_nsel = w->cur_nsel = nsel;
 	w->have_base = 1;
+	w->have_result = 0;
 	return 1;
 }
 
@@ -338,7 +367,7 @@ int mdns_host_walk_groups(mdns_walk *w, const uint8_t *mask, int32_t *group_of, 
 {
 	if (!w || !w->lpT) return -1;
 	const int nlive = w->nlive, ndata = w->ndata;
-	int64_t nsel = 0;
+	int64_t nsel = 0, ngone = 0;
 	int subset = w->have_base;
 	for (int d = 0; d < ndata; d++) {
 		const int m = mask[d] != 0;
@@ -352,81 +381,244 @@ int mdns_host_walk_groups(mdns_walk *w, const uint8_t *mask, int32_t *group_of, 
 		for (int d = 0; d < ndata; d++) {
 			if (!w->cur[d] || mask[d]) continue;
 			w->cur[d] = 0;
+			w->gone[ngone++] = d;
 			const int32_t *ids = w->lpT + (size_t) d * nlive;
 			for (int k = 0; k < nlive; k++) if (--w->cnt[ids[k]] == 0) w->ndistinct--;
 		}
 		w->cur_nsel = nsel;
 	}
 	*ndistinct = w->ndistinct;
-	if (w->tag > 0x3ffffff0) {                                  /* tags wrap: start over (never in practice) */
-		for (int64_t t = 0; t < w->ntouched; t++) w->seen[w->touched[t]] = 0;
-		w->tag = 0;
-	}
-	const int32_t listed = ++w->tag, pending = ++w->tag;
+	uint64_t *listed = w->listed, *pending = w->pending;
+#define BIT(map, q) ((map)[(q) >> 6] >> ((q) & 63) & 1)
+#define SET(map, q) ((map)[(q) >> 6] |= 1ull << ((q) & 63))
 	if (sorted_distinct || w->ndistinct < sort_below) {
 		if (w->ndistinct > cap) return -2;
-		int64_t n = 0;
+		w->have_result = 0;
+		/* the distinct ids, ascending: marked in a bit map, read off word by word */
+		int32_t lo = INT32_MAX, hi = -1;
 		for (int d = 0; d < ndata; d++) {
 			if (!w->cur[d]) continue;
 			const int32_t *ids = w->lpT + (size_t) d * nlive;
-			for (int k = 0; k < nlive; k++) if (w->seen[ids[k]] != listed) { w->seen[ids[k]] = listed; points[n++] = ids[k]; }
+			for (int k = 0; k < nlive; k++) {
+				const int32_t q = ids[k];
+				SET(listed, q);
+				if (q < lo) lo = q;
+				if (q > hi) hi = q;
+			}
 		}
-		sort_i32(points, n, w->sort_tmp);
+		int64_t n = 0;
+		if (hi >= 0)
+			for (int64_t wd = lo >> 6; wd <= hi >> 6; wd++) {
+				uint64_t bits = listed[wd];
+				listed[wd] = 0;
+				while (bits) { points[n++] = (int32_t) (wd * 64 + __builtin_ctzll(bits)); bits &= bits - 1; }
+			}
 		return 0;
 	}
+	/* Only a few data sets left since the last walk of this base?  Then the new lists are the
+	 * old ones without the ids nobody holds any more -- provided no group lost its first data
+	 * set and every id a departed data set shares with the remaining ones was listed in a batch
+	 * that still has one of its holders: then every remaining data set is brought in by the same
+	 * point as before and every id is found in the same batch (see the header comment). */
+	if (w->have_result && ngone * 8 < w->cur_nsel + ngone) {
+		int ok = 1;
+		for (int64_t gi = 0; gi < ngone && ok; gi++) {
+			const int x = w->gone[gi];
+			if (w->res_lead[w->dgroup[x]] == x) { ok = 0; break; }
+			const int32_t *ids = w->lpT + (size_t) x * nlive;
+			for (int k = 0; k < nlive && ok; k++) {
+				const int32_t q = ids[k];
+				if (w->cnt[q] == 0) continue;                       /* leaves the list with x */
+				const int32_t want = w->qbatch[q];
+				const int32_t *list = w->holders + w->first[q];      /* cnt > 0 and x held it: at least two base holders */
+				const int32_t n = w->len[q];
+				int32_t h = 0;
+				for (; h < n; h++) { const int y = list[h]; if (w->cur[y] && w->dbatch[y] == want) break; }
+				ok = h < n;
+			}
+		}
+		if (ok) {
+			for (int64_t gi = 0; gi < ngone; gi++) w->dgroup[w->gone[gi]] = -1;
+			int64_t used = 0;
+			for (int g = 0; g < w->res_ngroups; g++) {
+				const int64_t from = w->res_offsets[g], to = w->res_offsets[g + 1];
+				w->res_offsets[g] = used;
+				for (int64_t i = from; i < to; i++) {
+					const int32_t q = w->res_points[i];
+					if (w->cnt[q] > 0) w->res_points[used++] = q;
+				}
+			}
+			w->res_offsets[w->res_ngroups] = used;
+			if (used > cap) return -2;
+			memcpy(points, w->res_points, (size_t) used * sizeof(int32_t));
+			memcpy(offsets, w->res_offsets, (size_t) (w->res_ngroups + 1) * sizeof(int64_t));
+			memcpy(group_of, w->dgroup, (size_t) ndata * sizeof(int32_t));
+			w->res_used = used;
+			return w->res_ngroups;
+		}
+	}
+	w->have_result = 0;
 	for (int d = 0; d < ndata; d++) { w->todo[d] = w->cur[d]; group_of[d] = -1; }
 	int64_t used = 0, left = nsel;
 	int next_first = 0, ngroups = 0;
 	offsets[0] = 0;
-	int32_t *sel = w->sel, *fresh = w->fresh;
+	int32_t *sel = w->sel, *pos = w->pos;
+	uint8_t *todo = w->todo, *isnew = w->isnew;
+	/* ids of the selection not yet in a list, ascending (those that got listed meanwhile are
+	 * dropped when the array is next walked) */
+	int64_t nunl = 0;
+	for (int64_t t = 0; t < w->ntouched; t++) if (w->cnt[w->touched[t]] > 0) w->unlisted[nunl++] = w->touched[t];
+	enum { STRAGGLERS = 16 };
+	int32_t rest[STRAGGLERS];
+	int32_t batch = 0;                                          /* counts leads and bringing points */
 	while (left > 0) {
-		while (!w->todo[next_first]) next_first++;
+		while (!todo[next_first]) next_first++;
 		const int lead = next_first;
-		w->todo[lead] = 0; left--;
+		todo[lead] = 0; left--;
 		group_of[lead] = ngroups;
+		w->res_lead[ngroups] = lead;
+		w->dbatch[lead] = ++batch;
 		const int64_t begin = used;
-		if (used + nlive > cap) return -2;
+		if (used + nlive > cap) { ngroups = -2; break; }
 		for (int k = 0; k < nlive; k++) {
 			const int32_t p = w->lpT[(size_t) lead * nlive + k];
+			pos[p] = (int32_t) used;
+			w->qbatch[p] = batch;
 			points[used++] = p;
-			w->seen[p] = listed;
+			SET(listed, p);
 		}
-		for (int64_t i = begin; i < used && left > 0; i++) {
-			const int32_t p = points[i];
-			if (w->cnt[p] < 2) continue;                        /* held by nobody else in the selection */
+		int64_t i = begin;
+		int nrest = -1;                                         /* >= 0: the data sets still to place are in rest[] */
+		while (i < used && left > 0) {
 			int64_t nnew = 0;
-			const int32_t *list = w->holders + w->first[p];
-			for (int32_t h = 0; h < w->len[p]; h++) {
-				const int d = list[h];
-				if (w->todo[d]) { w->todo[d] = 0; left--; group_of[d] = ngroups; sel[nnew++] = d; }
+			if (left <= STRAGGLERS) {
+				/* A handful of data sets are left: instead of scanning the holder lists of all the
+				 * points still to come, look where each of them first meets the list. */
+				if (nrest < 0) {
+					nrest = 0;
+					for (int d = next_first; d < ndata && nrest < left; d++) if (todo[d]) rest[nrest++] = d;
+				}
+				int64_t best = INT64_MAX;
+				int64_t meets[STRAGGLERS];
+				for (int r = 0; r < nrest; r++) {
+					const int32_t *ids = w->lpT + (size_t) rest[r] * nlive;
+					int64_t e = INT64_MAX;
+					for (int k = 0; k < nlive; k++) {
+						const int32_t q = ids[k];
+						if (BIT(listed, q) && pos[q] < e) e = pos[q];
+					}
+					meets[r] = e;
+					if (e < best) best = e;
+				}
+				if (best == INT64_MAX) break;                   /* nobody left shares a point with this group */
+				i = best + 1;                                   /* (a point before i would have brought them in already) */
+				int keep = 0;
+				for (int r = 0; r < nrest; r++) {
+					if (meets[r] == best) { const int d = rest[r]; todo[d] = 0; left--; group_of[d] = ngroups; sel[nnew++] = d; }
+					else rest[keep++] = rest[r];
+				}
+				nrest = keep;
+			} else {
+				const int32_t p = points[i++];
+				if (w->cnt[p] < 2) continue;                    /* held by nobody else in the selection */
+				const int32_t *list = w->holders + w->first[p];
+				for (int32_t h = 0; h < w->len[p]; h++) {
+					const int d = list[h];
+					if (todo[d]) { todo[d] = 0; left--; group_of[d] = ngroups; sel[nnew++] = d; }
+				}
+				if (!nnew) continue;
 			}
-			if (!nnew) continue;
-			int64_t nfresh = 0;
+			++batch;
+			for (int64_t m = 0; m < nnew; m++) w->dbatch[sel[m]] = batch;
+			/* The not yet listed ids of the newcomers, ascending and each once: marked in the
+			 * `pending` bit map, then read off word by word.  Marking goes through the newcomers'
+			 * rows (nnew * nlive ids), or -- when a batch brings in so many data sets that this
+			 * is the larger number -- through the unlisted ids, each asking its holders. */
 			int32_t lo = INT32_MAX, hi = -1;
-			for (int64_t m = 0; m < nnew; m++) {
-				const int32_t *ids = w->lpT + (size_t) sel[m] * nlive;
-				for (int k = 0; k < nlive; k++) {
-					const int32_t q = ids[k];
-					if (w->seen[q] != listed && w->seen[q] != pending) {            /* each once */
-						w->seen[q] = pending; fresh[nfresh++] = q;
-						if (q < lo) lo = q;
-						if (q > hi) hi = q;
+			int by_rows = 1;
+			if (nnew * nlive > 4 * nunl && nunl > 0) {
+				for (int64_t m = 0; m < nnew; m++) isnew[sel[m]] = 1;
+				int64_t budget = nnew * nlive, keep = 0;
+				by_rows = 0;
+				for (int64_t t = 0; t < nunl; t++) {
+					const int32_t q = w->unlisted[t];
+					if (BIT(listed, q) || w->cnt[q] == 0) continue;   /* listed meanwhile */
+					int found = 0;
+					if (w->len[q] < 2) found = isnew[w->first[q]];
+					else {
+						const int32_t *list = w->holders + w->first[q];
+						const int32_t n = w->len[q];
+						int32_t h = 0;
+						for (; h < n && !isnew[list[h]]; h++) { }
+						found = h < n;
+						budget -= h;
+					}
+					if (found) { SET(pending, q); if (q < lo) lo = q; hi = q; }
+					else w->unlisted[keep++] = q;
+					if (budget < 0) {                                  /* not worth it after all */
+						for (int64_t u = t + 1; u < nunl; u++) w->unlisted[keep++] = w->unlisted[u];
+						by_rows = 1;
+						break;
+					}
+				}
+				nunl = keep;
+				for (int64_t m = 0; m < nnew; m++) isnew[sel[m]] = 0;
+				if (by_rows && hi >= 0) {
+					/* the marks made so far are valid (a marked id is fresh either way) but the
+					 * ids dropped from `unlisted` with them must stay findable: they are, through
+					 * the rows pass below, which marks every fresh id again */
+				}
+			}
+			if (by_rows) {
+				for (int64_t m = 0; m < nnew; m++) {
+					const int32_t *ids = w->lpT + (size_t) sel[m] * nlive;
+					for (int k = 0; k < nlive; k++) {
+						const int32_t q = ids[k];
+						const uint64_t fresh = ~listed[q >> 6] >> (q & 63) & 1;
+						pending[q >> 6] |= fresh << (q & 63);
+						lo = fresh && q < lo ? q : lo;
+						hi = fresh && q > hi ? q : hi;
 					}
 				}
 			}
-			/* ascending: a dense batch is read off the marks in id order, a sparse one is sorted */
-			if (nfresh >= 192 && (int64_t) hi - lo < 24 * nfresh) {
-				int64_t n = 0;
-				for (int32_t q = lo; q <= hi; q++) if (w->seen[q] == pending) { w->seen[q] = listed; fresh[n++] = q; }
-			} else {
-				for (int64_t f = 0; f < nfresh; f++) w->seen[fresh[f]] = listed;
-				sort_i32(fresh, nfresh, w->sort_tmp);
+			if (hi < 0) continue;
+			int overflow = 0;
+			for (int64_t wd = lo >> 6; wd <= hi >> 6; wd++) {
+				uint64_t bits = pending[wd];
+				if (!bits) continue;
+				pending[wd] = 0;
+				if (used + __builtin_popcountll(bits) > cap) { overflow = 1; continue; }
+				listed[wd] |= bits;
+				while (bits) {
+					const int32_t q = (int32_t) (wd * 64 + __builtin_ctzll(bits));
+					pos[q] = (int32_t) used;
+					w->qbatch[q] = batch;
+					points[used++] = q;
+					bits &= bits - 1;
+				}
 			}
-			if (used + nfresh > cap) return -2;
-			memcpy(points + used, fresh, (size_t) nfresh * sizeof(int32_t));
-			used += nfresh;
+			if (overflow) { ngroups = -2; break; }
 		}
+		if (ngroups < 0) break;
 		offsets[++ngroups] = used;
 	}
+	/* the bit maps go back clean: every listed id is in the point list */
+	for (int64_t i = 0; i < used; i++) listed[points[i] >> 6] = 0;
+	if (ngroups > 0 && walk_fit((void **) &w->res_points, &w->cap_res, used, sizeof(int32_t), 0)) {
+		memcpy(w->res_points, points, (size_t) used * sizeof(int32_t));
+		memcpy(w->res_offsets, offsets, (size_t) (ngroups + 1) * sizeof(int64_t));
+		memcpy(w->dgroup, group_of, (size_t) ndata * sizeof(int32_t));
+		w->res_used = used; w->res_ngroups = ngroups; w->have_result = 1;
+	}
+	if (ngroups < 0) {
+		/* an aborted call may have left marks outside the list: clear what the selection holds */
+		for (int d = 0; d < ndata; d++) {
+			if (!w->cur[d]) continue;
+			const int32_t *ids = w->lpT + (size_t) d * nlive;
+			for (int k = 0; k < nlive; k++) { listed[ids[k] >> 6] = 0; pending[ids[k] >> 6] = 0; }
+		}
+	}
+#undef BIT
+#undef SET
 	return ngroups;
 }

@@ -42,9 +42,19 @@ __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const 
 	const size_t nd = (size_t) st.ndata;
 	double m = st.live[d];
 	int am = 0;
-	for (int p = 1; p < st.nlive; p++) {
-		const double v = st.live[p * nd + d];
-		if (v < m) { m = v; am = p; }
+	{
+		int p = 1;
+		for (; p + 8 <= st.nlive; p += 8) {                      // eight loads in flight
+			double v[8];
+#pragma unroll
+			for (int u = 0; u < 8; u++) v[u] = st.live[(p + u) * nd + d];
+#pragma unroll
+			for (int u = 0; u < 8; u++) if (v[u] < m) { m = v[u]; am = p + u; }
+		}
+		for (; p < st.nlive; p++) {
+			const double v = st.live[p * nd + d];
+			if (v < m) { m = v; am = p; }
+		}
 	}
 	// purge (multi_nested_sampler.py:137-138: keep entries with L > Lmin, order kept)
 	const int n = st.shelfn[d];

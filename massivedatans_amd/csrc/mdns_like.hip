@@ -420,6 +420,55 @@ __device__ __forceinline__ void cols_accumulate(const double *__restrict__ YT, i
 	if (st == 1) stage(ya, yb, true);
 }
 
+// The same sums for launches too small to hide memory latency behind other waves (a draw over
+// a few hundred spectra, the one-candidate commit pass): a ring of NB stage buffers keeps NB - 1
+// stages of spectra values in flight instead of one.  Same operations in the same order per
+// (candidate, spectrum), so the same bits as cols_accumulate.
+template <int BT, int NB, bool RUNTIME_STRIDE>
+__device__ __forceinline__ void cols_accumulate_deep(const double *__restrict__ YT, int nxp,
+                                                     const double *mp, int mstride,
+                                                     const int *__restrict__ rows, int M, int tile, int lane,
+                                                     int &k, double (&acc)[BT])
+{
+	constexpr int CH = 8;
+	k = tile * 64 + lane;
+	int col = k;
+	if (rows) col = rows[k < M ? k : M - 1];
+	else if (col >= ((M + 63) & ~63)) col = M - 1;
+	const double *yp = YT + ((size_t) (col >> 6) * nxp << 6) + (col & 63);
+#pragma unroll
+	for (int b = 0; b < BT; b++) acc[b] = 0.0;
+	const int ms = RUNTIME_STRIDE ? mstride : BT;
+	const int nst = nxp / CH;
+	double y[NB][CH];
+#pragma unroll
+	for (int i = 0; i < NB - 1; i++) {
+		const double *p = yp + (size_t) min(i, nst - 1) * CH * 64;
+#pragma unroll
+		for (int c = 0; c < CH; c++) y[i][c] = p[c * 64];
+	}
+#pragma unroll 1
+	for (int s0 = 0; s0 < nst; s0 += NB) {
+#pragma unroll
+		for (int i = 0; i < NB; i++) {
+			const int s = s0 + i;                                // wave-uniform
+			if (s < nst) {
+				const double *p = yp + (size_t) min(s + NB - 1, nst - 1) * CH * 64;
+#pragma unroll
+				for (int c = 0; c < CH; c++) y[(i + NB - 1) % NB][c] = p[c * 64];
+				const double *m = mp + (size_t) s * CH * ms;
+#pragma unroll
+				for (int c = 0; c < CH; c++)
+#pragma unroll
+					for (int b = 0; b < BT; b++) {
+						const double d = m[c * ms + b] - y[i][c];
+						acc[b] = fma(d, d, acc[b]);
+					}
+			}
+		}
+	}
+}
+
 template <int BT, int SP>
 __global__ __launch_bounds__(kBlock) void k_gauss_cols(
     const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
@@ -448,7 +497,8 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 // (hiermetriclearn.py:193 `any(L > Lmins)`): nothing but one flag per candidate leaves the
 // kernel.  `thr_rows` names the data set behind every position of the selection (NULL: the
 // position itself), `higher` holds the thresholds of all data sets (multi_nested_sampler.py:438-447).
-template <int BT>
+// DEEP: the launch has too few waves to hide latency (see cols_accumulate_deep)
+template <int BT, bool DEEP>
 __global__ __launch_bounds__(kBlock) void k_gauss_cols_accept(
     const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
     double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
@@ -460,7 +510,8 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_accept(
 	const double *mp = model_t + (size_t) bt * nxp * BT;
 	int k[1];
 	double acc[1][BT];
-	cols_accumulate<BT, 1, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
+	if constexpr (DEEP) cols_accumulate_deep<BT, 4, false>(YT, nxp, mp, BT, rows, M, tile, lane, k[0], acc[0]);
+	else cols_accumulate<BT, 1, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
 	const bool live = k[0] < M;
 	const int kk = live ? k[0] : M - 1;
 	// a quiet NaN compares false with everything: lanes past the selection never vote
@@ -504,7 +555,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
 	const double *mp = model_t + (size_t) (bstar / mstride) * nxp * mstride + bstar % mstride;
 	int k[1];
 	double acc[1][1];
-	cols_accumulate<1, 1, true>(YT, nxp, mp, mstride, rows, M, tile, lane, k, acc);
+	cols_accumulate_deep<1, 4, true>(YT, nxp, mp, mstride, rows, M, tile, lane, k[0], acc[0]);
 	const bool live = k[0] < M;
 	const double L = acc[0][0] * scale;
 	bool beats = false;
@@ -523,7 +574,15 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
 				// it occurs more than once, else the smaller of L and the next value above it.
 				int at_most = 0;
 				double next = INFINITY;
-				for (int p = 0; p < st.nlive; p++) {
+				int p = 0;
+				for (; p + 8 <= st.nlive; p += 8) {                  // eight loads in flight
+					double v[8];
+#pragma unroll
+					for (int u = 0; u < 8; u++) v[u] = st.live[(size_t) (p + u) * st.ndata + d];
+#pragma unroll
+					for (int u = 0; u < 8; u++) { if (v[u] <= thr) at_most++; else next = fmin(next, v[u]); }
+				}
+				for (; p < st.nlive; p++) {
 					const double v = st.live[(size_t) p * st.ndata + d];
 					if (v <= thr) at_most++; else next = fmin(next, v);
 				}
@@ -892,15 +951,17 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 	int nq_xcd, cu_slots;
 	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots);
 	ProfileScope prof(0);
-	note_kernel(0, "k_gauss_cols_accept<%d>", bt);
-#define ACCEPT_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols_accept<BT>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+	note_kernel(0, "k_gauss_cols_accept<%d, %s>", bt, ((long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4) ? "true" : "false");
+	// fewer than two waves per SIMD: nothing hides a wave's memory latency but its own loads
+	const bool deep = (long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4;
+#define ACCEPT_LAUNCH(BT, DEEP) hipLaunchKernelGGL((k_gauss_cols_accept<BT, DEEP>), dim3(blocks), dim3(kBlock), 0, c->stream, \
 	d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags)
 	switch (bt) {
-	case 16: ACCEPT_LAUNCH(16); break;
-	case 8: ACCEPT_LAUNCH(8); break;
-	case 4: ACCEPT_LAUNCH(4); break;
-	case 2: ACCEPT_LAUNCH(2); break;
-	default: ACCEPT_LAUNCH(1); break;
+	case 16: ACCEPT_LAUNCH(16, false); break;
+	case 8: ACCEPT_LAUNCH(8, false); break;
+	case 4: if (deep) ACCEPT_LAUNCH(4, true); else ACCEPT_LAUNCH(4, false); break;
+	case 2: if (deep) ACCEPT_LAUNCH(2, true); else ACCEPT_LAUNCH(2, false); break;
+	default: if (deep) ACCEPT_LAUNCH(1, true); else ACCEPT_LAUNCH(1, false); break;
 	}
 #undef ACCEPT_LAUNCH
 	return launched("k_gauss_cols_accept");

@@ -182,9 +182,8 @@ class MultiNestedSampler(object):
         self.ndraws = nlive_points
         self._shelves = _Shelves(ndata)
         self._real_indices = None
-        self._lpT = None                    # live_pointsp relabelled + transposed, for the native grouping walk
-        self._alive = None
-        self._label = numpy.zeros(1024, dtype=numpy.int32)
+        self._lpT = None                    # live_pointsp transposed (int32), for the native grouping walk
+        self._walk_stale = True
         self._walk = None                   # native incremental grouping walk (csrc/host_groups.c)
         self._low = None                    # smallest live likelihoods per data set (_refresh_thresholds)
         self._low_cap = -1
@@ -337,49 +336,42 @@ class MultiNestedSampler(object):
             yield data_mask, self.live_pointsp[:, numpy.flatnonzero(data_mask)[0]]
             return
         if self._lpT is None:
-            # Once per iteration (the matrix is fixed while the shelves are filled): the ids in
-            # use, relabelled 0..nalive-1 in ascending order, and the matrix transposed.  The pile
-            # holds every point ever accepted (millions by the end of a run); the walk's work
-            # arrays must be as long as the ids in use, not as the pile.
-            self._alive = numpy.flatnonzero(self._refcount[:len(self.pointpile)])
-            if len(self._label) < len(self.pointpile):
-                self._label = numpy.zeros(max(2 * len(self._label), len(self.pointpile) + 1024), dtype=numpy.int32)
-            self._label[self._alive] = numpy.arange(len(self._alive), dtype=numpy.int32)
-            self._lpT = numpy.ascontiguousarray(self._label[self.live_pointsp.T])
+            # the id matrix with one ROW per data set (the walk reads whole data sets), int32;
+            # kept up to date by __next__ / cut_down instead of being rebuilt every iteration
+            self._lpT = numpy.ascontiguousarray(self.live_pointsp.T, dtype=numpy.int32)
+            self._walk_stale = True
+        if self._walk_stale:
             if self._walk is None:
                 self._walk = lib.mdns_host_walk_create()
                 if not self._walk:
                     raise MemoryError("mdns_host_walk_create")
+            # ids are rows of the pile: the walk's per-id arrays are as long as the pile (they
+            # are only ever touched at the ids a selection holds)
             if lib.mdns_host_walk_reset(self._walk, self._lpT.ctypes.data, self._lpT.shape[1], self._lpT.shape[0],
-                                        len(self._alive)) != 0:
+                                        len(self.pointpile)) != 0:
                 raise MemoryError("mdns_host_walk_reset")
+            self._walk_stale = False
         lp = self._lpT
-        alive = self._alive
         ndata, nlive = lp.shape
         mask8 = numpy.ascontiguousarray(data_mask, dtype=numpy.uint8)
         group_of = numpy.empty(ndata, dtype=numpy.int32)
         offsets = numpy.empty(ndata + 1, dtype=numpy.int64)
         ndistinct = ctypes.c_int64(0)
-        cap = min(len(alive), nsel * nlive) + nlive
+        cap = nsel * nlive + nlive                    # a group's list never exceeds its members' ids
         trivial = 1 if len(self.superpoints) > 0 else 0
-        while True:
-            points = numpy.empty(cap, dtype=numpy.int32)
-            n = lib.mdns_host_walk_groups(self._walk, mask8.ctypes.data, group_of.ctypes.data, points.ctypes.data, cap,
-                                          offsets.ctypes.data, ctypes.byref(ndistinct), trivial, 2 * self.nlive_points)
-            if n != -2:
-                break
-            cap = nsel * nlive                        # columns with repeated ids: the safe bound
+        points = numpy.empty(cap, dtype=numpy.int32)
+        n = lib.mdns_host_walk_groups(self._walk, mask8.ctypes.data, group_of.ctypes.data, points.ctypes.data, cap,
+                                      offsets.ctypes.data, ctypes.byref(ndistinct), trivial, 2 * self.nlive_points)
         if n < 0:
-            raise MemoryError("mdns_host_walk_groups")
+            raise MemoryError("mdns_host_walk_groups (%d)" % n)
         if n == 0:
             # some points are shared by all, or there are few of them: one group, ids ascending
-            # (labels ascend with the ids)
-            yield data_mask, alive[points[:ndistinct.value]]
+            yield data_mask, points[:ndistinct.value]
         elif n == 1:
-            yield data_mask.copy(), alive[points[:offsets[1]]]
+            yield data_mask.copy(), points[:offsets[1]]
         else:
             for g in range(n):
-                yield group_of == g, alive[points[offsets[g]:offsets[g + 1]]]
+                yield group_of == g, points[offsets[g]:offsets[g + 1]]
 
     def _groups_native_stateless(self, lib, data_mask):
         """The same through the stateless entry point (one index build per call); kept as the
@@ -703,7 +695,9 @@ class MultiNestedSampler(object):
             self.superpoints.difference_update(numpy.unique(dead).tolist())
         newp, newL = self._shelves.pop_heads()
         self.live_pointsp[Lmini, every] = newp
-        self._lpT = None
+        if self._lpT is not None:
+            self._lpT[every, Lmini] = newp
+        self._walk_stale = True
         if self.joint is not None:
             self.joint.advance()
             self._live_cache = None

@@ -154,9 +154,8 @@ def _fake_sampler(lp, npoints, nlive):
     s.point_data_map = None
     s.ndata = lp.shape[1]
     s._lpT = None
-    s._alive = None
     s._walk = None
-    s._label = np.zeros(16, dtype=np.int32)
+    s._walk_stale = True
     s._refcount = np.bincount(lp.ravel(), minlength=npoints)
     return s
 
