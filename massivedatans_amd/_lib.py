@@ -169,8 +169,9 @@ def require_device():
 
 
 def ptr(a):
-    """Raw data pointer of a C-contiguous numpy array (kept alive by the caller)."""
-    return a.ctypes.data_as(C.c_void_p)
+    """Raw data pointer (an int; every pointer argument is declared c_void_p) of a C-contiguous
+    numpy array that the caller keeps alive."""
+    return a.ctypes.data
 
 
 def as_f64(a):

@@ -59,13 +59,13 @@ static int init_locked(int device)
 		set_error("device %d requested but only %d visible", device, count);
 		return 1;
 	}
-	if (g_ctx_ready) {       // switching device: drop per-device scratch
-		if (g_ctx.d_ws) (void) hipFree(g_ctx.d_ws);
-		if (g_ctx.d_mask) (void) hipFree(g_ctx.d_mask);
-		if (g_ctx.h_pin) (void) hipHostFree(g_ctx.h_pin);
-		if (g_ctx.own_stream) (void) hipStreamDestroy(g_ctx.own_stream);
-		g_ctx = Context();
-		g_ctx_ready = false;
+	if (g_ctx_ready) {
+		// One process drives ONE GPU (include/mdns.h): spectra, regions, result slots, pooled
+		// buffers and events all live on the first device; handing them to another one would use
+		// them across devices.
+		set_error("mdns_init(%d): this process already runs on device %d; one process drives one GPU "
+		          "(start one process per GPU)", device, g_ctx.device);
+		return 1;
 	}
 	if (!MDNS_HIP(hipSetDevice(device))) return 1;
 	hipDeviceProp_t prop;

@@ -144,7 +144,7 @@ struct mdns_joint {
 	char *d_result = nullptr;          // = (char *) (d_flags + kFlagInts)
 	// staging of the host-pointer draw
 	double *d_params = nullptr;
-	int *d_rows = nullptr;
+	int *d_rows = nullptr;             // inside d_params' block, behind the candidates
 	char *h_pin = nullptr;  size_t pin_bytes = 0;
 	// what the last score launched with (commit uses the same spectra replica and templates)
 	const double *last_yT = nullptr;
@@ -170,7 +170,7 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
 	void *bufs[] = {j->st.live, j->st.shelfL, j->st.shelfn, j->st.higher, j->d_running, j->d_Lmin, j->d_argmin_run,
-	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params, j->d_rows};
+	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	if (j->h_pin) (void) hipHostFree(j->h_pin);
 	delete j;
@@ -198,8 +198,8 @@ extern "C" mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_c
 	    MDNS_HIP(hipMalloc((void **) &j->d_argmin, nd * sizeof(int))) &&
 	    MDNS_HIP(hipMalloc((void **) &j->d_status, sizeof(int))) &&
 	    MDNS_HIP(hipMalloc((void **) &j->d_flags, res)) &&
-	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 3 * sizeof(double))) &&
-	    MDNS_HIP(hipMalloc((void **) &j->d_rows, nd * sizeof(int)));
+	    // candidates [B, 3] followed by the selection's row ids: one staging block
+	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 3 * sizeof(double) + nd * sizeof(int) + 16));
 	if (ok) {
 		j->d_result = (char *) (j->d_flags + kFlagInts);
 		j->st.nlive = nlive; j->st.cap = shelf_cap; j->st.ndata = s->ndata;
@@ -471,18 +471,16 @@ static int joint_stage_and_score(mdns_joint *j, const double *params, int B, dou
 		set_error("%s: M=%d without row_ids (ndata=%d)", who, M, j->ndata);
 		return 1;
 	}
+	// candidates and selection travel together: one pinned block, one copy
 	const size_t pbytes = (size_t) B * 24, rbytes = row_ids ? (size_t) M * 4 : 0;
 	const size_t in_bytes = (pbytes + rbytes + 15) & ~(size_t) 15;
 	char *pin = joint_pin(j, in_bytes + result_bytes(j->ndata));
 	if (!pin) return 1;
-	if (pbytes) {
-		memcpy(pin, params, pbytes);
-		if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
-	}
-	if (rbytes) {
-		memcpy(pin + pbytes, row_ids, rbytes);
-		if (!MDNS_HIP(hipMemcpyAsync(j->d_rows, pin + pbytes, rbytes, hipMemcpyHostToDevice, c->stream))) return 1;
-	}
+	if (pbytes) memcpy(pin, params, pbytes);
+	if (rbytes) memcpy(pin + pbytes, row_ids, rbytes);
+	if (pbytes + rbytes &&
+	    !MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes + rbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	j->d_rows = (int *) ((char *) j->d_params + pbytes);
 	j->staged_rows = row_ids != nullptr;
 	j->staged_M = M;
 	j->staged_in_bytes = in_bytes;

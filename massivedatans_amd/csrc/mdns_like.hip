@@ -343,7 +343,8 @@ __device__ __forceinline__ bool cols_item(int ntiles, int nq_xcd, int nbt, int c
 	if (first + round >= next) return false;
 	bt = (first + round) / nq_xcd;
 	const int quad = ((first + round) % nq_xcd) * 8 + xcd;
-	tile = quad * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int wpb = blockDim.x >> 6;                          // waves (spectrum tiles) per workgroup: 4
+	tile = quad * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	return tile < ntiles;
 }
 
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 // position itself), `higher` holds the thresholds of all data sets (multi_nested_sampler.py:438-447).
 // DEEP: the launch has too few waves to hide latency (see cols_accumulate_deep)
 template <int BT, bool DEEP>
-__global__ __launch_bounds__(kBlock) void k_gauss_cols_accept(
+__global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_accept(
     const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
     double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
     int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, int *__restrict__ flags)
@@ -869,9 +870,9 @@ bool launch_gauss_model(const double *d_x, int nx, const double *d_params, int B
 }
 
 // grid of the lane kernels for `ntiles` spectrum tiles and `nbt` candidate tiles (see cols_item)
-static int cols_grid(const Context *c, int ntiles, int nbt, int &nq_xcd, int &cu_slots)
+static int cols_grid(const Context *c, int ntiles, int nbt, int &nq_xcd, int &cu_slots, int wpb = 4)
 {
-	const int nquads = (ntiles + 3) / 4;
+	const int nquads = (ntiles + wpb - 1) / wpb;
 	nq_xcd = (nquads + 7) / 8;                              // quads per XCD (some may be empty)
 	cu_slots = c->num_cus >= 8 ? c->num_cus / 8 : 1;
 	const int rounds = (nbt * nq_xcd + cu_slots - 1) / cu_slots;
@@ -949,12 +950,15 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 	const int ntiles = (M + 63) / 64;
 	const int nbt = (B + bt - 1) / bt;
 	int nq_xcd, cu_slots;
-	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots);
+	// (512-thread workgroups -- 8 spectrum tiles of a candidate tile per workgroup, fewer template
+	// streams per CU -- measured slower: 48.7 vs 43.4 us at 10 000 x 256)
+	const int wpb = 4;
+	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots, wpb);
 	ProfileScope prof(0);
 	note_kernel(0, "k_gauss_cols_accept<%d, %s>", bt, ((long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4) ? "true" : "false");
 	// fewer than two waves per SIMD: nothing hides a wave's memory latency but its own loads
 	const bool deep = (long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4;
-#define ACCEPT_LAUNCH(BT, DEEP) hipLaunchKernelGGL((k_gauss_cols_accept<BT, DEEP>), dim3(blocks), dim3(kBlock), 0, c->stream, \
+#define ACCEPT_LAUNCH(BT, DEEP) hipLaunchKernelGGL((k_gauss_cols_accept<BT, DEEP>), dim3(blocks), dim3(64 * wpb), 0, c->stream, \
 	d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags)
 	switch (bt) {
 	case 16: ACCEPT_LAUNCH(16, false); break;

@@ -12,7 +12,7 @@ frozen by numpy's compatibility policy):
 The reference stores ``y`` as ``[n_channels, n_datasets]`` (C order); that is what these
 functions return, so they can be fed to the drop-in ``like()`` entry points unchanged.  The
 device-resident layout ``[n_datasets, n_channels]`` is produced at upload time
-(:class:`massivedatans_amd.like.GaussLineData`).
+(:class:`massivedatans_amd.like.GaussLineSpectra`).
 
 File containers: a path ending in ``.hdf5`` / ``.h5`` is read and written through h5py exactly as
 the reference does (same dataset names, gzip + shuffle), so files of the reference's generators

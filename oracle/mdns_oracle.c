@@ -5,7 +5,7 @@
  * as the checker in tests/, in __graft_entry__.smoke() and as bench.py's cpu_baseline leg.
  * Nothing under massivedatans_amd/ may load, link or call this file.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_ref.py shows every function below to be
+ * Parity status: PINNED.  tests/test_oracle.py shows every function below to be
  * bit-identical to the reference's own C (compiled from /root/reference by oracle/Makefile
  * into oracle/_ref/) on seeded inputs, and the .npz fixtures in tests/golden (made by oracle/make_golden.py
  * from oracle/_ref) pins it where /root/reference is absent (the GPU box).

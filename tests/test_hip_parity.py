@@ -386,10 +386,11 @@ def test_registered_spectra_are_reused(hip, golden):
 
 
 def test_c4_size_single_gpu():
-    """100 000 spectra (config C4's total) on one GPU: sizes, indexing and the XCD tiling at a
-    grid 10x larger than the bench's; checked by properties (no oracle at this size)."""
+    """BASELINE.json configs[3]'s data -- gensimple_horns, 100 000 spectra -- on one GPU: sizes,
+    indexing and the XCD tiling at a grid 10x larger than the bench's; checked by properties
+    (the oracle checks one GPU's 12 500-spectra shard of it in the next test)."""
     from massivedatans_amd.like import GaussLineSpectra
-    d = gen.nothing(100000)
+    d = gen.horns(100000)
     sp = GaussLineSpectra(d["x"], d["y"])
     rng = np.random.RandomState(8)
     params = np.column_stack([rng.uniform(0.01, 1, 40), rng.uniform(400, 800, 40), 10 ** rng.uniform(0, 2, 40)])
@@ -404,6 +405,49 @@ def test_c4_size_single_gpu():
     m = np.zeros(100000, bool)
     m[cols] = True
     assert np.array_equal(sp.loglike_batch(params, m), full[:, m])   # 40 candidates, sparse: lane kernel + gather
+    sp.close()
+
+
+def test_c4_shard_against_the_oracle(oracle):
+    """One GPU's share of configs[3]: spectra 37 500..50 000 of gensimple_horns(100 000), i.e. what
+    rank 3 of 8 holds (parallel.shard_range), against the CPU oracle on the same columns -- the
+    batched lane kernel, the one-candidate row kernel and a sparse selection; plus the joint
+    state on that shard: a draw chunk decided on the device against the oracle's likelihoods."""
+    from massivedatans_amd import jointstate, parallel, sample
+    from massivedatans_amd.like import GaussLineSpectra
+    d = gen.horns(100000)
+    lo, hi = parallel.shard_range(100000, 3, 8)
+    assert (lo, hi) == (37500, 50000)
+    y = np.ascontiguousarray(d["y"][:, lo:hi])
+    sp = GaussLineSpectra(d["x"], y)
+    rng = np.random.RandomState(12)
+    params = np.column_stack([rng.uniform(0.01, 1, 24), rng.uniform(400, 800, 24), 10 ** rng.uniform(0, 2, 24)])
+    mask = np.ones(hi - lo, dtype=np.bool_)
+    got = sp.loglike_batch(params)
+    for b in (0, 7, 23):
+        want = -0.5 * oracle.gauss_like(d["x"], y, params[b, 0], params[b, 1], params[b, 2], 0.01, mask)
+        assert rel_err(got[b], want) < RTOL_L
+    assert rel_err(sp.loglike_batch(params[5:6])[0], got[5]) < 1e-13
+    sel = rng.uniform(size=hi - lo) < 0.02
+    want = -0.5 * oracle.gauss_like(d["x"], y, params[2, 0], params[2, 1], params[2, 2], 0.01, sel)
+    assert rel_err(sp.loglike_batch(params[:3], sel)[2], want) < RTOL_L
+    # a draw chunk on the shard: thresholds = lowest of 20 live points per spectrum
+    nlive = 20
+    js = jointstate.GaussJointState(sp, nlive, sample.kernel_params)
+    xs0 = sample.priortransform_batch(rng.uniform(size=(nlive, 3)))
+    js.init(xs0)
+    Lmin, arg, _ = js.prepare()
+    live = np.array([-0.5 * oracle.gauss_like(d["x"], y, p[0], p[1], p[2], 0.01, mask) for p in sample.kernel_params(xs0)])
+    assert np.array_equal(arg, live.argmin(axis=0)) and rel_err(Lmin, live.min(axis=0)) < RTOL_L
+    cube = rng.uniform(size=(64, 3))
+    xs = sample.priortransform_batch(cube)
+    idx, Lrow, beats, n = js.draw(xs, None)
+    Ls = np.array([-0.5 * oracle.gauss_like(d["x"], y, p[0], p[1], p[2], 0.01, mask) for p in sample.kernel_params(xs[:n])])
+    ok = (Ls > live.min(axis=0)).any(axis=1)
+    assert idx == (int(np.argmax(ok)) if ok.any() else -1)
+    if idx >= 0:
+        assert rel_err(Lrow, Ls[idx]) < RTOL_L and np.array_equal(beats, Ls[idx] > live.min(axis=0))
+    js.close()
     sp.close()
 
 
@@ -628,22 +672,60 @@ def test_c2_size_bookkeeping_matches_the_cpu_path(kind, cap):
     assert np.max(np.abs(results["logZ"][:5] - np.array(want["logZ_first5"]))) < 1e-9
 
 
+def test_c3_is_the_low_acceptance_stress_it_is_meant_to_be():
+    """BASELINE.json configs[2] (gennothing: no signal anywhere) exists to stress the RadFriends
+    proposals: the likelihood surfaces of the data sets disagree, so regions stay large and most
+    proposals are rejected.  On the first 400 iterations: the membership kernel (K3) sees many
+    more proposals than ever become candidates, and a constrained draw needs several tries --
+    both worse than on the horns data of configs[1], where a line pulls the data sets together."""
+    from massivedatans_amd import sample
+    from massivedatans_amd.clustering import neighbors
+    stats = {}
+    for kind in ("nothing", "horns"):
+        data = (gen.nothing if kind == "nothing" else gen.horns)(10000)
+        seen = {"proposed": 0, "inside": 0}
+        orig_count, orig_any = neighbors.MemberSet.count, neighbors.MemberSet.any
+
+        def count(self, points, _o=orig_count, _s=seen):
+            c = _o(self, points)
+            _s["proposed"] += len(c)
+            _s["inside"] += int((c > 0).sum())
+            return c
+
+        neighbors.MemberSet.count = count
+        neighbors.MemberSet.any = lambda self, points: count(self, points) > 0
+        try:
+            with np.errstate(all="ignore"):
+                results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=400, use_graph=False)
+        finally:
+            neighbors.MemberSet.count, neighbors.MemberSet.any = orig_count, orig_any
+        stats[kind] = dict(tries_per_draw=(sampler.ndraws - 100) / sampler.ndraw_calls,
+                           k3_proposals_per_try=seen["proposed"] / (sampler.ndraws - 100),
+                           inside_fraction=seen["inside"] / seen["proposed"])
+        if sampler.joint is not None:
+            sampler.joint.close()
+    n, h = stats["nothing"], stats["horns"]
+    assert n["tries_per_draw"] > 1.0 and n["k3_proposals_per_try"] > 1.0
+    assert 0.0 < n["inside_fraction"] < 1.0
+    print("RadFriends stress, first 400 iterations:", stats)
+
+
 @pytest.mark.parametrize("kind", ["nothing", "horns"])
 def test_full_run_matches_the_cpu_path(kind):
     """BASELINE.json configs[2] (10 000 no-signal spectra) / configs[1] (horns), 100 live points,
     TO TERMINATION on the GPU against the same complete run on the CPU oracle backends
     (tests/golden/full_c3.npz / full_c2.npz from oracle/make_full_run.py): same iterations and
     draws, the pile of accepted points byte for byte, and the evidences of all 10 000 data sets
-    within 1e-9 (relative bar of BASELINE.json: 1e-6).  The horns run takes 3.5 minutes on the
-    GPU (hours on the CPU) and only runs with MDNS_LONG_TESTS=1."""
+    within 1e-9 (relative bar of BASELINE.json: 1e-6).  The horns run takes a minute and a half
+    on the GPU (2.3 hours on the CPU path); MDNS_SKIP_LONG_TESTS=1 leaves it out."""
     import hashlib
     from massivedatans_amd import sample
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "tests", "golden", "full_c3.npz" if kind == "nothing" else "full_c2.npz")
     if not os.path.exists(path):
         pytest.skip("fixture not generated (oracle/make_full_run.py %s)" % kind)
-    if kind == "horns" and os.environ.get("MDNS_LONG_TESTS") != "1":
-        pytest.skip("3.5 minutes: set MDNS_LONG_TESTS=1")
+    if kind == "horns" and os.environ.get("MDNS_SKIP_LONG_TESTS") == "1":
+        pytest.skip("MDNS_SKIP_LONG_TESTS=1")
     with np.load(path) as f:
         want = {k: f[k] for k in f.files}
     data = (gen.nothing if kind == "nothing" else gen.horns)(10000)

@@ -104,3 +104,65 @@ def test_shard_bounds():
     assert parallel.shard_bounds(3, 8).tolist() == [0, 1, 2, 3, 3, 3, 3, 3, 3]
     m = np.arange(10) % 2 == 0
     assert parallel.local_mask(m, 1, 3).tolist() == m[4:7].tolist()
+
+
+_GPU_RANK_SCRIPT = r'''
+import os, sys, json
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch                      # before libmdns_hip: ONE HIP runtime per process (DESIGN.md 6)
+import torch.distributed as dist
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % sys.argv[2], rank=int(sys.argv[3]), world_size=2)
+from massivedatans_amd import gen, parallel, sample
+from massivedatans_amd.like import GaussLineSpectra
+from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
+d = gen.horns(300)
+backend = parallel.ShardedGaussLine(d["x"], d["y"], lambda x, y: GaussLineSpectra(x, y, noise_level=0.01))
+out = {}
+for fused in (False, True):
+    problem = sample.GaussLineProblem(d["x"], d["y"], backend=backend)
+    sampler = sample.build_sampler(problem, nlive_points=40, use_graph=False, seed=1, batched=True, fused=fused)
+    with np.errstate(all="ignore"):
+        res = multi_nested_integrator(tolerance=0.5, multi_sampler=sampler, min_samples=0, max_samples=120)
+    out["fused" if fused else "classic"] = dict(ndraws=int(sampler.ndraws), npoints=int(len(sampler.pointpile)),
+                                                pile=np.ascontiguousarray(sampler.pointpile).tobytes().hex()[:64],
+                                                logZ=[float(v) for v in res["logZ"][:5]],
+                                                joint=type(sampler.joint).__name__)
+print("RESULT " + json.dumps(out))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.gpu
+def test_two_ranks_share_the_gpu_with_hip_kernels(tmp_path):
+    """The N-rank analysis with the REAL kernels: two fresh child processes (never an exec from a
+    process that touched the GPU) share the one GPU, each holds half of the spectra
+    (parallel.ShardedGaussLine over like.GaussLineSpectra) and, in the fused form, half of the
+    joint state (parallel.ShardedJointState over jointstate.GaussJointState); they exchange through
+    gloo (RCCL wants one device per rank).  Both ranks, both forms and the single-process run
+    must take the same draws."""
+    import json
+    import subprocess
+    script = tmp_path / "rank.py"
+    script.write_text(_GPU_RANK_SCRIPT)
+    port = str(29600 + os.getpid() % 300)
+    env = dict(os.environ, MDNS_DEVICE="0")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, port, str(r)], env=env, stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    res = [json.loads([ln for ln in so.splitlines() if ln.startswith("RESULT ")][0][7:]) for so, _ in outs]
+    assert res[0] == res[1]
+    assert res[0]["fused"]["joint"] == "ShardedJointState" and res[0]["classic"]["joint"] == "NoneType"
+    for k in ("ndraws", "npoints", "pile"):
+        assert res[0]["fused"][k] == res[0]["classic"][k]
+    assert np.allclose(res[0]["fused"]["logZ"], res[0]["classic"]["logZ"], rtol=0, atol=1e-9)
+    # and the single process
+    from massivedatans_amd import gen, sample
+    d = gen.horns(300)
+    with np.errstate(all="ignore"):
+        results, sampler, _, _ = sample.run(d["x"], d["y"], nlive_points=40, max_samples=120, use_graph=False)
+    assert sampler.ndraws == res[0]["fused"]["ndraws"] and len(sampler.pointpile) == res[0]["fused"]["npoints"]
+    assert np.ascontiguousarray(sampler.pointpile).tobytes().hex()[:64] == res[0]["fused"]["pile"]
+    assert np.allclose(results["logZ"][:5], res[0]["fused"]["logZ"], rtol=0, atol=1e-9)
