@@ -15,6 +15,7 @@
 //   y and 1/v stay in registers over both passes of cmuselike.c:50-61 (scale, then chi), so
 //   the reference's two strided passes become one HBM pass.
 #include "mdns_internal.h"
+#include <climits>
 #include <cstdlib>
 
 namespace mdns {
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_rows(
 // feeds two v_add/v_fmac pairs.
 // Which (spectrum tile, candidate tile) a wave works on -- see the comments in k_gauss_cols.
 // Returns false when the wave has nothing to do.
-__device__ __forceinline__ bool cols_item(int ntiles, int nq_xcd, int nbt, int cu_slots, int &tile, int &bt)
+__device__ __forceinline__ bool cols_item(int ntiles, int tile_limit, int nq_xcd, int nbt, int cu_slots, int &tile, int &bt)
 {
 	// A workgroup takes 4 adjacent spectrum tiles (a "quad") of ONE candidate tile, so its
 	// waves pull the same template values through the scalar cache.  Workgroups are dealt
@@ -345,7 +346,8 @@ __device__ __forceinline__ bool cols_item(int ntiles, int nq_xcd, int nbt, int c
 	const int quad = ((first + round) % nq_xcd) * 8 + xcd;
 	const int wpb = blockDim.x >> 6;                          // waves (spectrum tiles) per workgroup: 4
 	tile = quad * wpb + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	return tile < ntiles;
+	(void) ntiles;
+	return tile < tile_limit;         // (INT_MAX: the caller has a workgroup barrier to reach first)
 }
 
 // The sums of one wave: acc[s][b] = sum over the channels, in ascending order, of
@@ -422,12 +424,17 @@ __device__ __forceinline__ void cols_accumulate(const double *__restrict__ YT, i
 }
 
 // The same sums for launches too small to hide memory latency behind other waves (a draw over
-// a few hundred spectra, the one-candidate commit pass): a ring of NB stage buffers keeps NB - 1
-// stages of spectra values in flight instead of one.  Same operations in the same order per
-// (candidate, spectrum), so the same bits as cols_accumulate.
-template <int BT, int NB, bool RUNTIME_STRIDE>
+// a few hundred spectra, the one-candidate commit pass).  Two changes, none to the arithmetic
+// (same operations in the same order per (candidate, spectrum): the same bits as
+// cols_accumulate): a ring of NB stage buffers keeps NB - 1 stages of spectra values in flight
+// instead of one, and the template values come from an LDS copy of the candidate tile
+// (`tpl`, [channel][BT], filled by the workgroup before the loop) as broadcast ds_read_b64 -- the
+// scalar loads of the big kernel expose their full latency once per stage when nothing else
+// runs on the SIMD (measured on the constrained draws of a real run: 29 us per launch of which
+// 3 are arithmetic).
+template <int BT, int NB>
 __device__ __forceinline__ void cols_accumulate_deep(const double *__restrict__ YT, int nxp,
-                                                     const double *mp, int mstride,
+                                                     const double *tpl,
                                                      const int *__restrict__ rows, int M, int tile, int lane,
                                                      int &k, double (&acc)[BT])
 {
@@ -439,7 +446,6 @@ __device__ __forceinline__ void cols_accumulate_deep(const double *__restrict__ 
 	const double *yp = YT + ((size_t) (col >> 6) * nxp << 6) + (col & 63);
 #pragma unroll
 	for (int b = 0; b < BT; b++) acc[b] = 0.0;
-	const int ms = RUNTIME_STRIDE ? mstride : BT;
 	const int nst = nxp / CH;
 	double y[NB][CH];
 #pragma unroll
@@ -457,17 +463,38 @@ __device__ __forceinline__ void cols_accumulate_deep(const double *__restrict__ 
 				const double *p = yp + (size_t) min(s + NB - 1, nst - 1) * CH * 64;
 #pragma unroll
 				for (int c = 0; c < CH; c++) y[(i + NB - 1) % NB][c] = p[c * 64];
-				const double *m = mp + (size_t) s * CH * ms;
+				const double *m = tpl + s * CH * BT;
 #pragma unroll
 				for (int c = 0; c < CH; c++)
 #pragma unroll
 					for (int b = 0; b < BT; b++) {
-						const double d = m[c * ms + b] - y[i][c];
+						const double d = m[c * BT + b] - y[i][c];
 						acc[b] = fma(d, d, acc[b]);
 					}
 			}
 		}
 	}
+}
+
+// copies n template values from global memory (stride `stride` doubles apart) into LDS, all of a
+// thread's loads in flight at once; ends with the workgroup barrier
+__device__ __forceinline__ void stage_templates(double *__restrict__ dst, const double *__restrict__ src, int n, int stride)
+{
+	constexpr int U = 4;
+	for (int base = 0; base < n; base += U * (int) blockDim.x) {
+		double r[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int e = base + u * (int) blockDim.x + (int) threadIdx.x;
+			r[u] = src[(size_t) (e < n ? e : n - 1) * stride];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const int e = base + u * (int) blockDim.x + (int) threadIdx.x;
+			if (e < n) dst[e] = r[u];
+		}
+	}
+	__syncthreads();
 }
 
 template <int BT, int SP>
@@ -479,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols(
 	// Work item of a wave = (spectrum tile, candidate tile), a spectrum tile being 64*SP
 	// spectra, one per workgroup wave (cols_item).
 	int tile, bt;
-	if (!cols_item(ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
+	if (!cols_item(ntiles, ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
 	const double *mp = model_t + (size_t) bt * nxp * BT;     // wave-uniform: CH*BT contiguous doubles per stage
 	int k[SP];                                // positions in the (compacted) output
 	double acc[SP][BT];
@@ -507,12 +534,20 @@ __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_accept(
 {
 	const int lane = threadIdx.x & 63;
 	int tile, bt;
-	if (!cols_item(ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
-	const double *mp = model_t + (size_t) bt * nxp * BT;
 	int k[1];
 	double acc[1][BT];
-	if constexpr (DEEP) cols_accumulate_deep<BT, 4, false>(YT, nxp, mp, BT, rows, M, tile, lane, k[0], acc[0]);
-	else cols_accumulate<BT, 1, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
+	if constexpr (DEEP) {
+		extern __shared__ __attribute__((aligned(16))) double tpl[];      // [nxp][BT]
+		const bool mine = cols_item(ntiles, INT_MAX, nq_xcd, nbt, cu_slots, tile, bt);   // false for whole workgroups only
+		if (!mine) return;
+		stage_templates(tpl, model_t + (size_t) bt * nxp * BT, nxp * BT, 1);
+		if (tile >= ntiles) return;
+		cols_accumulate_deep<BT, 4>(YT, nxp, tpl, rows, M, tile, lane, k[0], acc[0]);
+	} else {
+		if (!cols_item(ntiles, ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
+		const double *mp = model_t + (size_t) bt * nxp * BT;
+		cols_accumulate<BT, 1, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
+	}
 	const bool live = k[0] < M;
 	const int kk = live ? k[0] : M - 1;
 	// a quiet NaN compares false with everything: lanes past the selection never vote
@@ -540,7 +575,10 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
     int ntiles, int nq_xcd, int cu_slots, const int *__restrict__ flags, JointArrays st,
     JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits, double *__restrict__ Lrow)
 {
-	__shared__ int s_first;
+	// all LDS in the dynamic region (a static variable in front of it would leave the template
+	// column 4 bytes off its 8-byte alignment): [nxp] template doubles, then one int
+	extern __shared__ __attribute__((aligned(16))) double tpl[];
+	int &s_first = *reinterpret_cast<int *>(tpl + nxp);
 	if (threadIdx.x == 0) s_first = 0x7fffffff;
 	__syncthreads();
 	for (int b = threadIdx.x; b < B; b += kBlock)
@@ -551,12 +589,14 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
 	if (bstar >= B) return;
 	const int lane = threadIdx.x & 63;
 	int tile, bt_unused;
-	if (!cols_item(ntiles, nq_xcd, 1, cu_slots, tile, bt_unused)) return;
-	// templates are laid out [candidate tile][channel][mstride candidates]
-	const double *mp = model_t + (size_t) (bstar / mstride) * nxp * mstride + bstar % mstride;
+	if (!cols_item(ntiles, INT_MAX, nq_xcd, 1, cu_slots, tile, bt_unused)) return;      // whole workgroups only
+	// templates are laid out [candidate tile][channel][mstride candidates]: the accepted
+	// candidate's column goes to LDS
+	stage_templates(tpl, model_t + (size_t) (bstar / mstride) * nxp * mstride + bstar % mstride, nxp, mstride);
+	if (tile >= ntiles) return;
 	int k[1];
 	double acc[1][1];
-	cols_accumulate_deep<1, 4, true>(YT, nxp, mp, mstride, rows, M, tile, lane, k[0], acc[0]);
+	cols_accumulate_deep<1, 4>(YT, nxp, tpl, rows, M, tile, lane, k[0], acc[0]);
 	const bool live = k[0] < M;
 	const double L = acc[0][0] * scale;
 	bool beats = false;
@@ -955,10 +995,11 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 	const int wpb = 4;
 	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots, wpb);
 	ProfileScope prof(0);
-	note_kernel(0, "k_gauss_cols_accept<%d, %s>", bt, ((long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4) ? "true" : "false");
+	note_kernel(0, "k_gauss_cols_accept<%d, %s>", bt, ((long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4 && (size_t) cols_nx(s->nx) * bt * sizeof(double) <= 48 * 1024) ? "true" : "false");
 	// fewer than two waves per SIMD: nothing hides a wave's memory latency but its own loads
-	const bool deep = (long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4;
-#define ACCEPT_LAUNCH(BT, DEEP) hipLaunchKernelGGL((k_gauss_cols_accept<BT, DEEP>), dim3(blocks), dim3(64 * wpb), 0, c->stream, \
+	const size_t tpl_bytes = (size_t) cols_nx(s->nx) * bt * sizeof(double);
+	const bool deep = (long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4 && tpl_bytes <= 48 * 1024;
+#define ACCEPT_LAUNCH(BT, DEEP) hipLaunchKernelGGL((k_gauss_cols_accept<BT, DEEP>), dim3(blocks), dim3(64 * wpb), DEEP ? tpl_bytes : 0, c->stream, \
 	d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags)
 	switch (bt) {
 	case 16: ACCEPT_LAUNCH(16, false); break;
@@ -979,7 +1020,7 @@ bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const d
 	const int ntiles = (M + 63) / 64;
 	int nq_xcd, cu_slots;
 	const int blocks = cols_grid(c, ntiles, 1, nq_xcd, cu_slots);
-	hipLaunchKernelGGL(k_gauss_cols_commit, dim3(blocks), dim3(kBlock), 0, c->stream,
+	hipLaunchKernelGGL(k_gauss_cols_commit, dim3(blocks), dim3(kBlock), (size_t) (cols_nx(s->nx) + 2) * sizeof(double), c->stream,
 	                   d_yT, cols_nx(s->nx), d_model_t, mstride, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, cu_slots,
 	                   d_flags, st, (JointHeader *) d_header, d_fillbits, d_Lrow);
 	return launched("k_gauss_cols_commit");
