@@ -68,9 +68,16 @@ def priortransform(cube):
     return np.column_stack([10 ** (cube[:, 0] * 2 - 2), cube[:, 1] * 400 + 400, 10 ** (cube[:, 2] * 2)])
 
 
+#: the GPU pool gives a one-GPU job a 16-core share of its host, whatever the host has and the
+#: affinity mask says; OpenMP legs use at most that many threads (256 threads on a shared host
+#: measured 30x SLOWER than 16)
+CORE_SHARE = 16
+
+
 def host_cores():
-    """Cores this process may use, and what lscpu says about the host."""
+    """Threads the OpenMP legs use (the job's core share), and what lscpu says about the host."""
     usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    usable = min(usable, CORE_SHARE)
     info = {}
     try:
         out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
@@ -115,7 +122,7 @@ def cpu_baseline_gauss(data, params, budget_s=12.0):
     usable, info = host_cores()
     res = {"value": n * nd / el, "unit": "likelihood evals/s", "cores": 1, "kind": kind,
            "sample": "%d candidates x %d spectra x 200 channels, full mask, serial clike loop, %.1f s" % (n, nd, el),
-           "binary": ref_provenance(), "host": info, "cores_usable": usable}
+           "binary": ref_provenance(), "host": info, "core_share": usable}
     # best-effort multi-threaded form (dataset-parallel OpenMP restatement), for context only
     try:
         os.environ.setdefault("OMP_NUM_THREADS", str(usable))
@@ -200,15 +207,18 @@ def e2e_leg(data, iterations):
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes of this command
-    (profiles/pmc_latest.json: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md HBM section)."""
-    pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-    if not os.path.exists(pmc):
-        return None, None
-    try:
-        doc = json.load(open(pmc))
-        return doc["kernels"]["mdns::" + kernel]["hbm_bytes"], "profiles/pmc_latest.json (committed; tag %s)" % doc.get("tag")
-    except Exception:      # noqa: BLE001
-        return None, None
+    (profiles/r*_pmc.json, newest round first: FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md
+    HBM section; tools/collect_profiles.sh + tools/profile_summary.py make them)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")), reverse=True):
+        try:
+            doc = json.load(open(path))
+            entry = doc["kernels"].get("mdns::" + kernel)
+            if entry is not None:
+                return entry["hbm_bytes"], "profiles/%s (committed rocprofv3 --pmc passes of this command)" % os.path.basename(path)
+        except Exception:      # noqa: BLE001
+            continue
+    return None, None
 
 
 # ------------------------------------------------------------------------------------------
@@ -486,7 +496,7 @@ def cpu_baseline_muse(y_t, v_t, templates, budget_s=15.0):
     return {"value": n * nd / el, "unit": "likelihood evals/s", "cores": int(os.environ.get("OMP_NUM_THREADS", usable)),
             "kind": kind, "sample": "%d templates x %d spectra x %d channels, full mask, cmuselike OpenMP build, %.1f s"
                                     % (n, nd, y_t.shape[0], el),
-            "binary": ref_provenance(), "host": info, "cores_usable": usable}, out.copy(), (n - 1) % len(templates)
+            "binary": ref_provenance(), "host": info, "core_share": usable}, out.copy(), (n - 1) % len(templates)
 
 
 def bench_muse(args):

@@ -1131,6 +1131,8 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 	if (gy < 1) gy = 1;
 	const int bchunk = 2 * (((B + gy - 1) / gy + 1) / 2);         // even: k_muse_rows<NP, 2> walks pairs
 	gy = (B + bchunk - 1) / bchunk;
+	note_kernel(1, two_rows ? "k_muse_rows2<%d>" : (B >= 2 ? "k_muse_rows<%d, 2>" : "k_muse_rows<%d, 1>"),
+	            nx <= 512 ? 1 : nx <= 1024 ? 2 : nx <= 2048 ? 4 : 8);
 #define MUSE_LAUNCH(NP) do { if (two_rows) hipLaunchKernelGGL((k_muse_rows2<NP>), dim3((blocks + 1) / 2), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
 	else if (B >= 2) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks, gy), dim3(kBlock), 0, c->stream, \
