@@ -35,6 +35,8 @@ class CachedConstrainer(object):
         self.last_mask = []
         self.last_points = []
         self.last_realmask = None
+        self.last_key = None
+        self._last_table = None
         self.sampler = sampler
 
     # names kept for readers of the reference
@@ -48,6 +50,8 @@ class CachedConstrainer(object):
             self.last_mask = []
             self.last_realmask = None
             self.last_points = []
+            self.last_key = None
+            self._last_table = None
             self.iter += 1
 
     def _similar_to_last(self, mask, realmask, points):
@@ -58,16 +62,32 @@ class CachedConstrainer(object):
         return (len(mask) < len(self.last_mask) and len(mask) > 0.80 * len(self.last_mask)
                 and len(points) <= len(self.last_points) and len(points) > 0.90 * len(self.last_points)
                 and numpy.mean(self.last_realmask == realmask) > 0.80
-                and numpy.isin(points, self.last_points).all())
+                and self._all_among_last(points))
+
+    def _all_among_last(self, points):
+        """``numpy.isin(points, self.last_points).all()`` through a table of the point ids
+        (they are rows of the pile: small non-negative integers), built once per ``last_points``."""
+        points = numpy.asarray(points)
+        if self._last_table is None:
+            last = numpy.asarray(self.last_points)
+            self._last_table = numpy.zeros(int(last.max()) + 1 if len(last) else 1, dtype=bool)
+            self._last_table[last] = True
+        if len(points) and int(points.max()) >= len(self._last_table):
+            return False
+        return bool(self._last_table[points].all())
 
     def get(self, mask, realmask, points, it):
         self._advance_to(it)
         if self._similar_to_last(mask, realmask, points):
-            return self.generations[0][tuple(self.last_mask.tolist())].draw_constrained
-        key = tuple(mask.tolist())
+            return self.generations[0][self.last_key].draw_constrained
+        # (the reference keys its dictionaries with tuple(mask): the bytes of the index array
+        # identify the same selections at a hundredth of the cost)
+        key = (len(mask), numpy.ascontiguousarray(mask, dtype=numpy.int64).tobytes())
         self.last_realmask = realmask
         self.last_mask = mask
+        self.last_key = key
         self.last_points = points
+        self._last_table = None
         current = self.generations[0]
         if key not in current:
             for older in self.generations[1:]:
