@@ -8,8 +8,8 @@ Workload horns / nothing (BASELINE.json configs[1] / configs[2]; default horns)
 One STEP = one nested-sampling iteration with ONE superset constrained draw, everything
 resident in HBM when the timed region starts and every decision taken on the device:
 
-  0. the live-likelihood matrix [100, 10 000] is put back to its saved state (8 MB device copy:
-     extra work, it makes every step the same iteration)
+  0. the previous step's advance is taken back (the 10 000 replaced live likelihoods rewritten,
+     shelves emptied: extra work, it makes every step the same iteration)
   1. prepare     per data set: lowest live likelihood + slot, shelf purge, threshold
                  (multi_nested_sampler.py:130-143, 438-447)
   2. (N > 1)     RCCL all-gather of the shared live-point pool, K/N points per rank
@@ -24,8 +24,9 @@ resident in HBM when the timed region starts and every decision taken on the dev
                  whichever is accepted): its likelihood row, one fill bit per data set, shelf
                  appends, next thresholds (multi_nested_sampler.py:482-485)
   8. advance     worst live point of every data set replaced by its shelf head (:494-534)
-  9. host        fetches the radius (polled mapped memory) and {accepted index, fill bits,
-                 likelihood row} (one 80 KB copy) -- the round trip a real draw makes
+  9. host        fetches the radius (polled mapped memory) and {accepted index, fill bits}
+                 (one 1.3 KB copy; the likelihood row stays on the device, as in a real run) --
+                 the round trip a real draw makes
 
 `value` = (candidate, spectrum) likelihood evaluations per second over all ranks.  N > 1: weak
 scaling, 10 000 spectra per GPU cut from horns(10 000 N), one process per GPU.
@@ -305,7 +306,7 @@ def bench_gauss(args):
     rng = np.random.RandomState(1)                      # sample.py:162
     live_params = priortransform(rng.uniform(size=(NLIVE, NDIM)))
     _lib.check(lib.mdns_joint_init_gauss(joint, _lib.ptr(live_params), 0.01), "init")
-    d_saved = lib.mdns_dev_alloc(NLIVE * nd * 8)
+    d_saved = lib.mdns_dev_alloc(NLIVE * nd * 8)           # the initial matrix, for the check after the timed region
     _lib.check(lib.mdns_d2d(d_saved, lib.mdns_joint_live_dev(joint), NLIVE * nd * 8), "save live")
     # B - 1 candidates no data set accepts (lines ten times brighter than the prior allows, as
     # broad as it allows), then one that beats the worst live point of every data set (a line at
@@ -329,7 +330,9 @@ def bench_gauss(args):
     d_params, d_chosen, d_cands = dev(params), dev(chosen), dev(cands)
     d_counts = lib.mdns_dev_alloc(NCAND * 4)
     nres = lib.mdns_joint_result_bytes(nd)
+    nhead = 16 + 8 * ((nd + 63) // 64)                     # {accepted, status} + fill bits: what the host needs per draw
     result = np.zeros(nres, dtype=np.uint8)
+    state = {"advanced": False}
     d_flags = lib.mdns_joint_flags_dev(joint)
     d_result = lib.mdns_joint_result_dev(joint)
     if use_dist:
@@ -359,7 +362,8 @@ def bench_gauss(args):
         raise _lib.MdnsError(_lib.last_error())
 
     def step():
-        _lib.check(lib.mdns_joint_restore_live_dev(joint, d_saved), "restore")
+        if state["advanced"]:
+            _lib.check(lib.mdns_joint_undo_advance_dev(joint), "undo advance")
         _lib.check(lib.mdns_joint_prepare_dev(joint), "prepare")
         if use_dist:
             dist.all_gather_into_tensor(t_pool, t_mine)
@@ -374,6 +378,7 @@ def bench_gauss(args):
             _lib.check(lib.mdns_d2d(d_flags, C.c_void_p(t_flags.data_ptr()), 4 * B), "flags in")
         _lib.check(lib.mdns_joint_commit_dev(joint, None, nd), "commit")
         _lib.check(lib.mdns_joint_advance_dev(joint), "advance")
+        state["advanced"] = True
         if use_dist:
             # the host bookkeeping of every rank needs the fill bits of all data sets
             _lib.check(lib.mdns_d2d(C.c_void_p(t_bits.data_ptr()), C.c_void_p(d_result + 16), 8 * nbits), "bits out")
@@ -382,7 +387,7 @@ def bench_gauss(args):
         radius = lib.mdns_region_radius(region)
         if radius != radius:
             raise _lib.MdnsError(_lib.last_error())
-        _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nres), "result")
+        _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nhead), "result")
 
     def fence():
         _lib.check(lib.mdns_sync(), "sync")
@@ -408,6 +413,13 @@ def bench_gauss(args):
     fence()
 
     # sanity: the timed steps decided what they were built to decide, with the right numbers
+    _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nres), "result")       # now with the likelihood row
+    live_now = np.empty((NLIVE, nd))
+    _lib.check(lib.mdns_joint_undo_advance_dev(joint), "undo advance")
+    _lib.check(lib.mdns_joint_get_live(joint, _lib.ptr(live_now)), "get live")
+    live_first = np.empty((NLIVE, nd))
+    _lib.check(lib.mdns_d2h(_lib.ptr(live_first), d_saved, live_first.nbytes), "d2h")
+    assert np.array_equal(live_now, live_first), "taking back the advance did not restore the live matrix"
     accepted = int(result[:4].view(np.int32)[0])
     status = int(result[4:8].view(np.int32)[0])
     nbw = (nd + 63) // 64

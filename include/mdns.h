@@ -221,7 +221,7 @@ int mdns_joint_shelf_cap(const mdns_joint *j);
  * uint64[ceil(M/64)] with bit k set when it beats the threshold of the k-th selected data set
  * (multi_nested_sampler.py:482-485); those data sets' shelves receive it and their thresholds
  * move up, all on the device.  Likelihoods of the other candidates never reach memory.
- * B <= 1024.
+ * Lrow may be NULL (the row then stays on the device).  B <= 1024.
  */
 int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B, double noise_level,
                           const int *row_ids, int M, int *accepted, double *Lrow,
@@ -306,6 +306,9 @@ size_t mdns_joint_result_bytes(int M);
 int mdns_joint_prepare_dev(mdns_joint *j);
 int mdns_joint_advance_dev(mdns_joint *j);
 int mdns_joint_restore_live_dev(mdns_joint *j, const double *d_liveL);
+/* Takes back the last mdns_joint_advance[_dev]: every running data set's replaced live slot gets
+ * the likelihood back that the preceding prepare found there; shelves emptied (bench.py). */
+int mdns_joint_undo_advance_dev(mdns_joint *j);
 const double *mdns_joint_live_dev(mdns_joint *j);
 
 /* K3 on device: d_members f64[K,ndim], d_cands f64[M,ndim]; d_counts int32[M] is

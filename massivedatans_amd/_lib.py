@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "mdns_joint_advance", "mdns_joint_reserve", "mdns_joint_shelf_cap", "mdns_joint_draw_gauss", "mdns_joint_score", "mdns_joint_commit",
     "mdns_joint_get_thresholds", "mdns_joint_score_dev", "mdns_joint_flags_dev", "mdns_joint_commit_dev",
     "mdns_joint_result_dev", "mdns_joint_result_bytes", "mdns_joint_prepare_dev", "mdns_joint_advance_dev",
-    "mdns_joint_restore_live_dev", "mdns_joint_live_dev",
+    "mdns_joint_restore_live_dev", "mdns_joint_undo_advance_dev", "mdns_joint_live_dev",
 )
 
 #: mdns.h MDNS_JOINT_MAX_BATCH
@@ -128,6 +128,7 @@ def _declare(lib):
         "mdns_joint_prepare_dev": (i, [vp]),
         "mdns_joint_advance_dev": (i, [vp]),
         "mdns_joint_restore_live_dev": (i, [vp, vp]),
+        "mdns_joint_undo_advance_dev": (i, [vp]),
         "mdns_joint_live_dev": (vp, [vp]),
     }
     for name, (res, args) in sig.items():

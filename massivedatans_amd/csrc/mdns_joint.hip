@@ -36,26 +36,42 @@ __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const 
                                                           int *__restrict__ argmin, unsigned long long *__restrict__ keep,
                                                           int keep_words)
 {
-	const int r = blockIdx.x * kBlock + threadIdx.x;
-	if (r >= nrun) return;
-	const int d = running[r];
+	// a workgroup = 64 data sets x 4 slices of the live slots: thread (slice g, data set) looks at
+	// slots g, g + 4, ... (a quarter of the serial loads), the four partial minima meet in LDS --
+	// ties go to the lower slot, which is numpy.argmin's first occurrence -- and slice 0 goes on
+	__shared__ double part_m[4][64];
+	__shared__ int part_i[4][64];
+	const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+	const int r = blockIdx.x * 64 + lane;
+	const int d = running[r < nrun ? r : nrun - 1];
 	const size_t nd = (size_t) st.ndata;
-	double m = st.live[d];
-	int am = 0;
+	double m = INFINITY;
+	int am = 0x7fffffff;
 	{
-		int p = 1;
-		for (; p + 8 <= st.nlive; p += 8) {                      // eight loads in flight
+		int p = g;
+		for (; p + 28 < st.nlive; p += 32) {                     // eight loads in flight
 			double v[8];
 #pragma unroll
-			for (int u = 0; u < 8; u++) v[u] = st.live[(p + u) * nd + d];
+			for (int u = 0; u < 8; u++) v[u] = st.live[(p + 4 * u) * nd + d];
 #pragma unroll
-			for (int u = 0; u < 8; u++) if (v[u] < m) { m = v[u]; am = p + u; }
+			for (int u = 0; u < 8; u++) if (v[u] < m) { m = v[u]; am = p + 4 * u; }
 		}
-		for (; p < st.nlive; p++) {
+		for (; p < st.nlive; p += 4) {
 			const double v = st.live[p * nd + d];
 			if (v < m) { m = v; am = p; }
 		}
 	}
+	part_m[g][lane] = m;
+	part_i[g][lane] = am;
+	__syncthreads();
+	if (g != 0 || r >= nrun) return;
+#pragma unroll
+	for (int o = 1; o < 4; o++) {
+		const double v = part_m[o][lane];
+		const int i = part_i[o][lane];
+		if (v < m || (v == m && i < am)) { m = v; am = i; }
+	}
+	if (am == 0x7fffffff) am = 0;                                // a column of NaNs: numpy.argmin's answer is moot
 	// purge (multi_nested_sampler.py:137-138: keep entries with L > Lmin, order kept)
 	const int n = st.shelfn[d];
 	int w = 0;
@@ -117,6 +133,19 @@ __global__ __launch_bounds__(kBlock) void k_joint_advance(JointArrays st, const 
 	st.live[argmin[d] * nd + d] = st.shelfL[d];
 	for (int e = 1; e < n; e++) st.shelfL[(e - 1) * nd + d] = st.shelfL[e * nd + d];
 	st.shelfn[d] = n - 1;
+}
+
+// Takes back the last advance: the slot every running data set gave to its shelf head gets the
+// likelihood back that prepare found there, and the shelves are emptied.  (bench.py re-runs the
+// same iteration; 10 000 rewritten entries instead of an 8 MB copy.)
+__global__ __launch_bounds__(kBlock) void k_joint_undo_advance(JointArrays st, const int *__restrict__ running, int nrun,
+                                                               const int *__restrict__ argmin, const double *__restrict__ Lmin)
+{
+	const int r = blockIdx.x * kBlock + threadIdx.x;
+	if (r >= nrun) return;
+	const int d = running[r];
+	st.live[(size_t) argmin[d] * st.ndata + d] = Lmin[r];
+	st.shelfn[d] = 0;
 }
 
 __global__ void k_joint_fill(double *__restrict__ p, size_t n, double value)
@@ -284,6 +313,17 @@ extern "C" int mdns_joint_restore_live_dev(mdns_joint *j, const double *d_liveL)
 	return joint_reset(j);
 }
 
+extern "C" int mdns_joint_undo_advance_dev(mdns_joint *j)
+{
+	Context *c = ctx();
+	if (!c || !j) return 1;
+	if (!j->prepared) { set_error("mdns_joint_undo_advance_dev: nothing to take back"); return 1; }
+	if (j->nrun == 0) return 0;
+	hipLaunchKernelGGL(k_joint_undo_advance, dim3((j->nrun + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+	                   j->st, j->d_running, j->nrun, j->d_argmin, j->d_Lmin);
+	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
+}
+
 extern "C" const double *mdns_joint_live_dev(mdns_joint *j) { return j ? j->st.live : nullptr; }
 
 extern "C" int mdns_joint_set_live(mdns_joint *j, const double *liveL)
@@ -342,7 +382,7 @@ extern "C" int mdns_joint_prepare_dev(mdns_joint *j)
 	}
 	j->prepared = true;
 	if (j->nrun == 0) return 0;
-	hipLaunchKernelGGL(k_joint_prepare, dim3((j->nrun + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+	hipLaunchKernelGGL(k_joint_prepare, dim3((j->nrun + 63) / 64), dim3(kBlock), 0, c->stream,
 	                   j->st, j->d_running, j->nrun, j->d_Lmin, j->d_argmin_run, j->d_argmin, j->d_keep, kw);
 	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
 }
@@ -493,10 +533,10 @@ static int joint_commit_and_fetch(mdns_joint *j, int *accepted, double *Lrow, un
 	if (!c || !j) return 1;
 	const int M = j->staged_M;
 	if (mdns_joint_commit_dev(j, j->staged_rows ? j->d_rows : nullptr, M) != 0) return 1;
-	const size_t out_bytes = result_bytes(M);
-	char *out = j->h_pin + j->staged_in_bytes;
 	// the header says whether the rest matters, but one copy of at most 80 KB costs less than a
-	// second round trip
+	// second round trip; a caller that does not ask for the likelihood row gets header + bits
+	const size_t out_bytes = Lrow ? result_bytes(M) : sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8;
+	char *out = j->h_pin + j->staged_in_bytes;
 	if (!MDNS_HIP(hipMemcpyAsync(out, j->d_result, out_bytes, hipMemcpyDeviceToHost, c->stream)) || !joint_sync(c)) return 1;
 	const JointHeader *h = (const JointHeader *) out;
 	if (h->status) { set_error("%s: a shelf overflowed its capacity %d (mdns_joint_reserve)", who, j->cap); return 1; }

@@ -158,7 +158,10 @@ class GaussJointState(object):
     EVAL_BUDGET = 2560000
     MIN_CHUNK = 32
 
-    def __init__(self, spectra, nlive, to_kernel_params, shelf_cap=64):
+    def __init__(self, spectra, nlive, to_kernel_params, shelf_cap=64, fetch_rows=True):
+        #: copy the accepted candidate's likelihood row to the host with every draw (the sampler
+        #: itself needs only the index and the fill bits: sample.py turns this off)
+        self.fetch_rows = fetch_rows
         self._lib = _lib.require_device()
         self.spectra = spectra                             # keeps the spectra handle alive
         self.nlive, self.ndata = int(nlive), int(spectra.ndata)
@@ -250,7 +253,8 @@ class GaussJointState(object):
             self.cap = self._lib.mdns_joint_shelf_cap(self._h)
         self._check(self._lib.mdns_joint_draw_gauss(
             self._h, _lib.ptr(params), B, self.noise_level, _lib.ptr(rows) if rows is not None else None, M,
-            C.byref(self._accepted), _lib.ptr(self._Lrow), _lib.ptr(self._bits)), "mdns_joint_draw_gauss")
+            C.byref(self._accepted), _lib.ptr(self._Lrow) if self.fetch_rows else None, _lib.ptr(self._bits)),
+            "mdns_joint_draw_gauss")
         self.ncalls += 1
         idx = self._accepted.value
         if idx < 0:
@@ -262,7 +266,7 @@ class GaussJointState(object):
             self.shelf_n[beats] += 1
         else:
             self.shelf_n[rows[beats]] += 1
-        return idx, self._Lrow[:M].copy(), beats, B
+        return idx, (self._Lrow[:M].copy() if self.fetch_rows else None), beats, B
 
     # the two halves of draw() (include/mdns.h: mdns_joint_score / mdns_joint_commit)
     def _reserve_for(self, rows):
@@ -306,11 +310,12 @@ class GaussJointState(object):
         """The first flagged candidate (``idx`` is only checked against it) is the accepted point."""
         rows = self._scored_rows
         M = self.ndata if rows is None else len(rows)
-        self._check(self._lib.mdns_joint_commit(self._h, C.byref(self._accepted), _lib.ptr(self._Lrow), _lib.ptr(self._bits)),
+        self._check(self._lib.mdns_joint_commit(self._h, C.byref(self._accepted),
+                                                _lib.ptr(self._Lrow) if self.fetch_rows else None, _lib.ptr(self._bits)),
                     "mdns_joint_commit")
         got = self._accepted.value
         if M == 0:
-            return numpy.zeros(0), numpy.zeros(0, dtype=bool)
+            return (numpy.zeros(0) if self.fetch_rows else None), numpy.zeros(0, dtype=bool)
         if got < 0 or (idx is not None and got != idx):
             raise _lib.MdnsError("mdns_joint_commit accepted candidate %d, expected %s" % (got, idx))
         beats = numpy.unpackbits(self._bits[:(M + 63) // 64].view(numpy.uint8), bitorder='little')[:M].astype(bool)
@@ -318,7 +323,7 @@ class GaussJointState(object):
             self.shelf_n[beats] += 1
         else:
             self.shelf_n[rows[beats]] += 1
-        return self._Lrow[:M].copy(), beats
+        return (self._Lrow[:M].copy() if self.fetch_rows else None), beats
 
     def advance(self):
         self._check(self._lib.mdns_joint_advance(self._h), "mdns_joint_advance")

@@ -649,7 +649,9 @@ class MultiNestedSampler(object):
                 self.pointpilex = self._pile_x[:ppi + 1]
                 if self.joint is not None:
                     beats = last['beats']             # decided where the thresholds are
-                    self._shelves.append(joint_indices[beats], ppi, Lj[beats])
+                    # (the likelihoods of the waiting points stay with the joint state; the host
+                    # queues carry them only when the state hands the row over)
+                    self._shelves.append(joint_indices[beats], ppi, Lj[beats] if Lj is not None else numpy.nan)
                 else:
                     beats = Lj > Lmins_higher
                     self._shelves.append(joint_indices[beats], ppi, Lj[beats])

@@ -249,16 +249,18 @@ class ShardedJointState(object):
             return -1, None, None, B
         idx = int(hit[0])
         Lrow, beats = self.local.commit(idx)
-        # the accepted candidate's block of every rank: likelihoods, then fill bits
+        # the accepted candidate's block of every rank: likelihoods (when the local state hands
+        # them over), then fill bits
         width = int(counts.max())
         block = np.zeros(2 * width)
-        block[:len(Lrow)] = Lrow
+        if Lrow is not None:
+            block[:len(Lrow)] = Lrow
         block[width:width + len(beats)] = beats
         mine_t = torch.from_numpy(block).to(_device())
         gathered = torch.empty(self.world * 2 * width, dtype=mine_t.dtype, device=_device())
         dist.all_gather_into_tensor(gathered, mine_t)
         g = gathered.cpu().numpy().reshape(self.world, 2, width)
-        L = np.concatenate([g[r, 0, :counts[r]] for r in range(self.world)])
+        L = np.concatenate([g[r, 0, :counts[r]] for r in range(self.world)]) if Lrow is not None else None
         b = np.concatenate([g[r, 1, :counts[r]] for r in range(self.world)]) != 0
         return idx, L, b, B
 

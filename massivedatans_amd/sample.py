@@ -111,7 +111,7 @@ class GaussLineProblem(object):
 
         def build(scorer, ndata):
             if isinstance(scorer, GaussLineSpectra):
-                return jointstate.GaussJointState(scorer, nlive_points, kernel_params)
+                return jointstate.GaussJointState(scorer, nlive_points, kernel_params, fetch_rows=False)
             return jointstate.HostJointState(scorer, nlive_points, ndata, kernel_params)
 
         if isinstance(self.backend, parallel.ShardedGaussLine):
