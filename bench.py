@@ -350,10 +350,13 @@ def bench_gauss(args):
             ch = np.zeros((Kdev, NBOOT))
             ch[:K] = chosen
             d_chosen = dev(ch)
-        t_flags = torch.zeros(_lib.JOINT_MAX_BATCH, dtype=torch.int32, device="cuda")
+        # the joint state's own buffers, reduced / gathered in place (no staging copies)
+        from massivedatans_amd.parallel import device_view
         nbits = (nd + 63) // 64
-        t_bits = torch.zeros(nbits, dtype=torch.int64, device="cuda")
+        t_flags = device_view(d_flags, (B,), "<i4")
+        t_bits = device_view(d_result + 16, (nbits,), "<i8")
         t_allbits = torch.zeros(world * nbits, dtype=torch.int64, device="cuda")
+        allbits = np.zeros(world * nbits, dtype=np.int64)
     else:
         d_pool = dev(pool)
         Kdev = K
@@ -364,30 +367,35 @@ def bench_gauss(args):
     def step():
         if state["advanced"]:
             _lib.check(lib.mdns_joint_undo_advance_dev(joint), "undo advance")
+        if use_dist:
+            # the pool exchange runs on RCCL's stream beside the state kernels; K6 waits for it
+            gathered = dist.all_gather_into_tensor(t_pool, t_mine, async_op=True)
         _lib.check(lib.mdns_joint_prepare_dev(joint), "prepare")
         if use_dist:
-            dist.all_gather_into_tensor(t_pool, t_mine)
+            gathered.wait()
         # K6, then radius + membership threshold finished on the device: K3 follows in stream order
         _lib.check(lib.mdns_region_bootstrap_radius_async(region, d_chosen, NBOOT), "K6")
         _lib.check(lib.mdns_region_count_dev(region, d_cands, NCAND, d_counts), "K3")
         _lib.check(lib.mdns_joint_score_dev(joint, d_params, B, 0.01, None, nd), "K1 + accept")
         if use_dist:
             # every rank learns which candidates ANY rank's data sets accept: B flags, not L[B, M]
-            _lib.check(lib.mdns_d2d(C.c_void_p(t_flags.data_ptr()), d_flags, 4 * B), "flags out")
             dist.all_reduce(t_flags, op=dist.ReduceOp.MAX)
-            _lib.check(lib.mdns_d2d(d_flags, C.c_void_p(t_flags.data_ptr()), 4 * B), "flags in")
         _lib.check(lib.mdns_joint_commit_dev(joint, None, nd), "commit")
         _lib.check(lib.mdns_joint_advance_dev(joint), "advance")
         state["advanced"] = True
         if use_dist:
             # the host bookkeeping of every rank needs the fill bits of all data sets
-            _lib.check(lib.mdns_d2d(C.c_void_p(t_bits.data_ptr()), C.c_void_p(d_result + 16), 8 * nbits), "bits out")
-            dist.all_gather_into_tensor(t_allbits, t_bits)
+            gathered = dist.all_gather_into_tensor(t_allbits, t_bits, async_op=True)
         # the host needs the radius (bounding box of the next proposals) and the outcome of the draw
         radius = lib.mdns_region_radius(region)
         if radius != radius:
             raise _lib.MdnsError(_lib.last_error())
-        _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nhead), "result")
+        if use_dist:
+            gathered.wait()
+            _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, 16), "result")
+            _lib.check(lib.mdns_d2h(_lib.ptr(allbits), C.c_void_p(t_allbits.data_ptr()), allbits.nbytes), "fill bits of all ranks")
+        else:
+            _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nhead), "result")
 
     def fence():
         _lib.check(lib.mdns_sync(), "sync")
@@ -429,6 +437,9 @@ def bench_gauss(args):
     want = -0.5 * (((ypred.reshape((-1, 1)) - shard[:, :64]) / 0.01) ** 2).sum(axis=0)
     assert accepted == B - 1 and status == 0, ("bench draw: accepted %d status %d" % (accepted, status))
     assert bits.all(), "bench draw: the accepted candidate must fill every shelf"
+    if use_dist:
+        every = np.unpackbits(allbits.view(np.uint8).reshape(world, -1), axis=1, bitorder="little")[:, :nd]
+        assert every.all(), "bench draw: the gathered fill bits of some rank are incomplete"
     assert np.allclose(Lrow[:64], want, rtol=1e-10), "bench output check failed"
 
     if rank == 0:

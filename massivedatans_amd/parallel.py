@@ -144,6 +144,22 @@ class ShardedGaussLine(object):
         return allgather_columns(block, counts)
 
 
+class _DeviceMemory(object):
+    """Device memory owned by libmdns_hip, described through the CUDA array interface so that
+    torch can wrap it without a copy (torch.as_tensor)."""
+
+    def __init__(self, address, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(address), False),
+                                         "version": 2, "strides": None}
+
+
+def device_view(address, shape, typestr):
+    """A torch tensor over library-owned device memory (no copy): what a collective reduces or
+    gathers in place.  The library keeps ownership; the view must not outlive the allocation."""
+    torch, _ = _dist()
+    return torch.as_tensor(_DeviceMemory(address, shape, typestr), device=_device())
+
+
 class ShardedJointState(object):
     """The joint sampler state (``jointstate``) with the data sets sharded over the ranks: rank r
     keeps live likelihoods, shelves and thresholds of ITS block next to its block of spectra.
@@ -156,8 +172,8 @@ class ShardedJointState(object):
 
     Per iteration: the per-data-set minima / slots / purge decisions of ``prepare`` (an object
     gather; once per iteration).  With the ``nccl`` backend the flags are reduced on the device
-    (the state's flag buffer is copied into a CUDA tensor on the library stream, RCCL reduces it
-    there); with ``gloo`` through the host.  Same interface as the single-process states."""
+    (RCCL reduces the state's own flag buffer in place, on the library stream, which is torch's
+    current stream); with ``gloo`` through the host.  Same interface as the single-process states."""
 
     def __init__(self, local, ndata, lo, hi):
         torch, dist = _dist()
@@ -169,7 +185,8 @@ class ShardedJointState(object):
         self._device_flags = dist.get_backend() == "nccl" and hasattr(local, "flags_address")
         if self._device_flags:
             from . import _lib
-            self._flags_t = torch.zeros(_lib.JOINT_MAX_BATCH, dtype=torch.int32, device=_device())
+            # the state's own flag buffer, reduced in place
+            self._flags_t = device_view(local.flags_address(), (_lib.JOINT_MAX_BATCH,), "<i4")
         self.nevals_scored = 0
         self.ncalls = 0
 
@@ -221,11 +238,7 @@ class ShardedJointState(object):
     def _reduce_flags(self, B):
         torch, dist = _dist()
         if self._device_flags:
-            from . import _lib
-            lib = _lib.load()
-            _lib.check(lib.mdns_d2d(self._flags_t.data_ptr(), self.local.flags_address(), 4 * B), "mdns_d2d")
-            dist.all_reduce(self._flags_t, op=dist.ReduceOp.MAX)
-            _lib.check(lib.mdns_d2d(self.local.flags_address(), self._flags_t.data_ptr(), 4 * B), "mdns_d2d")
+            dist.all_reduce(self._flags_t[:B], op=dist.ReduceOp.MAX)
             return self._flags_t[:B].cpu().numpy()
         flags = torch.from_numpy(np.ascontiguousarray(self._local_flags, dtype=np.int32)).to(_device())
         dist.all_reduce(flags, op=dist.ReduceOp.MAX)

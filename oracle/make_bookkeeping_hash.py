@@ -8,7 +8,10 @@ pinned bit for bit against the reference on the small traces (tests/test_orchest
 fixture extends the comparison of the GPU path with it to the full size, where the reference
 itself takes hours.  Test infrastructure: writes tests/golden/bookkeeping_c2.json.
 
-    python oracle/make_bookkeeping_hash.py [--all]
+    python oracle/make_bookkeeping_hash.py [--all] [--case kind:ndata:nlive:iterations ...]
+
+--case adds (or redoes) single entries, e.g. horns:100000:100:300 -- BASELINE.json configs[3]'s
+data set, 100 000 spectra, on one host (a quarter of an hour on 8 cores).
 """
 import hashlib
 import json
@@ -41,6 +44,11 @@ def main():
     if os.path.exists(path) and "--all" not in sys.argv:
         out = json.load(open(path))                  # keep what is there, redo the quick cases
         cases = cases[:2]
+    if "--case" in sys.argv:
+        cases = []
+        for a in sys.argv[sys.argv.index("--case") + 1:]:
+            kind, ndata, nlive, cap = a.split(":")
+            cases.append((kind, int(ndata), int(nlive), int(cap)))
     for kind, ndata, nlive, cap in cases:
         data = (gen.horns if kind == "horns" else gen.nothing)(ndata)
         backend = oracle_backend.OracleSpectra(o, data["x"], data["y"])

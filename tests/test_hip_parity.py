@@ -649,20 +649,23 @@ def test_packed_bootstrap_choice_gives_the_same_radius(nb, oracle):
         s.close()
 
 
-@pytest.mark.parametrize("kind,cap", [("horns", 400), ("nothing", 400), ("horns", 700)])
-def test_c2_size_bookkeeping_matches_the_cpu_path(kind, cap):
+@pytest.mark.parametrize("kind,ndata,cap", [("horns", 10000, 400), ("nothing", 10000, 400), ("horns", 10000, 700),
+                                            ("horns", 100000, 300)])
+def test_full_size_bookkeeping_matches_the_cpu_path(kind, ndata, cap):
     """BASELINE.json configs[1]/[2] at full size (10 000 spectra, 100 live points), first 400
-    iterations (and 700 for horns: 265 425 draws, 40 minutes on the CPU path), on the GPU, against the same run of the host orchestration on the CPU oracle
+    iterations (and 700 for horns: 265 425 draws, 40 minutes on the CPU path), and configs[3]'s
+    data set whole (gensimple_horns, 100 000 spectra, 300 iterations) on the one GPU, against the
+    same run of the host orchestration on the CPU oracle
     backends (tests/golden/bookkeeping_c2.json from oracle/make_bookkeeping_hash.py; that pair is
     pinned bit for bit against the reference on the small traces): same number of draws, the
     pile of accepted points byte for byte -- i.e. every accept decision and every RNG draw
-    coincided over 12 117 (5 261) constrained draws -- and evidences within 1e-9."""
+    coincided over 12 117 (5 261, 265 425, 2 992) constrained draws -- and evidences within 1e-9."""
     import hashlib
     import json
     from massivedatans_amd import sample
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    want = json.load(open(os.path.join(root, "tests", "golden", "bookkeeping_c2.json")))["%s_10000_100_%d" % (kind, cap)]
-    data = (gen.horns if kind == "horns" else gen.nothing)(10000)
+    want = json.load(open(os.path.join(root, "tests", "golden", "bookkeeping_c2.json")))["%s_%d_100_%d" % (kind, ndata, cap)]
+    data = (gen.horns if kind == "horns" else gen.nothing)(ndata)
     with np.errstate(all="ignore"):
         results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=cap, use_graph=False)
     assert sampler.ndraws == want["ndraws"]
