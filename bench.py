@@ -223,6 +223,9 @@ def pmc_traffic(kernel):
 
 
 # ------------------------------------------------------------------------------------------
+COMM = {"direct": None, "rccl": None, "stream": None}      # set by setup_dist in a distributed run
+
+
 def setup_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -255,6 +258,16 @@ def setup_dist(args):
         torch.cuda.set_stream(bench_stream)
         assert bench_stream.cuda_stream != 0
         _lib.check(lib.mdns_set_stream(C.c_void_p(bench_stream.cuda_stream)), "mdns_set_stream")
+        # The exchanges of a step are tiny (B flags, one bit per data set, the pool): RCCL is
+        # called directly on that stream (massivedatans_amd/rccl.py), one enqueue per collective;
+        # MDNS_BENCH_COLLECTIVES=torch goes through torch.distributed instead.
+        COMM["stream"] = bench_stream.cuda_stream
+        if os.environ.get("MDNS_BENCH_COLLECTIVES", "rccl") != "torch":
+            from massivedatans_amd import rccl
+            try:
+                COMM["rccl"], COMM["direct"] = rccl, rccl.from_torch_distributed()
+            except (rccl.RcclError, OSError, AttributeError) as e:
+                print("bench.py: direct RCCL unavailable (%s), using torch.distributed" % e, file=sys.stderr)
     return world, rank, use_dist, torch, dist, lib, _lib
 
 
@@ -360,6 +373,7 @@ def bench_gauss(args):
     else:
         d_pool = dev(pool)
         Kdev = K
+    direct, rccl, stream = COMM["direct"], COMM["rccl"], COMM["stream"]
     region = lib.mdns_region_wrap_dev(d_pool, Kdev, NDIM)     # the pool buffer is refilled in place
     if not region:
         raise _lib.MdnsError(_lib.last_error())
@@ -367,31 +381,38 @@ def bench_gauss(args):
     def step():
         if state["advanced"]:
             _lib.check(lib.mdns_joint_undo_advance_dev(joint), "undo advance")
-        if use_dist:
+        if direct is not None:
+            direct.all_gather(t_mine.data_ptr(), t_pool.data_ptr(), share * NDIM, rccl.FLOAT64, stream)
+        elif use_dist:
             # the pool exchange runs on RCCL's stream beside the state kernels; K6 waits for it
             gathered = dist.all_gather_into_tensor(t_pool, t_mine, async_op=True)
         _lib.check(lib.mdns_joint_prepare_dev(joint), "prepare")
-        if use_dist:
+        if use_dist and direct is None:
             gathered.wait()
         # K6, then radius + membership threshold finished on the device: K3 follows in stream order
         _lib.check(lib.mdns_region_bootstrap_radius_async(region, d_chosen, NBOOT), "K6")
         _lib.check(lib.mdns_region_count_dev(region, d_cands, NCAND, d_counts), "K3")
         _lib.check(lib.mdns_joint_score_dev(joint, d_params, B, 0.01, None, nd), "K1 + accept")
-        if use_dist:
-            # every rank learns which candidates ANY rank's data sets accept: B flags, not L[B, M]
+        # every rank learns which candidates ANY rank's data sets accept: B flags, not L[B, M]
+        if direct is not None:
+            direct.all_reduce(d_flags, d_flags, B, rccl.INT32, rccl.MAX, stream)
+        elif use_dist:
             dist.all_reduce(t_flags, op=dist.ReduceOp.MAX)
         _lib.check(lib.mdns_joint_commit_dev(joint, None, nd), "commit")
         _lib.check(lib.mdns_joint_advance_dev(joint), "advance")
         state["advanced"] = True
-        if use_dist:
-            # the host bookkeeping of every rank needs the fill bits of all data sets
+        # the host bookkeeping of every rank needs the fill bits of all data sets
+        if direct is not None:
+            direct.all_gather(d_result + 16, t_allbits.data_ptr(), nbits, rccl.INT64, stream)
+        elif use_dist:
             gathered = dist.all_gather_into_tensor(t_allbits, t_bits, async_op=True)
         # the host needs the radius (bounding box of the next proposals) and the outcome of the draw
         radius = lib.mdns_region_radius(region)
         if radius != radius:
             raise _lib.MdnsError(_lib.last_error())
         if use_dist:
-            gathered.wait()
+            if direct is None:
+                gathered.wait()
             _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, 16), "result")
             _lib.check(lib.mdns_d2h(_lib.ptr(allbits), C.c_void_p(t_allbits.data_ptr()), allbits.nbytes), "fill bits of all ranks")
         else:
@@ -462,7 +483,11 @@ def bench_gauss(args):
                                    "all on the device (BASELINE.json configs[%d])"
                                    % (args.workload, nd, nx, NLIVE, K, NCAND, B, 1 if args.workload == "horns" else 2),
                        "spectra_per_gpu": nd, "channels": nx, "candidates_per_step": B, "pool_points": K,
-                       "parallelism": "datasets sharded x%d" % world},
+                       "parallelism": "datasets sharded x%d" % world,
+                       "collectives": (None if not use_dist else
+                                       "per step: pool all-gather, MAX all-reduce of the accept flags, fill-bit all-gather; "
+                                       + ("RCCL called directly on the kernels' stream" if direct is not None
+                                          else "torch.distributed (nccl)"))},
             "roofline": {"bound": "fp64_valu", "kernel": kernel, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source,
@@ -493,6 +518,8 @@ def bench_gauss(args):
     lib.mdns_joint_destroy(joint)
     lib.mdns_spectra_destroy(spectra)
     if use_dist:
+        if direct is not None:
+            direct.destroy()
         dist.destroy_process_group()
 
 
@@ -602,6 +629,8 @@ def bench_muse(args):
         print(json.dumps(res))
     lib.mdns_spectra_destroy(spectra)
     if use_dist:
+        if COMM["direct"] is not None:
+            COMM["direct"].destroy()
         dist.destroy_process_group()
 
 

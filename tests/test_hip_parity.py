@@ -650,16 +650,16 @@ def test_packed_bootstrap_choice_gives_the_same_radius(nb, oracle):
 
 
 @pytest.mark.parametrize("kind,ndata,cap", [("horns", 10000, 400), ("nothing", 10000, 400), ("horns", 10000, 700),
-                                            ("horns", 100000, 300)])
+                                            ("horns", 100000, 300), ("horns", 100000, 450)])
 def test_full_size_bookkeeping_matches_the_cpu_path(kind, ndata, cap):
     """BASELINE.json configs[1]/[2] at full size (10 000 spectra, 100 live points), first 400
     iterations (and 700 for horns: 265 425 draws, 40 minutes on the CPU path), and configs[3]'s
-    data set whole (gensimple_horns, 100 000 spectra, 300 iterations) on the one GPU, against the
+    data set whole (gensimple_horns, 100 000 spectra, 300 and 450 iterations) on the one GPU, against the
     same run of the host orchestration on the CPU oracle
     backends (tests/golden/bookkeeping_c2.json from oracle/make_bookkeeping_hash.py; that pair is
     pinned bit for bit against the reference on the small traces): same number of draws, the
     pile of accepted points byte for byte -- i.e. every accept decision and every RNG draw
-    coincided over 12 117 (5 261, 265 425, 2 992) constrained draws -- and evidences within 1e-9."""
+    coincided over 12 117 (5 261, 265 425, 2 992, 31 982) likelihood calls -- and evidences within 1e-9."""
     import hashlib
     import json
     from massivedatans_amd import sample

@@ -166,3 +166,65 @@ def test_two_ranks_share_the_gpu_with_hip_kernels(tmp_path):
     assert sampler.ndraws == res[0]["fused"]["ndraws"] and len(sampler.pointpile) == res[0]["fused"]["npoints"]
     assert np.ascontiguousarray(sampler.pointpile).tobytes().hex()[:64] == res[0]["fused"]["pile"]
     assert np.allclose(results["logZ"][:5], res[0]["fused"]["logZ"], rtol=0, atol=1e-9)
+
+
+def test_rccl_binding_matches_the_header():
+    """massivedatans_amd/rccl.py against rccl.h: the id is 128 bytes passed by value, the enum
+    values are the header's, and the entry points the sharded path calls exist."""
+    import ctypes
+    import re
+    from massivedatans_amd import rccl
+    assert ctypes.sizeof(rccl._UniqueId) == rccl.UNIQUE_ID_BYTES == 128
+    L = rccl.lib()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclAllGather", "ncclAllReduce", "ncclGetErrorString"):
+        assert hasattr(L, name)
+    header = "/opt/rocm/include/rccl/rccl.h"
+    if os.path.exists(header):
+        text = open(header).read()
+        for name, value in (("ncclInt32", rccl.INT32), ("ncclInt64", rccl.INT64), ("ncclUint64", rccl.UINT64),
+                            ("ncclFloat64", rccl.FLOAT64), ("ncclMax", rccl.MAX), ("ncclSum", rccl.SUM), ("ncclMin", rccl.MIN)):
+            m = re.search(r"\b%s\s*=\s*(\d+)" % name, text)
+            assert m and int(m.group(1)) == value, name
+        assert re.search(r"#define\s+NCCL_UNIQUE_ID_BYTES\s+128", text)
+
+
+_RCCL_SCRIPT = r'''
+import sys, ctypes as C
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import torch                                  # first: one HIP runtime per process
+torch.cuda.set_device(0)
+from massivedatans_amd import _lib, rccl
+lib = _lib.require_device()
+stream = torch.cuda.Stream()
+torch.cuda.set_stream(stream)
+_lib.check(lib.mdns_set_stream(C.c_void_p(stream.cuda_stream)), "stream")
+comm = rccl.Communicator(1, 0, lambda payload: payload)
+n = 1000
+a = np.arange(n, dtype=np.int32) % 7
+bits = np.arange(n, dtype=np.int64) * 3
+d_a, d_b, d_c = lib.mdns_dev_alloc(4 * n), lib.mdns_dev_alloc(8 * n), lib.mdns_dev_alloc(8 * n)
+_lib.check(lib.mdns_h2d(d_a, _lib.ptr(a), a.nbytes), "h2d")
+_lib.check(lib.mdns_h2d(d_b, _lib.ptr(bits), bits.nbytes), "h2d")
+comm.all_reduce(d_a, d_a, n, rccl.INT32, rccl.MAX, stream.cuda_stream)
+comm.all_gather(d_b, d_c, n, rccl.INT64, stream.cuda_stream)
+a2, c = np.empty_like(a), np.empty_like(bits)
+_lib.check(lib.mdns_d2h(_lib.ptr(a2), d_a, a.nbytes), "d2h")
+_lib.check(lib.mdns_d2h(_lib.ptr(c), d_c, c.nbytes), "d2h")
+assert np.array_equal(a2, a) and np.array_equal(c, bits)
+comm.destroy()
+print("RCCL OK")
+'''
+
+
+@pytest.mark.gpu
+def test_direct_rccl_on_the_library_stream(tmp_path):
+    """massivedatans_amd/rccl.py on hardware, as far as one GPU allows: a one-rank communicator,
+    MAX all-reduce in place and an all-gather on library-owned device memory, on the stream the
+    kernels use.  (bench.py --gpus N uses the same calls; N > 1 needs N devices.)"""
+    import subprocess
+    script = tmp_path / "rccl_one_rank.py"
+    script.write_text(_RCCL_SCRIPT)
+    out = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, MDNS_DEVICE="0"))
+    assert out.returncode == 0 and "RCCL OK" in out.stdout, out.stderr[-2000:]
