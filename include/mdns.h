@@ -25,6 +25,7 @@
 #define MDNS_H
 
 #include <stddef.h>
+#include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -321,6 +322,45 @@ int mdns_count_within_dev(const double *d_members, int K, int ndim, double maxdi
 int mdns_bootstrap_round_maxsq_dev(const double *d_members, int K, int ndim,
                                    const double *d_chosen, int nbootstraps,
                                    double *d_round_sq);
+
+/* ------------------------------------------------------------------------------------------
+ * Part 4 -- grouping of the data sets that share live points.
+ *
+ * Replaces, behind `MultiNestedSampler.generate_subsets_graph` (multi_nested_sampler.py:268-355),
+ * igraph's `Graph.clusters()` on the bipartite graph {data sets} -- {live points} (:319-325)
+ * and the `numpy.unique(live_pointsp[:, selected])` in front of it (:279): connected components
+ * by minimum-label propagation on the device, the distinct ids as a bit map.  Integer results,
+ * independent of the order the hardware works in.
+ *
+ * The handle keeps the id matrix `live_pointsp` (int32[nlive][ndata], C order, :108) on the
+ * device, indexed by the ORIGINAL data-set index for the whole run.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct mdns_groups mdns_groups;
+mdns_groups *mdns_groups_create(int nlive, int ndata);
+void mdns_groups_destroy(mdns_groups *g);
+/* the whole matrix, ids int32[nlive][ndata] */
+int mdns_groups_set_ids(mdns_groups *g, const int32_t *ids);
+int mdns_groups_get_ids(mdns_groups *g, int32_t *ids);
+/* End of an iteration (multi_nested_sampler.py:510-520): data set rows[i] gives up the live point
+ * in slot slots[i] and takes new_ids[i]; n entries, rows distinct. */
+int mdns_groups_replace(mdns_groups *g, const int32_t *rows, const int32_t *slots,
+                        const int32_t *new_ids, int n);
+/* Connected components over the data sets rows[0..M) (ascending original indices; NULL with
+ * M == ndata: all).  Every id must lie in [0, npoints).  *ncomponents receives their number,
+ * *ndistinct the number of distinct ids the selection holds and `distinct` (int32[cap], may be
+ * NULL) those ids in ascending order -- numpy.unique of the selected columns (:279).  `touched`
+ * (uint64[ceil(npoints/64)], may be NULL) receives the same set as a bit map: bit q = some
+ * selected data set holds live point q. */
+int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M, long long npoints,
+                           int *ncomponents, long long *ndistinct, int32_t *distinct, long long cap,
+                           unsigned long long *touched);
+/* Of the last mdns_groups_components: labels int32[M] = the lowest data-set index of the
+ * component rows[i] lies in (components in ascending label order are igraph's cluster order,
+ * which numbers them by their first vertex); point_labels int32[npoints] = the label of the
+ * component holding live point q, -1 when no selected data set holds it.  Either may be NULL. */
+int mdns_groups_labels(mdns_groups *g, int32_t *labels, int32_t *point_labels);
+/* rounds of label propagation per mdns_groups_components call so far, on average */
+double mdns_groups_mean_rounds(const mdns_groups *g);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,8 @@ ABI_SYMBOLS = (
     "mdns_joint_get_thresholds", "mdns_joint_score_dev", "mdns_joint_flags_dev", "mdns_joint_commit_dev",
     "mdns_joint_result_dev", "mdns_joint_result_bytes", "mdns_joint_prepare_dev", "mdns_joint_advance_dev",
     "mdns_joint_restore_live_dev", "mdns_joint_undo_advance_dev", "mdns_joint_live_dev",
+    "mdns_groups_create", "mdns_groups_destroy", "mdns_groups_set_ids", "mdns_groups_get_ids",
+    "mdns_groups_replace", "mdns_groups_components", "mdns_groups_labels", "mdns_groups_mean_rounds",
 )
 
 #: mdns.h MDNS_JOINT_MAX_BATCH
@@ -130,6 +132,14 @@ def _declare(lib):
         "mdns_joint_restore_live_dev": (i, [vp, vp]),
         "mdns_joint_undo_advance_dev": (i, [vp]),
         "mdns_joint_live_dev": (vp, [vp]),
+        "mdns_groups_create": (vp, [i, i]),
+        "mdns_groups_destroy": (None, [vp]),
+        "mdns_groups_set_ids": (i, [vp, vp]),
+        "mdns_groups_get_ids": (i, [vp, vp]),
+        "mdns_groups_replace": (i, [vp, vp, vp, vp, i]),
+        "mdns_groups_components": (i, [vp, vp, i, C.c_longlong, vp, vp, vp, C.c_longlong, vp]),
+        "mdns_groups_labels": (i, [vp, vp, vp]),
+        "mdns_groups_mean_rounds": (d, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

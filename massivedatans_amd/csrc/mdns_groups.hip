@@ -1,0 +1,451 @@
+// Grouping of data sets that share live points, on the device (include/mdns.h, Part 4).
+//
+// The reference's default grouping (`generate_subsets_graph`, multi_nested_sampler.py:268-355)
+// builds the bipartite graph {data sets} -- {live points they hold} with igraph and asks for
+// its connected components (`graph.clusters()`, :325); with ONE component -- the rule late in a
+// run -- it hands on the selection and the ascending distinct ids (`numpy.unique`, :279,:331).
+// Both are order-free integer results, which is what a GPU can produce without a sequential
+// walk: minimum-label propagation over the edges.
+//
+//   idsT   int32[ndata][nlive]   the id matrix `live_pointsp` (:108) transposed, resident: the ids
+//                                of a data set are contiguous; one entry per running data set
+//                                changes per iteration (mdns_groups_replace)
+//   label  int32[ndata]          label of a data set: starts as its own index
+//   plabel int32[npoints]        label of a live point: starts above every index
+//
+// One wave per selected data set, one kernel per ROUND: the wave pulls the minimum over
+// label[d], the plabel of its ids and the label of that minimum, and pushes it to whatever
+// stands higher.
+// Labels only ever take the index of a data set of the same component, the component's lowest
+// data set keeps its own, so the only state no edge wants to change is "everything in a
+// component carries its lowest index" -- reached after a few rounds (the graphs are dense: a
+// live point is shared by ~100 data sets), detected by a round that changes nothing.
+//
+// No read-modify-write atomics: on this chip a million atomicMin on ~10^4 addresses take 70-100 us
+// and ten thousand on ONE address 3 ms (measured; the hot case is real -- early in a run every
+// data set holds the same initial points), and a lock-free union-find spends milliseconds
+// chasing and halving paths through the few hundred hot roots.  Relaxed device-scope loads and
+// stores cost 8 us per million.  A store that loses a race against a higher label is redone in
+// the next round by the edge that still sees the difference.
+#include "mdns_internal.h"
+
+#include <cstring>
+
+namespace mdns {
+
+static constexpr int kBlock = 256;
+static constexpr int kMaxRounds = 64;                 // rounds whose "changed" flag the header holds
+static constexpr int kUnclaimed = 0x7f7f7f7f;         // memset pattern: above every data-set index
+
+// what a components call copies back first: counts, failure bits (1 = id out of range, 2 = bad
+// replacement) and, per round, whether it still moved a label
+struct GroupsHeader { int ncomponents; int ndistinct; int status; int pad; int changed[kMaxRounds]; };
+
+// Device-scope relaxed accesses: values move between the waves of one kernel.
+__device__ __forceinline__ int load_relaxed(const int *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_relaxed(int *p, int v)
+{
+	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(kBlock) void k_groups_begin(int *__restrict__ label, const int *__restrict__ rows, int M)
+{
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= M) return;
+	const int d = rows ? rows[i] : i;
+	label[d] = d;
+}
+
+__device__ __forceinline__ int wave_min(int v)
+{
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) {
+		const int other = __shfl_xor(v, o, 64);
+		v = other < v ? other : v;
+	}
+	return v;
+}
+
+// One WAVE per selected data set d (its ids, idsT[d][0..nlive), are contiguous: lanes take slots
+// lane, lane + 64, ...): the wave pulls m = min(label[d], plabel of its ids, label[that minimum]),
+// lane 0 lowers label[d], every lane lowers the plabel of its ids that stand above m.  Data
+// sets are dispatched in ascending order, so a popular id is usually claimed by one of its lowest
+// holders before the others look: a handful of stores per id instead of one per holder (a
+// store per edge made a round of 10^6 edges 250 us; a round that only looks takes 6).
+__global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__ idsT, int nlive,
+                                                         const int *__restrict__ rows, int M, long long npoints,
+                                                         int *plabel, int *label,
+                                                         int *__restrict__ changed, int *__restrict__ status)
+{
+	const int lane = threadIdx.x & 63;
+	const int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (i >= M) return;                                               // whole waves
+	const int d = rows ? rows[i] : i;
+	const int *mine = idsT + (size_t) d * nlive;
+	const int l = label[d];
+	int m = l;
+	bool bad = false;
+	for (int p = lane; p < nlive; p += 64) {
+		const int q = mine[p];
+		if (q < 0 || q >= npoints) { bad = true; continue; }
+		const int pl = plabel[q];
+		m = pl < m ? pl : m;
+	}
+	if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(status, 1); return; }
+	m = wave_min(m);
+	const int lm = label[m];                           // m is a data set of this component: jump to ITS label
+	m = lm < m ? lm : m;
+	bool moved = false;
+	for (int p = lane; p < nlive; p += 64) {
+		const int q = mine[p];
+		if (m < plabel[q]) { plabel[q] = m; moved = true; }
+	}
+	if (lane == 0 && m < l) { label[d] = m; moved = true; }
+	// one flag for the round, raised by a wave that moved something unless it is up already
+	if (__ballot(moved) != 0ull && lane == 0 && load_relaxed(changed) == 0) store_relaxed(changed, 1);
+}
+
+// [rows][cols] -> [cols][rows]
+__global__ __launch_bounds__(kBlock) void k_groups_transpose(const int *__restrict__ src, int nrows, int ncols, int *__restrict__ dst)
+{
+	__shared__ int tile[32][33];
+	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;               // 32 x 8
+	const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+	for (int k = ty; k < 32; k += 8)
+		if (r0 + k < nrows && c0 + tx < ncols) tile[k][tx] = src[(size_t) (r0 + k) * ncols + c0 + tx];
+	__syncthreads();
+	for (int k = ty; k < 32; k += 8)
+		if (c0 + k < ncols && r0 + tx < nrows) dst[(size_t) (c0 + k) * nrows + r0 + tx] = tile[tx][k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_groups_finish(const int *__restrict__ label, const int *__restrict__ rows, int M,
+                                                          int *__restrict__ labels, GroupsHeader *__restrict__ header)
+{
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= M) return;
+	const int d = rows ? rows[i] : i;
+	const int l = label[d];
+	labels[i] = l;
+	if (l == d) atomicAdd(&header->ncomponents, 1);
+}
+
+// bit q of the map = some selected data set holds live point q: a wave's ballot is the word
+__global__ __launch_bounds__(kBlock) void k_groups_touched(const int *__restrict__ plabel, long long npoints,
+                                                           unsigned long long *__restrict__ touched)
+{
+	const long long q = (long long) blockIdx.x * kBlock + threadIdx.x;
+	const bool held = q < npoints && plabel[q] != kUnclaimed;
+	const unsigned long long word = __ballot(held);
+	if ((threadIdx.x & 63) == 0 && q < npoints) touched[q >> 6] = word;
+}
+
+// The set bits of the map as an ascending list of ids -- numpy.unique of the selected columns
+// (multi_nested_sampler.py:279) -- by ONE workgroup: popcounts of contiguous runs of words, a scan
+// over the 1024 run totals, then every thread writes out its run.
+__global__ __launch_bounds__(1024) void k_groups_compact(const unsigned long long *__restrict__ touched, long long nwords,
+                                                         int *__restrict__ distinct, GroupsHeader *__restrict__ header)
+{
+	__shared__ int wave_total[16];
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const long long run = (nwords + 1023) / 1024;
+	const long long w0 = t * run, w1 = w0 + run < nwords ? w0 + run : nwords;
+	int mine = 0;
+	for (long long w = w0; w < w1; w++) mine += __popcll(touched[w]);
+	int incl = mine;                                                   // inclusive scan inside the wave
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int up = __shfl_up(incl, o, 64);
+		if (lane >= o) incl += up;
+	}
+	if (lane == 63) wave_total[wave] = incl;
+	__syncthreads();
+	int before = 0;
+	for (int k = 0; k < wave; k++) before += wave_total[k];
+	int at = before + incl - mine;
+	for (long long w = w0; w < w1; w++) {
+		unsigned long long bits = touched[w];
+		while (bits) {
+			distinct[at++] = (int) (w * 64 + __builtin_ctzll(bits));
+			bits &= bits - 1;
+		}
+	}
+	if (t == 1023) header->ndistinct = before + incl;
+}
+
+__global__ __launch_bounds__(kBlock) void k_groups_point_labels(const int *__restrict__ plabel, long long npoints,
+                                                                int *__restrict__ point_labels)
+{
+	const long long q = (long long) blockIdx.x * kBlock + threadIdx.x;
+	if (q >= npoints) return;
+	const int l = plabel[q];
+	point_labels[q] = l == kUnclaimed ? -1 : l;
+}
+
+__global__ __launch_bounds__(kBlock) void k_groups_replace(int *__restrict__ idsT, int ndata, int nlive,
+                                                           const int *__restrict__ rows, const int *__restrict__ slots,
+                                                           const int *__restrict__ new_ids, int n, int *__restrict__ status)
+{
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	if (i >= n) return;
+	const int d = rows[i], p = slots[i];
+	if (d < 0 || d >= ndata || p < 0 || p >= nlive) { atomicOr(status, 2); return; }
+	idsT[(size_t) d * nlive + p] = new_ids[i];
+}
+
+}  // namespace mdns
+
+using namespace mdns;
+
+struct mdns_groups {
+	int nlive = 0, ndata = 0;
+	int *d_idsT = nullptr;             // [ndata][nlive]
+	int *d_tmp = nullptr;              // [nlive][ndata] staging of set_ids / get_ids
+	int *d_label = nullptr;            // [ndata] by data set
+	int *d_rows = nullptr;             // [3 * ndata]: selection, or (rows | slots | new ids) of a replacement
+	int *d_labels = nullptr;           // [ndata] by position in the selection
+	// per id; grown with the pile of accepted points.  One block:
+	//   header | distinct ids (ascending) | touched bit map | plabel | point labels (out)
+	// -- header and the list in front, so that one copy fetches both
+	char *d_points = nullptr;  long long cap_points = 0;
+	char *h_pin = nullptr;  size_t pin_bytes = 0;
+	bool have_ids = false;
+	int last_M = -1;  long long last_npoints = 0;      // of the last components call (-1: ids changed since)
+	int rounds_hint = 4;                               // rounds the next call launches before it looks
+	long long distinct_hint = 1024;                    // ids the next call fetches with the header
+	long long rounds_total = 0, calls_total = 0;
+};
+
+static constexpr size_t kHeaderBytes = 512;            // sizeof(GroupsHeader) rounded up: keeps what follows aligned
+static_assert(sizeof(GroupsHeader) <= kHeaderBytes, "header grew");
+static size_t words_of(long long npoints) { return (size_t) ((npoints + 63) / 64); }
+static GroupsHeader *hdr_of(mdns_groups *g) { return (GroupsHeader *) g->d_points; }
+static int *distinct_of(mdns_groups *g) { return (int *) (g->d_points + kHeaderBytes); }
+static unsigned long long *touched_of(mdns_groups *g) { return (unsigned long long *) (distinct_of(g) + g->cap_points); }
+static int *plabel_of(mdns_groups *g) { return (int *) (touched_of(g) + words_of(g->cap_points)); }
+static int *pout_of(mdns_groups *g) { return plabel_of(g) + g->cap_points; }
+
+static char *groups_pin(mdns_groups *g, size_t bytes)
+{
+	if (bytes <= g->pin_bytes) return g->h_pin;
+	Context *c = ctx();
+	if (g->h_pin) { (void) hipStreamSynchronize(c->stream); (void) hipHostFree(g->h_pin); g->h_pin = nullptr; g->pin_bytes = 0; }
+	const size_t want = bytes + bytes / 2 + 4096;
+	if (!MDNS_HIP(hipHostMalloc((void **) &g->h_pin, want, hipHostMallocDefault))) return nullptr;
+	g->pin_bytes = want;
+	return g->h_pin;
+}
+
+static bool groups_fit_points(mdns_groups *g, long long npoints)
+{
+	if (npoints <= g->cap_points) return true;
+	Context *c = ctx();
+	long long cap = g->cap_points > 0 ? g->cap_points : 4096;
+	while (cap < npoints) cap *= 2;                                    // (a multiple of 64: the regions stay 8-byte aligned)
+	if (g->d_points) { (void) hipStreamSynchronize(c->stream); (void) hipFree(g->d_points); g->d_points = nullptr; g->cap_points = 0; }
+	const size_t bytes = kHeaderBytes + words_of(cap) * 8 + (size_t) cap * 3 * sizeof(int);
+	if (!MDNS_HIP(hipMalloc((void **) &g->d_points, bytes))) return false;
+	g->cap_points = cap;
+	g->last_M = -1;
+	return MDNS_HIP(hipMemsetAsync(g->d_points, 0, kHeaderBytes, c->stream));
+}
+
+extern "C" void mdns_groups_destroy(mdns_groups *g)
+{
+	if (!g) return;
+	Context *c = ctx();
+	if (c) (void) hipStreamSynchronize(c->stream);
+	void *bufs[] = {g->d_idsT, g->d_tmp, g->d_label, g->d_rows, g->d_labels, g->d_points};
+	for (void *b : bufs) if (b) (void) hipFree(b);
+	if (g->h_pin) (void) hipHostFree(g->h_pin);
+	delete g;
+}
+
+extern "C" mdns_groups *mdns_groups_create(int nlive, int ndata)
+{
+	Context *c = ctx();
+	if (!c) return nullptr;
+	if (nlive <= 0 || ndata <= 0) { set_error("mdns_groups_create: nlive=%d ndata=%d", nlive, ndata); return nullptr; }
+	mdns_groups *g = new mdns_groups();
+	g->nlive = nlive; g->ndata = ndata;
+	const size_t nd = (size_t) ndata;
+	const bool ok =
+	    MDNS_HIP(hipMalloc((void **) &g->d_idsT, (size_t) nlive * nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &g->d_tmp, (size_t) nlive * nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &g->d_label, nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &g->d_rows, 3 * nd * sizeof(int))) &&
+	    MDNS_HIP(hipMalloc((void **) &g->d_labels, nd * sizeof(int))) &&
+	    groups_fit_points(g, 4096);
+	if (!ok) { mdns_groups_destroy(g); return nullptr; }
+	return g;
+}
+
+extern "C" int mdns_groups_set_ids(mdns_groups *g, const int32_t *ids)
+{
+	Context *c = ctx();
+	if (!c || !g || !ids) return 1;
+	const size_t bytes = (size_t) g->nlive * g->ndata * sizeof(int);
+	if (!MDNS_HIP(hipMemcpyAsync(g->d_tmp, ids, bytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	hipLaunchKernelGGL(k_groups_transpose, dim3((g->ndata + 31) / 32, (g->nlive + 31) / 32), dim3(kBlock), 0, c->stream,
+	                   g->d_tmp, g->nlive, g->ndata, g->d_idsT);
+	if (!MDNS_HIP(hipGetLastError()) || !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+	g->have_ids = true;
+	g->last_M = -1;
+	return 0;
+}
+
+extern "C" int mdns_groups_get_ids(mdns_groups *g, int32_t *ids)
+{
+	Context *c = ctx();
+	if (!c || !g || !ids) return 1;
+	const size_t bytes = (size_t) g->nlive * g->ndata * sizeof(int);
+	hipLaunchKernelGGL(k_groups_transpose, dim3((g->nlive + 31) / 32, (g->ndata + 31) / 32), dim3(kBlock), 0, c->stream,
+	                   g->d_idsT, g->ndata, g->nlive, g->d_tmp);
+	return MDNS_HIP(hipGetLastError()) &&
+	       MDNS_HIP(hipMemcpyAsync(ids, g->d_tmp, bytes, hipMemcpyDeviceToHost, c->stream)) &&
+	       MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
+}
+
+extern "C" int mdns_groups_replace(mdns_groups *g, const int32_t *rows, const int32_t *slots, const int32_t *new_ids, int n)
+{
+	Context *c = ctx();
+	if (!c || !g) return 1;
+	if (n < 0 || n > g->ndata || (n > 0 && (!rows || !slots || !new_ids))) { set_error("mdns_groups_replace: n=%d", n); return 1; }
+	if (!g->have_ids) { set_error("mdns_groups_replace: no id matrix yet (mdns_groups_set_ids)"); return 1; }
+	if (n == 0) return 0;
+	// rows | slots | new ids: one pinned block, one copy.  Nothing waits: a bad index raises a
+	// bit in the header that the next mdns_groups_components reports.
+	char *pin = groups_pin(g, (size_t) 3 * n * sizeof(int));
+	if (!pin) return 1;
+	// (the staging block may still feed the previous copy)
+	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+	memcpy(pin, rows, (size_t) n * 4);
+	memcpy(pin + (size_t) n * 4, slots, (size_t) n * 4);
+	memcpy(pin + (size_t) n * 8, new_ids, (size_t) n * 4);
+	if (!MDNS_HIP(hipMemcpyAsync(g->d_rows, pin, (size_t) 3 * n * 4, hipMemcpyHostToDevice, c->stream))) return 1;
+	hipLaunchKernelGGL(k_groups_replace, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+	                   g->d_idsT, g->ndata, g->nlive, g->d_rows, g->d_rows + n, g->d_rows + 2 * n, n, &hdr_of(g)->status);
+	g->last_M = -1;
+	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
+}
+
+extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M, long long npoints,
+                                      int *ncomponents, long long *ndistinct, int32_t *distinct, long long cap,
+                                      unsigned long long *touched)
+{
+	Context *c = ctx();
+	if (!c || !g || !ncomponents) return 1;
+	if (!g->have_ids) { set_error("mdns_groups_components: no id matrix yet (mdns_groups_set_ids)"); return 1; }
+	if (M <= 0 || M > g->ndata || npoints <= 0 || (!rows && M != g->ndata) || (distinct && cap < 0)) {
+		set_error("mdns_groups_components: M=%d (ndata=%d) npoints=%lld", M, g->ndata, npoints);
+		return 1;
+	}
+	if (rows)
+		for (int i = 0; i < M; i++)
+			if (rows[i] < 0 || rows[i] >= g->ndata || (i > 0 && rows[i] <= rows[i - 1])) {
+				set_error("mdns_groups_components: rows must be ascending indices below %d", g->ndata);
+				return 1;
+			}
+	// (a pending replacement wrote its failure bit into the old block: keep it across a regrowth)
+	if (npoints > g->cap_points) {
+		int status = 0;
+		if (!MDNS_HIP(hipMemcpyAsync(&status, &hdr_of(g)->status, sizeof(int), hipMemcpyDeviceToHost, c->stream)) ||
+		    !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+		if (!groups_fit_points(g, npoints)) return 1;
+		if (status && !MDNS_HIP(hipMemcpyAsync(&hdr_of(g)->status, &status, sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
+		if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+	}
+	const size_t nw = words_of(npoints);
+	// the most this selection can hold, and how much of the list travels with the header
+	long long most = (long long) M * g->nlive < npoints ? (long long) M * g->nlive : npoints;
+	long long guess = distinct ? (g->distinct_hint < most ? g->distinct_hint : most) : 0;
+	char *pin = groups_pin(g, (size_t) M * 4 + 16 + kHeaderBytes + (size_t) most * 4);
+	if (!pin) return 1;
+	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;             // the staging block is free again
+	if (rows) {
+		memcpy(pin, rows, (size_t) M * 4);
+		if (!MDNS_HIP(hipMemcpyAsync(g->d_rows, pin, (size_t) M * 4, hipMemcpyHostToDevice, c->stream))) return 1;
+	}
+	const int *d_rows = rows ? g->d_rows : nullptr;
+	// round flags and counts cleared (not the failure bits), no live point labelled
+	if (!MDNS_HIP(hipMemsetAsync(&hdr_of(g)->changed[0], 0, sizeof(int) * kMaxRounds, c->stream)) ||
+	    !MDNS_HIP(hipMemsetAsync(plabel_of(g), 0x7f, (size_t) npoints * sizeof(int), c->stream))) return 1;
+	hipLaunchKernelGGL(k_groups_begin, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g->d_label, d_rows, M);
+	char *out = pin + (((size_t) M * 4 + 15) & ~(size_t) 15);
+	const GroupsHeader *h = (const GroupsHeader *) out;
+	int done = 0, batch = g->rounds_hint;
+	while (true) {
+		if (done + batch > kMaxRounds) batch = kMaxRounds - done;
+		for (int r = done; r < done + batch; r++)
+			hipLaunchKernelGGL(k_groups_round, dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
+			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, &hdr_of(g)->changed[r],
+			                   &hdr_of(g)->status);
+		done += batch;
+		// optimistically everything that follows a converged state, in the same round trip
+		if (!MDNS_HIP(hipMemsetAsync(hdr_of(g), 0, 2 * sizeof(int), c->stream))) return 1;      // the two counts
+		hipLaunchKernelGGL(k_groups_finish, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
+		                   g->d_label, d_rows, M, g->d_labels, hdr_of(g));
+		hipLaunchKernelGGL(k_groups_touched, dim3((unsigned) ((npoints + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+		                   plabel_of(g), npoints, touched_of(g));
+		hipLaunchKernelGGL(k_groups_compact, dim3(1), dim3(1024), 0, c->stream, touched_of(g), (long long) nw, distinct_of(g), hdr_of(g));
+		if (!MDNS_HIP(hipGetLastError())) return 1;
+		if (!MDNS_HIP(hipMemcpyAsync(out, g->d_points, kHeaderBytes + (size_t) guess * 4, hipMemcpyDeviceToHost, c->stream)) ||
+		    !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+		if (h->status) {
+			const int status = h->status;
+			(void) hipMemsetAsync(&hdr_of(g)->status, 0, sizeof(int), c->stream);
+			set_error(status & 2 ? "mdns_groups_components: an earlier mdns_groups_replace named a data set or slot that does not exist"
+			                     : "mdns_groups_components: an id outside [0, %lld) was met", npoints);
+			return 1;
+		}
+		if (h->changed[done - 1] == 0) break;                        // the last round found nothing to do
+		if (done >= kMaxRounds) { set_error("mdns_groups_components: labels still moving after %d rounds", kMaxRounds); return 1; }
+		batch = 4;
+	}
+	int clean = done - 1;
+	while (clean > 0 && h->changed[clean - 1] == 0) clean--;
+	g->rounds_hint = clean + 2 < 2 ? 2 : (clean + 2 > 16 ? 16 : clean + 2);
+	g->rounds_total += clean + 1; g->calls_total++;
+	*ncomponents = h->ncomponents;
+	const long long nd = h->ndistinct;
+	if (ndistinct) *ndistinct = nd;
+	g->distinct_hint = nd + nd / 4 + 256;
+	if (distinct) {
+		if (nd > cap) { set_error("mdns_groups_components: %lld distinct ids, room for %lld", nd, cap); return 1; }
+		if (nd > guess) {                                            // the rest of the list
+			if (!MDNS_HIP(hipMemcpyAsync(out + kHeaderBytes + (size_t) guess * 4, distinct_of(g) + guess, (size_t) (nd - guess) * 4,
+			                             hipMemcpyDeviceToHost, c->stream)) || !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+		}
+		memcpy(distinct, out + kHeaderBytes, (size_t) nd * 4);
+	}
+	if (touched) {
+		if (!MDNS_HIP(hipMemcpyAsync(touched, touched_of(g), nw * 8, hipMemcpyDeviceToHost, c->stream)) ||
+		    !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+	}
+	g->last_M = M; g->last_npoints = npoints;
+	return 0;
+}
+
+/* rounds the label propagation needed per call so far (the clean round included) */
+extern "C" double mdns_groups_mean_rounds(const mdns_groups *g)
+{
+	return g && g->calls_total ? (double) g->rounds_total / (double) g->calls_total : 0.0;
+}
+
+extern "C" int mdns_groups_labels(mdns_groups *g, int32_t *labels, int32_t *point_labels)
+{
+	Context *c = ctx();
+	if (!c || !g) return 1;
+	if (g->last_M <= 0) { set_error("mdns_groups_labels: no components computed since the ids last changed"); return 1; }
+	const int M = g->last_M;
+	const long long np = g->last_npoints;
+	if (point_labels)
+		hipLaunchKernelGGL(k_groups_point_labels, dim3((unsigned) ((np + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+		                   plabel_of(g), np, pout_of(g));
+	if (!MDNS_HIP(hipGetLastError())) return 1;
+	if (labels && !MDNS_HIP(hipMemcpyAsync(labels, g->d_labels, (size_t) M * 4, hipMemcpyDeviceToHost, c->stream))) return 1;
+	if (point_labels && !MDNS_HIP(hipMemcpyAsync(point_labels, pout_of(g), (size_t) np * 4, hipMemcpyDeviceToHost, c->stream))) return 1;
+	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
+}

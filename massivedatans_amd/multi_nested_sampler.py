@@ -125,7 +125,8 @@ class MultiNestedSampler(object):
     def __init__(self, priortransform, multi_loglikelihood, superset_draw_constrained,
                  individual_draw_constrained, draw_constrained, ndata, ndim, nlive_points=200,
                  draw_global_uniform=None, nsuperset_draws=10, use_graph=False,
-                 multi_loglikelihood_batch=None, joint_state=None, priortransform_batch=None):
+                 multi_loglikelihood_batch=None, joint_state=None, priortransform_batch=None,
+                 device_groups=False):
         self.nlive_points = nlive_points
         self.nsuperset_draws = nsuperset_draws
         self.priortransform = priortransform
@@ -140,6 +141,10 @@ class MultiNestedSampler(object):
         self.ndim = ndim
         self.ndata = ndata
         self.use_graph = use_graph
+        #: with use_graph: connected components and distinct ids from the device
+        #: (massivedatans_amd.grouping, csrc/mdns_groups.hip) instead of the host walk
+        self._device_groups_wanted = bool(device_groups)
+        self._dgroups = None
         self.point_data_map = None          # point id -> set of data sets holding it (lazy)
         #: likelihood evaluations = (candidate, data set) pairs actually scored
         self.nevals = 0
@@ -193,8 +198,28 @@ class MultiNestedSampler(object):
             if self._walk:
                 _host.lib().mdns_host_walk_destroy(self._walk)
                 self._walk = None
+            if self._dgroups is not None:
+                self._dgroups.close()
+                self._dgroups = None
         except Exception:
             pass
+
+    def _running_indices(self):
+        """Original index of every running data set."""
+        if self._real_indices is None:
+            self._real_indices = numpy.where(self.real_data_mask_all)[0]
+        return self._real_indices
+
+    def _device_groups(self):
+        """The id matrix on the device (created at the first grouping that needs it), or None."""
+        if not self._device_groups_wanted:
+            return None
+        if self._dgroups is None:
+            from .grouping import DeviceGroups
+            full = numpy.zeros((self.nlive_points, len(self.real_data_mask_all)), dtype=numpy.int32)
+            full[:, self._running_indices()] = self.live_pointsp
+            self._dgroups = DeviceGroups(full)
+        return self._dgroups
 
     @property
     def shelves(self):
@@ -482,6 +507,27 @@ class MultiNestedSampler(object):
         ORDER is restated from igraph's documented behaviour and is not pinned against a
         reference run; the PARTITION is that of the pinned walk (the components come from the
         same native code) and is cross-checked against networkx in tests/test_sampler_units.py."""
+        dg = self._device_groups()
+        if dg is not None:
+            selected = numpy.flatnonzero(data_mask)
+            if len(selected) == 1:
+                yield data_mask, self.live_pointsp[:, selected[0]]
+                return
+            # (the reference's two shortcuts, :283-297, name cases that are connected: the
+            # components say the same)
+            running = self._running_indices()
+            rows = None if len(selected) == dg.ndata else running[selected]
+            ncomp, ids = dg.components(rows, len(self.pointpile))
+            if ncomp == 1:
+                yield data_mask, ids
+                return
+            labels, point_labels = dg.labels()
+            of_id = point_labels[ids]
+            for root in numpy.unique(labels):            # ascending: clusters in order of their first vertex
+                member_mask = numpy.zeros(len(data_mask), dtype=bool)
+                member_mask[selected[labels == root]] = True
+                yield member_mask, ids[of_id == root]
+            return
         lib = _host_lib()
         if lib is not None:
             groups = list(self._groups_native(lib, data_mask))
@@ -604,9 +650,7 @@ class MultiNestedSampler(object):
                 if len(groups) > 1 and not focussed and (self._shelves.n[joint_indices] > 0).all():
                     continue                      # this group needs nothing
                 Lmins_higher = self._higher[joint_indices].copy() if self.joint is None else None
-                if self._real_indices is None:        # original index of every running data set
-                    self._real_indices = numpy.where(self.real_data_mask_all)[0]
-                real_indices = self._real_indices
+                real_indices = self._running_indices()
                 if njoints == 1:
                     draw = self.individual_draw_constrained(real_indices[firstd], self.global_iter, sampler=self)
                 elif rebuilding_draw:
@@ -700,6 +744,8 @@ class MultiNestedSampler(object):
         if self._lpT is not None:
             self._lpT[every, Lmini] = newp
         self._walk_stale = True
+        if self._dgroups is not None:
+            self._dgroups.replace(self._running_indices(), Lmini, newp)
         if self.joint is not None:
             self.joint.advance()
             self._live_cache = None

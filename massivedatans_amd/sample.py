@@ -131,6 +131,11 @@ def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False
     cc = CachedConstrainer()
     _, _, individual_draw_constrained = generate_individual_constrainer()
     numpy.random.seed(seed)                                      # sample.py:162
+    joint = problem.joint_state(nlive_points) if fused else None
+    # the graph variant of the grouping runs on the device when the likelihoods do
+    from .jointstate import GaussJointState
+    on_device = isinstance(joint, GaussJointState) or isinstance(getattr(joint, 'local', None), GaussJointState)
+    device_groups = use_graph and on_device and os.environ.get('MDNS_DEVICE_GROUPS', '1') != '0'
     sampler = MultiNestedSampler(
         nlive_points=nlive_points, priortransform=priortransform,
         multi_loglikelihood=problem.multi_loglikelihood, ndim=nparams, ndata=problem.ndata,
@@ -138,8 +143,8 @@ def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False
         individual_draw_constrained=individual_draw_constrained,
         draw_constrained=cc.get, nsuperset_draws=nsuperset_draws, use_graph=use_graph,
         multi_loglikelihood_batch=problem.multi_loglikelihood_batch if batched else None,
-        joint_state=problem.joint_state(nlive_points) if fused else None,
-        priortransform_batch=priortransform_batch if fused else None)
+        joint_state=joint, priortransform_batch=priortransform_batch if fused else None,
+        device_groups=device_groups)
     superset_constrainer.sampler = sampler
     cc.sampler = sampler
     return sampler
@@ -228,8 +233,9 @@ def main(argv=None):
     nlive_points = int(os.environ.get('NLIVE_POINTS', '400'))
     use_graph = os.environ.get('USE_GRAPH', '0') == '1'
     if use_graph:
-        log.warning('USE_GRAPH=1: the point order inside a group of data sets follows igraph\'s documented '
-                    'behaviour and is not pinned against a run of the reference (USE_GRAPH=0 is)')
+        log.warning('USE_GRAPH=1: when a selection falls into several groups, their order and the point order '
+                    'inside them follow igraph\'s documented behaviour and are not pinned against a run of the '
+                    'reference (a single group is: numpy.unique; so is USE_GRAPH=0)')
     backend = distributed_backend(data['x'], data['y'])
     results, sampler, problem, duration = run(
         data['x'], data['y'], nlive_points=nlive_points, backend=backend,

@@ -50,11 +50,14 @@ def main():
             kind, ndata, nlive, cap = a.split(":")
             cases.append((kind, int(ndata), int(nlive), int(cap)))
     for kind, ndata, nlive, cap in cases:
-        data = (gen.horns if kind == "horns" else gen.nothing)(ndata)
+        # kind "horns-graph": the grouping of the reference's USE_GRAPH=1 default
+        # (generate_subsets_graph: connected components, ids ascending), host implementation
+        use_graph = kind.endswith("-graph")
+        data = (gen.horns if kind.startswith("horns") else gen.nothing)(ndata)
         backend = oracle_backend.OracleSpectra(o, data["x"], data["y"])
         with np.errstate(all="ignore"):
             results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap,
-                                                use_graph=False, backend=backend)
+                                                use_graph=use_graph, backend=backend)
         out["%s_%d_%d_%d" % (kind, ndata, nlive, cap)] = {
             "ndraws": int(sampler.ndraws), "npoints": int(len(sampler.pointpile)),
             "pointpile_sha256": hashlib.sha256(np.ascontiguousarray(sampler.pointpile, dtype=np.float64).tobytes()).hexdigest(),

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """End-to-end analysis on the GPU: python tools/e2e_run.py <horns|nothing> <ndata> <nlive> <max_samples>
-(max_samples 0 = run to the termination criterion; MDNS_E2E_PROFILE=1 adds a cProfile summary on stderr)"""
+(max_samples 0 = run to the termination criterion; MDNS_E2E_PROFILE=1 adds a cProfile summary on stderr;
+USE_GRAPH=1 takes the reference's default grouping, connected components, computed on the device)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -28,7 +29,8 @@ def _beat():
 threading.Thread(target=_beat, daemon=True).start()
 def _go():
     with np.errstate(all="ignore"):
-        return sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap, use_graph=False,
+        return sample.run(data["x"], data["y"], nlive_points=nlive, max_samples=cap,
+                          use_graph=os.environ.get("USE_GRAPH", "0") == "1",
                           fused=os.environ.get("MDNS_FUSED", "1") != "0")
 if os.environ.get("MDNS_E2E_PROFILE") == "1":        # cProfile of the whole run, top entries on stderr
     import cProfile, pstats
@@ -45,5 +47,7 @@ print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nl
                   "launches": int(problem.ncalls + (sampler.joint.ncalls if sampler.joint is not None else 0)),
                   "fused": sampler.joint is not None, "constrained_draws": int(sampler.ndraw_calls),
                   "draw_chunks": int(sampler.ndraw_chunks),
+                  "grouping": ("graph (components on the device, %d calls)" % sampler._dgroups.ncalls) if sampler._dgroups is not None
+                  else ("graph (host)" if sampler.use_graph else "walk (host)"),
                   "useful_evals_per_s": sampler.nevals / duration,
                   "logZ_first3": results["logZ"][:3].tolist()}))
