@@ -178,16 +178,17 @@ def hbm_regime_leg(lib, _lib, ndata=1000000, nx=200, reps=20):
             "frac": gbs / HBM_PEAK_GBS, "evals_per_s": ndata / (us * 1e-6)}
 
 
-def e2e_leg(data, iterations):
+def e2e_leg(data, iterations, use_graph=False):
     """SURVEY 8(d)'s metric as it is defined: a real analysis (sampler + integrator + constrainers
     on the host, every kernel and the accept / fill decisions on the device) of the same spectra,
     capped after `iterations` nested-sampling iterations; useful (candidate, data set) evaluations
-    of the constrained draws divided by the wall-clock spent inside draw_constrained."""
+    of the constrained draws divided by the wall-clock spent inside draw_constrained.
+    use_graph: the reference's default grouping (connected components), computed on the device;
+    otherwise the pinned walk on the host (sample.py:189 USE_GRAPH)."""
     from massivedatans_amd import sample
-    t0 = time.perf_counter()
     with np.errstate(all="ignore"):
         results, sampler, problem, duration = sample.run(data["x"], data["y"], nlive_points=NLIVE,
-                                                         max_samples=iterations, use_graph=False)
+                                                         max_samples=iterations, use_graph=use_graph)
     joint = sampler.joint
     evals_draws = int(sampler.nevals) - NLIVE * data["y"].shape[1]          # without the initial live points
     out = {"workload": "complete analysis of the same spectra, capped at %d iterations (tolerance 0.5, nlive %d)"
@@ -200,7 +201,10 @@ def e2e_leg(data, iterations):
            "draw_constrained_wall_s": sampler.draw_seconds,
            "evals_per_s_in_draw_constrained": evals_draws / sampler.draw_seconds if sampler.draw_seconds else None,
            "evals_per_s_whole_run": int(sampler.nevals) / duration,
-           "fused": joint is not None, "logZ_first3": [float(v) for v in results["logZ"][:3]]}
+           "fused": joint is not None, "logZ_first3": [float(v) for v in results["logZ"][:3]],
+           "grouping": ("connected components on the device (USE_GRAPH=1), %d calls, %.1f rounds each"
+                        % (sampler._dgroups.ncalls, sampler._dgroups.mean_rounds())) if sampler._dgroups is not None
+           else ("connected components on the host (USE_GRAPH=1)" if use_graph else "discovery-order walk on the host (USE_GRAPH=0)")}
     if joint is not None:
         joint.close()
     return out
@@ -508,6 +512,7 @@ def bench_gauss(args):
         res.update(other)
         if world == 1 and not args.no_e2e:
             res["e2e"] = e2e_leg(data, args.e2e_iterations)
+            res["e2e_graph"] = e2e_leg(data, args.e2e_iterations, use_graph=True)
         if world == 1 and not args.no_hbm_leg:
             res["roofline_hbm_regime"] = hbm_regime_leg(lib, _lib)
         if world == 1 and not args.no_cpu_baseline:
