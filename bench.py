@@ -347,9 +347,10 @@ def bench_gauss(args):
     d_params, d_chosen, d_cands = dev(params), dev(chosen), dev(cands)
     d_counts = lib.mdns_dev_alloc(NCAND * 4)
     nres = lib.mdns_joint_result_bytes(nd)
-    nhead = 16 + 8 * ((nd + 63) // 64)                     # {accepted, status} + fill bits: what the host needs per draw
     result = np.zeros(nres, dtype=np.uint8)
     state = {"advanced": False}
+    accepted_now = C.c_int(-2)
+    fill_now = np.zeros((nd + 63) // 64, dtype=np.uint64)
     d_flags = lib.mdns_joint_flags_dev(joint)
     d_result = lib.mdns_joint_result_dev(joint)
     if use_dist:
@@ -414,13 +415,14 @@ def bench_gauss(args):
         radius = lib.mdns_region_radius(region)
         if radius != radius:
             raise _lib.MdnsError(_lib.last_error())
+        # ({accepted, status, fill words} arrive in mapped host memory: mdns_joint_fetch polls for them)
         if use_dist:
             if direct is None:
                 gathered.wait()
-            _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, 16), "result")
+            _lib.check(lib.mdns_joint_fetch(joint, nd, C.byref(accepted_now), None), "outcome")
             _lib.check(lib.mdns_d2h(_lib.ptr(allbits), C.c_void_p(t_allbits.data_ptr()), allbits.nbytes), "fill bits of all ranks")
         else:
-            _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nhead), "result")
+            _lib.check(lib.mdns_joint_fetch(joint, nd, C.byref(accepted_now), _lib.ptr(fill_now)), "outcome")
 
     def fence():
         _lib.check(lib.mdns_sync(), "sync")
@@ -461,6 +463,9 @@ def bench_gauss(args):
     ypred = params[B - 1, 0] * np.exp(-0.5 * ((params[B - 1, 1] - data["x"]) / params[B - 1, 2]) ** 2)
     want = -0.5 * (((ypred.reshape((-1, 1)) - shard[:, :64]) / 0.01) ** 2).sum(axis=0)
     assert accepted == B - 1 and status == 0, ("bench draw: accepted %d status %d" % (accepted, status))
+    assert accepted_now.value == B - 1, "bench draw: the polled outcome differs from the result buffer"
+    if not use_dist:
+        assert np.array_equal(fill_now.view(np.uint8), result[16:16 + 8 * nbw]), "bench draw: polled fill bits differ"
     assert bits.all(), "bench draw: the accepted candidate must fill every shelf"
     if use_dist:
         every = np.unpackbits(allbits.view(np.uint8).reshape(world, -1), axis=1, bitorder="little")[:, :nd]

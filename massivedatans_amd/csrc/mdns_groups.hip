@@ -51,14 +51,6 @@ __device__ __forceinline__ void store_relaxed(int *p, int v)
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(kBlock) void k_groups_begin(int *__restrict__ label, const int *__restrict__ rows, int M)
-{
-	const int i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= M) return;
-	const int d = rows ? rows[i] : i;
-	label[d] = d;
-}
-
 __device__ __forceinline__ int wave_min(int v)
 {
 #pragma unroll
@@ -77,7 +69,7 @@ __device__ __forceinline__ int wave_min(int v)
 // store per edge made a round of 10^6 edges 250 us; a round that only looks takes 6).
 __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__ idsT, int nlive,
                                                          const int *__restrict__ rows, int M, long long npoints,
-                                                         int *plabel, int *label,
+                                                         int *plabel, int *label, int first,
                                                          int *__restrict__ changed, int *__restrict__ status)
 {
 	const int lane = threadIdx.x & 63;
@@ -85,7 +77,9 @@ __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__
 	if (i >= M) return;                                               // whole waves
 	const int d = rows ? rows[i] : i;
 	const int *mine = idsT + (size_t) d * nlive;
-	const int l = label[d];
+	// the first round of a call starts every data set from its own index (label[] still holds
+	// the previous call's values: nobody reads another data set's label in this round)
+	const int l = first ? d : label[d];
 	int m = l;
 	bool bad = false;
 	for (int p = lane; p < nlive; p += 64) {
@@ -96,14 +90,16 @@ __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__
 	}
 	if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(status, 1); return; }
 	m = wave_min(m);
-	const int lm = label[m];                           // m is a data set of this component: jump to ITS label
-	m = lm < m ? lm : m;
+	if (!first) {
+		const int lm = label[m];                                      // m is a data set of this component: jump to ITS label
+		m = lm < m ? lm : m;
+	}
 	bool moved = false;
 	for (int p = lane; p < nlive; p += 64) {
 		const int q = mine[p];
 		if (m < plabel[q]) { plabel[q] = m; moved = true; }
 	}
-	if (lane == 0 && m < l) { label[d] = m; moved = true; }
+	if (lane == 0 && (m < l || first)) { label[d] = m; moved = moved || m < l; }
 	// one flag for the round, raised by a wave that moved something unless it is up already
 	if (__ballot(moved) != 0ull && lane == 0 && load_relaxed(changed) == 0) store_relaxed(changed, 1);
 }
@@ -372,7 +368,6 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 	// round flags and counts cleared (not the failure bits), no live point labelled
 	if (!MDNS_HIP(hipMemsetAsync(&hdr_of(g)->changed[0], 0, sizeof(int) * kMaxRounds, c->stream)) ||
 	    !MDNS_HIP(hipMemsetAsync(plabel_of(g), 0x7f, (size_t) npoints * sizeof(int), c->stream))) return 1;
-	hipLaunchKernelGGL(k_groups_begin, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, g->d_label, d_rows, M);
 	char *out = pin + (((size_t) M * 4 + 15) & ~(size_t) 15);
 	const GroupsHeader *h = (const GroupsHeader *) out;
 	int done = 0, batch = g->rounds_hint;
@@ -380,8 +375,8 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		if (done + batch > kMaxRounds) batch = kMaxRounds - done;
 		for (int r = done; r < done + batch; r++)
 			hipLaunchKernelGGL(k_groups_round, dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, &hdr_of(g)->changed[r],
-			                   &hdr_of(g)->status);
+			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, r == 0 ? 1 : 0,
+			                   &hdr_of(g)->changed[r], &hdr_of(g)->status);
 		done += batch;
 		// optimistically everything that follows a converged state, in the same round trip
 		if (!MDNS_HIP(hipMemsetAsync(hdr_of(g), 0, 2 * sizeof(int), c->stream))) return 1;      // the two counts
@@ -406,7 +401,7 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 	}
 	int clean = done - 1;
 	while (clean > 0 && h->changed[clean - 1] == 0) clean--;
-	g->rounds_hint = clean + 2 < 2 ? 2 : (clean + 2 > 16 ? 16 : clean + 2);
+	g->rounds_hint = clean + 1 < 2 ? 2 : (clean + 1 > 16 ? 16 : clean + 1);   // the deciding round is part of it
 	g->rounds_total += clean + 1; g->calls_total++;
 	*ncomponents = h->ncomponents;
 	const long long nd = h->ndistinct;

@@ -18,6 +18,7 @@
 // pass when an accepted point joins a shelf (k_gauss_cols_commit in mdns_like.hip).
 #include "mdns_internal.h"
 
+#include <atomic>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -171,6 +172,12 @@ struct mdns_joint {
 	// chunk clears flags + header; header onward is what the host reads)
 	int *d_flags = nullptr;
 	char *d_result = nullptr;          // = (char *) (d_flags + kFlagInts)
+	// the outcome of a commit without the likelihood row: mapped host memory the kernel writes
+	// and the host polls (JointMailbox), and the ticket counter of the workgroups
+	JointMailbox *h_box = nullptr, *h_box_dev = nullptr;
+	unsigned *d_ticket = nullptr;
+	unsigned long long box_seq = 0;
+	bool box_pending = false;          // a commit was launched whose mailbox has not been read
 	// staging of the host-pointer draw
 	double *d_params = nullptr;
 	int *d_rows = nullptr;             // inside d_params' block, behind the candidates
@@ -201,6 +208,8 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	void *bufs[] = {j->st.live, j->st.shelfL, j->st.shelfn, j->st.higher, j->d_running, j->d_Lmin, j->d_argmin_run,
 	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params};
 	for (void *b : bufs) if (b) (void) hipFree(b);
+	if (j->d_ticket) (void) hipFree(j->d_ticket);
+	if (j->h_box) (void) hipHostFree(j->h_box);
 	if (j->h_pin) (void) hipHostFree(j->h_pin);
 	delete j;
 }
@@ -228,14 +237,19 @@ extern "C" mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_c
 	    MDNS_HIP(hipMalloc((void **) &j->d_status, sizeof(int))) &&
 	    MDNS_HIP(hipMalloc((void **) &j->d_flags, res)) &&
 	    // candidates [B, 3] followed by the selection's row ids: one staging block
-	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 3 * sizeof(double) + nd * sizeof(int) + 16));
+	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 3 * sizeof(double) + nd * sizeof(int) + 16)) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_ticket, sizeof(unsigned))) &&
+	    MDNS_HIP(hipHostMalloc((void **) &j->h_box, sizeof(JointMailbox) + ((nd + 63) / 64) * 8, hipHostMallocMapped | hipHostMallocCoherent)) &&
+	    MDNS_HIP(hipHostGetDevicePointer((void **) &j->h_box_dev, j->h_box, 0));
 	if (ok) {
+		memset(j->h_box, 0, sizeof(JointMailbox) + ((nd + 63) / 64) * 8);
 		j->d_result = (char *) (j->d_flags + kFlagInts);
 		j->st.nlive = nlive; j->st.cap = shelf_cap; j->st.ndata = s->ndata;
 		std::vector<int> all(nd);
 		for (size_t i = 0; i < nd; i++) all[i] = (int) i;
 		ok = MDNS_HIP(hipMemsetAsync(j->st.shelfn, 0, nd * sizeof(int), c->stream)) &&
 		     MDNS_HIP(hipMemsetAsync(j->d_status, 0, sizeof(int), c->stream)) &&
+		     MDNS_HIP(hipMemsetAsync(j->d_ticket, 0, sizeof(unsigned), c->stream)) &&
 		     MDNS_HIP(hipMemsetAsync(j->d_flags, 0, res, c->stream)) &&
 		     MDNS_HIP(hipMemsetAsync(j->d_argmin, 0, nd * sizeof(int), c->stream)) &&
 		     MDNS_HIP(hipMemcpyAsync(j->d_running, all.data(), nd * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -481,15 +495,53 @@ extern "C" int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M)
 	Context *c = ctx();
 	if (!c || !check_draw(j, 0, M, "mdns_joint_commit_dev")) return 1;
 	if (j->last_B == 0 || M == 0) {
-		// an empty chunk accepts nothing
+		// an empty chunk accepts nothing (no kernel runs: the mailbox is filled from here, once
+		// whatever may still be writing to it has finished)
 		static const JointHeader none = {-1, 0, 0};
-		return MDNS_HIP(hipMemcpyAsync(j->d_result, &none, sizeof none, hipMemcpyHostToDevice, c->stream)) ? 0 : 1;
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_result, &none, sizeof none, hipMemcpyHostToDevice, c->stream)) || !joint_sync(c)) return 1;
+		j->h_box->accepted = -1; j->h_box->status = 0;
+		j->h_box->seq = ++j->box_seq;
+		j->box_pending = true;
+		return 0;
 	}
 	char *base = j->d_result;
 	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
 	double *Lrow = (double *) (base + sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8);
+	const JointFinish fin = {j->d_ticket, j->h_box_dev, ++j->box_seq};
+	j->box_pending = true;
 	return launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
-	                                d_row_ids, M, j->d_flags, j->st, base, bits, Lrow) ? 0 : 1;
+	                                d_row_ids, M, j->d_flags, j->st, base, bits, Lrow, fin) ? 0 : 1;
+}
+
+// waits for the mailbox of the last commit (see JointMailbox)
+static bool joint_wait_box(mdns_joint *j, const char *who)
+{
+	Context *c = ctx();
+	if (!j->box_pending) { set_error("%s: no commit to wait for", who); return false; }
+	volatile unsigned long long *seq = &j->h_box->seq;
+	// While polling, look at the stream now and then: a failed launch shows up as an error
+	// instead of a hang.
+	for (unsigned spin = 0; *seq != j->box_seq; spin++) {
+		if ((spin & 1023) != 1023) continue;
+		const hipError_t e = hipStreamQuery(c->stream);
+		if (e == hipErrorNotReady) continue;
+		if (e != hipSuccess) { set_error("%s: the commit failed: %s", who, hipGetErrorString(e)); return false; }
+		if (*seq != j->box_seq) { set_error("%s: the commit finished without an outcome", who); return false; }
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	j->box_pending = false;
+	return true;
+}
+
+extern "C" int mdns_joint_fetch(mdns_joint *j, int M, int *accepted, unsigned long long *fillbits)
+{
+	if (!ctx() || !j || !accepted) return 1;
+	if (M < 0 || M > j->ndata) { set_error("mdns_joint_fetch: M=%d", M); return 1; }
+	if (!joint_wait_box(j, "mdns_joint_fetch")) return 1;
+	if (j->h_box->status) { set_error("mdns_joint_fetch: a shelf overflowed its capacity %d (mdns_joint_reserve)", j->cap); return 1; }
+	*accepted = j->h_box->accepted;
+	if (fillbits && j->h_box->accepted >= 0) memcpy(fillbits, (const void *) j->h_box->bits, (size_t) ((M + 63) / 64) * 8);
+	return 0;
 }
 
 // host-pointer halves of the draw: `score` stages candidates and selection and leaves the accept
@@ -533,6 +585,15 @@ static int joint_commit_and_fetch(mdns_joint *j, int *accepted, double *Lrow, un
 	if (!c || !j) return 1;
 	const int M = j->staged_M;
 	if (mdns_joint_commit_dev(j, j->staged_rows ? j->d_rows : nullptr, M) != 0) return 1;
+	if (!Lrow) {
+		// no likelihood row wanted: the kernel leaves {accepted, status, fill words} in mapped host
+		// memory -- no copy, no stream synchronisation
+		if (!joint_wait_box(j, who)) return 1;
+		if (j->h_box->status) { set_error("%s: a shelf overflowed its capacity %d (mdns_joint_reserve)", who, j->cap); return 1; }
+		*accepted = j->h_box->accepted;
+		if (fillbits && j->h_box->accepted >= 0) memcpy(fillbits, (const void *) j->h_box->bits, (size_t) ((M + 63) / 64) * 8);
+		return 0;
+	}
 	// the header says whether the rest matters, but one copy of at most 80 KB costs less than a
 	// second round trip; a caller that does not ask for the likelihood row gets header + bits
 	const size_t out_bytes = Lrow ? result_bytes(M) : sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8;
