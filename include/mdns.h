@@ -301,8 +301,8 @@ int *mdns_joint_flags_dev(mdns_joint *j);
 int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M);
 const void *mdns_joint_result_dev(mdns_joint *j);
 size_t mdns_joint_result_bytes(int M);
-/* The outcome of the last mdns_joint_commit_dev without a copy: the commit kernel also leaves
- * {accepted, status, fill words} in host memory mapped into the device, `seq` last; this call
+/* The outcome of the last mdns_joint_commit_dev without a copy: a kernel behind the commit pass
+ * leaves {accepted, status, fill words} in host memory mapped into the device, `seq` last; this call
  * polls for it (no stream synchronisation) and hands over *accepted and, when a candidate was
  * accepted, fillbits uint64[ceil(M/64)] (may be NULL).  M as passed to the commit. */
 int mdns_joint_fetch(mdns_joint *j, int M, int *accepted, unsigned long long *fillbits);

@@ -86,15 +86,6 @@ struct JointArrays {
 };
 // what a chunk of a constrained draw leaves for the host (mdns.h, mdns_joint_commit_dev)
 struct JointHeader { int accepted; int status; long long pad; };
-// The same outcome without the likelihood row, in mapped host memory: the commit pass writes the
-// fill words there as it produces them and the LAST workgroup to finish adds {accepted, status}
-// and, last of all, `seq` -- the host polls for it instead of copying and synchronising.
-struct JointMailbox { unsigned long long seq; int accepted; int status; unsigned long long bits[1]; /* ceil(M/64) words */ };
-struct JointFinish {
-	unsigned *ticket;              // device; zero outside a launch
-	JointMailbox *box;             // device address of the mapped block (nullptr: no mailbox)
-	unsigned long long seq;        // the value `seq` takes for this commit
-};
 // accept test fused into the lane kernel: flags[b] = 1 when candidate b beats a threshold
 bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
@@ -102,8 +93,7 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 // first flagged candidate: its likelihood row, fill bits, shelf appends, new thresholds
 bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M, const int *d_flags,
-                              const JointArrays &st, void *d_header, unsigned long long *d_fillbits, double *d_Lrow,
-                              const JointFinish &fin);
+                              const JointArrays &st, void *d_header, unsigned long long *d_fillbits, double *d_Lrow);
 bool launch_gauss_cols(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                        double scale, const int *d_rows, int M, double *d_out);
 bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B,

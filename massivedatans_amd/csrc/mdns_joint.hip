@@ -149,6 +149,29 @@ __global__ __launch_bounds__(kBlock) void k_joint_undo_advance(JointArrays st, c
 	st.shelfn[d] = 0;
 }
 
+// What a commit leaves for a caller that does not want the likelihood row, in host memory
+// mapped into the device: the host polls `seq` instead of copying and synchronising.
+struct JointMailbox { unsigned long long seq; int accepted; int status; unsigned long long bits[1]; /* ceil(M/64) words */ };
+
+// Runs right behind the commit pass (stream order makes its results visible): one workgroup
+// copies {accepted, status} and the fill words into the mapped block and writes `seq` last.
+// (Doing this in the commit kernel itself -- last workgroup to finish -- needs a device- or
+// system-scope fence in every workgroup, i.e. an L2 write-back each: 16 -> 32 us, measured.)
+__global__ __launch_bounds__(kBlock) void k_joint_publish(const JointHeader *__restrict__ header,
+                                                          const unsigned long long *__restrict__ fillbits, int nwords,
+                                                          JointMailbox *__restrict__ box, unsigned long long seq)
+{
+	const int accepted = header->accepted;
+	if (accepted >= 0)
+		for (int w = threadIdx.x; w < nwords; w += kBlock) box->bits[w] = fillbits[w];
+	__threadfence_system();
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	box->accepted = accepted;
+	box->status = header->status;
+	__hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 __global__ void k_joint_fill(double *__restrict__ p, size_t n, double value)
 {
 	for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t) gridDim.x * blockDim.x) p[e] = value;
@@ -172,10 +195,9 @@ struct mdns_joint {
 	// chunk clears flags + header; header onward is what the host reads)
 	int *d_flags = nullptr;
 	char *d_result = nullptr;          // = (char *) (d_flags + kFlagInts)
-	// the outcome of a commit without the likelihood row: mapped host memory the kernel writes
-	// and the host polls (JointMailbox), and the ticket counter of the workgroups
+	// the outcome of a commit without the likelihood row: mapped host memory a kernel behind the
+	// commit pass writes and the host polls (JointMailbox)
 	JointMailbox *h_box = nullptr, *h_box_dev = nullptr;
-	unsigned *d_ticket = nullptr;
 	unsigned long long box_seq = 0;
 	bool box_pending = false;          // a commit was launched whose mailbox has not been read
 	// staging of the host-pointer draw
@@ -208,7 +230,6 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	void *bufs[] = {j->st.live, j->st.shelfL, j->st.shelfn, j->st.higher, j->d_running, j->d_Lmin, j->d_argmin_run,
 	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params};
 	for (void *b : bufs) if (b) (void) hipFree(b);
-	if (j->d_ticket) (void) hipFree(j->d_ticket);
 	if (j->h_box) (void) hipHostFree(j->h_box);
 	if (j->h_pin) (void) hipHostFree(j->h_pin);
 	delete j;
@@ -238,7 +259,6 @@ extern "C" mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_c
 	    MDNS_HIP(hipMalloc((void **) &j->d_flags, res)) &&
 	    // candidates [B, 3] followed by the selection's row ids: one staging block
 	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 3 * sizeof(double) + nd * sizeof(int) + 16)) &&
-	    MDNS_HIP(hipMalloc((void **) &j->d_ticket, sizeof(unsigned))) &&
 	    MDNS_HIP(hipHostMalloc((void **) &j->h_box, sizeof(JointMailbox) + ((nd + 63) / 64) * 8, hipHostMallocMapped | hipHostMallocCoherent)) &&
 	    MDNS_HIP(hipHostGetDevicePointer((void **) &j->h_box_dev, j->h_box, 0));
 	if (ok) {
@@ -249,7 +269,6 @@ extern "C" mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_c
 		for (size_t i = 0; i < nd; i++) all[i] = (int) i;
 		ok = MDNS_HIP(hipMemsetAsync(j->st.shelfn, 0, nd * sizeof(int), c->stream)) &&
 		     MDNS_HIP(hipMemsetAsync(j->d_status, 0, sizeof(int), c->stream)) &&
-		     MDNS_HIP(hipMemsetAsync(j->d_ticket, 0, sizeof(unsigned), c->stream)) &&
 		     MDNS_HIP(hipMemsetAsync(j->d_flags, 0, res, c->stream)) &&
 		     MDNS_HIP(hipMemsetAsync(j->d_argmin, 0, nd * sizeof(int), c->stream)) &&
 		     MDNS_HIP(hipMemcpyAsync(j->d_running, all.data(), nd * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -507,10 +526,12 @@ extern "C" int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M)
 	char *base = j->d_result;
 	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
 	double *Lrow = (double *) (base + sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8);
-	const JointFinish fin = {j->d_ticket, j->h_box_dev, ++j->box_seq};
+	if (!launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
+	                              d_row_ids, M, j->d_flags, j->st, base, bits, Lrow)) return 1;
+	hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
+	                   j->h_box_dev, ++j->box_seq);
 	j->box_pending = true;
-	return launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
-	                                d_row_ids, M, j->d_flags, j->st, base, bits, Lrow, fin) ? 0 : 1;
+	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
 }
 
 // waits for the mailbox of the last commit (see JointMailbox)

@@ -573,8 +573,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
     const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int mstride, int B,
     double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
     int ntiles, int nq_xcd, int cu_slots, const int *__restrict__ flags, JointArrays st,
-    JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits, double *__restrict__ Lrow,
-    JointFinish fin)
+    JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits, double *__restrict__ Lrow)
 {
 	// all LDS in the dynamic region (a static variable in front of it would leave the template
 	// column 4 bytes off its 8-byte alignment): [nxp] template doubles, then one int
@@ -587,14 +586,14 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
 	__syncthreads();
 	const int bstar = s_first;
 	if (blockIdx.x == 0 && threadIdx.x == 0) header->accepted = bstar < B ? bstar : -1;
+	if (bstar >= B) return;
 	const int lane = threadIdx.x & 63;
-	int tile = 0, bt_unused;
-	// (cols_item is false for whole workgroups only: the barriers below are reached together)
-	const bool work = bstar < B && cols_item(ntiles, INT_MAX, nq_xcd, 1, cu_slots, tile, bt_unused);
+	int tile, bt_unused;
+	if (!cols_item(ntiles, INT_MAX, nq_xcd, 1, cu_slots, tile, bt_unused)) return;      // whole workgroups only
 	// templates are laid out [candidate tile][channel][mstride candidates]: the accepted
 	// candidate's column goes to LDS
-	if (work) stage_templates(tpl, model_t + (size_t) (bstar / mstride) * nxp * mstride + bstar % mstride, nxp, mstride);
-	if (work && tile < ntiles) {
+	stage_templates(tpl, model_t + (size_t) (bstar / mstride) * nxp * mstride + bstar % mstride, nxp, mstride);
+	if (tile >= ntiles) return;
 	int k[1];
 	double acc[1][1];
 	cols_accumulate_deep<1, 4>(YT, nxp, tpl, rows, M, tile, lane, k[0], acc[0]);
@@ -639,23 +638,7 @@ __global__ __launch_bounds__(kBlock) void k_gauss_cols_commit(
 		}
 	}
 	const unsigned long long word = __ballot(beats);
-	if (lane == 0) {
-		fillbits[tile] = word;
-		if (fin.box) fin.box->bits[tile] = word;
-	}
-	}
-	if (!fin.box) return;
-	// The workgroup that finishes last publishes the outcome: every workgroup makes its words
-	// (and a shelf-overflow bit) visible, then takes a ticket.
-	__threadfence_system();
-	__syncthreads();
-	if (threadIdx.x != 0) return;
-	if (atomicAdd(fin.ticket, 1u) != gridDim.x - 1) return;
-	__threadfence();
-	*fin.ticket = 0;
-	fin.box->accepted = bstar < B ? bstar : -1;
-	fin.box->status = __hip_atomic_load(&header->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	__hip_atomic_store(&fin.box->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	if (lane == 0) fillbits[tile] = word;
 }
 
 // any nx: channels walked in chunks of 128, templates re-read per chunk (L2 resident)
@@ -1031,8 +1014,7 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 
 bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M, const int *d_flags,
-                              const JointArrays &st, void *d_header, unsigned long long *d_fillbits, double *d_Lrow,
-                              const JointFinish &fin)
+                              const JointArrays &st, void *d_header, unsigned long long *d_fillbits, double *d_Lrow)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
@@ -1040,7 +1022,7 @@ bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const d
 	const int blocks = cols_grid(c, ntiles, 1, nq_xcd, cu_slots);
 	hipLaunchKernelGGL(k_gauss_cols_commit, dim3(blocks), dim3(kBlock), (size_t) (cols_nx(s->nx) + 2) * sizeof(double), c->stream,
 	                   d_yT, cols_nx(s->nx), d_model_t, mstride, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, cu_slots,
-	                   d_flags, st, (JointHeader *) d_header, d_fillbits, d_Lrow, fin);
+	                   d_flags, st, (JointHeader *) d_header, d_fillbits, d_Lrow);
 	return launched("k_gauss_cols_commit");
 }
 
