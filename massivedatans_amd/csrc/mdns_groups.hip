@@ -29,6 +29,7 @@
 // the next round by the edge that still sees the difference.
 #include "mdns_internal.h"
 
+#include <atomic>
 #include <cstring>
 
 namespace mdns {
@@ -40,6 +41,9 @@ static constexpr int kUnclaimed = 0x7f7f7f7f;         // memset pattern: above e
 // what a components call copies back first: counts, failure bits (1 = id out of range, 2 = bad
 // replacement) and, per round, whether it still moved a label
 struct GroupsHeader { int ncomponents; int ndistinct; int status; int pad; int changed[kMaxRounds]; };
+// the same and the list of distinct ids in host memory mapped into the device: written by the
+// last kernel of a call (k_groups_compact), `seq` last; the host polls instead of copying
+struct GroupsBox { unsigned long long seq; unsigned long long pad; GroupsHeader header; int distinct[1]; };
 
 // Device-scope relaxed accesses: values move between the waves of one kernel.
 __device__ __forceinline__ int load_relaxed(const int *p)
@@ -142,7 +146,8 @@ __global__ __launch_bounds__(kBlock) void k_groups_touched(const int *__restrict
 // (multi_nested_sampler.py:279) -- by ONE workgroup: popcounts of contiguous runs of words, a scan
 // over the 1024 run totals, then every thread writes out its run.
 __global__ __launch_bounds__(1024) void k_groups_compact(const unsigned long long *__restrict__ touched, long long nwords,
-                                                         int *__restrict__ distinct, GroupsHeader *__restrict__ header)
+                                                         GroupsHeader *__restrict__ header, GroupsBox *__restrict__ box,
+                                                         unsigned long long seq)
 {
 	__shared__ int wave_total[16];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -161,14 +166,26 @@ __global__ __launch_bounds__(1024) void k_groups_compact(const unsigned long lon
 	int before = 0;
 	for (int k = 0; k < wave; k++) before += wave_total[k];
 	int at = before + incl - mine;
+	// the list goes straight to the host: `box` is host memory mapped into the device
 	for (long long w = w0; w < w1; w++) {
 		unsigned long long bits = touched[w];
 		while (bits) {
-			distinct[at++] = (int) (w * 64 + __builtin_ctzll(bits));
+			box->distinct[at++] = (int) (w * 64 + __builtin_ctzll(bits));
 			bits &= bits - 1;
 		}
 	}
-	if (t == 1023) header->ndistinct = before + incl;
+	__threadfence_system();
+	__syncthreads();
+	// counts, failure bits and the rounds' flags follow, `seq` last: the host polls for it
+	if (t < kMaxRounds) box->header.changed[t] = header->changed[t];
+	if (t == 1023) {
+		box->header.ncomponents = header->ncomponents;
+		box->header.ndistinct = before + incl;
+		box->header.status = header->status;
+	}
+	__threadfence_system();
+	__syncthreads();
+	if (t == 0) __hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(kBlock) void k_groups_point_labels(const int *__restrict__ plabel, long long npoints,
@@ -203,14 +220,14 @@ struct mdns_groups {
 	int *d_rows = nullptr;             // [3 * ndata]: selection, or (rows | slots | new ids) of a replacement
 	int *d_labels = nullptr;           // [ndata] by position in the selection
 	// per id; grown with the pile of accepted points.  One block:
-	//   header | distinct ids (ascending) | touched bit map | plabel | point labels (out)
-	// -- header and the list in front, so that one copy fetches both
+	//   header | touched bit map | plabel | point labels (out)
 	char *d_points = nullptr;  long long cap_points = 0;
 	char *h_pin = nullptr;  size_t pin_bytes = 0;
+	GroupsBox *h_box = nullptr, *h_box_dev = nullptr;  long long box_cap = 0;   // room for box_cap ids
+	unsigned long long box_seq = 0;
 	bool have_ids = false;
 	int last_M = -1;  long long last_npoints = 0;      // of the last components call (-1: ids changed since)
 	int rounds_hint = 4;                               // rounds the next call launches before it looks
-	long long distinct_hint = 1024;                    // ids the next call fetches with the header
 	long long rounds_total = 0, calls_total = 0;
 };
 
@@ -218,8 +235,7 @@ static constexpr size_t kHeaderBytes = 512;            // sizeof(GroupsHeader) r
 static_assert(sizeof(GroupsHeader) <= kHeaderBytes, "header grew");
 static size_t words_of(long long npoints) { return (size_t) ((npoints + 63) / 64); }
 static GroupsHeader *hdr_of(mdns_groups *g) { return (GroupsHeader *) g->d_points; }
-static int *distinct_of(mdns_groups *g) { return (int *) (g->d_points + kHeaderBytes); }
-static unsigned long long *touched_of(mdns_groups *g) { return (unsigned long long *) (distinct_of(g) + g->cap_points); }
+static unsigned long long *touched_of(mdns_groups *g) { return (unsigned long long *) (g->d_points + kHeaderBytes); }
 static int *plabel_of(mdns_groups *g) { return (int *) (touched_of(g) + words_of(g->cap_points)); }
 static int *pout_of(mdns_groups *g) { return plabel_of(g) + g->cap_points; }
 
@@ -241,11 +257,28 @@ static bool groups_fit_points(mdns_groups *g, long long npoints)
 	long long cap = g->cap_points > 0 ? g->cap_points : 4096;
 	while (cap < npoints) cap *= 2;                                    // (a multiple of 64: the regions stay 8-byte aligned)
 	if (g->d_points) { (void) hipStreamSynchronize(c->stream); (void) hipFree(g->d_points); g->d_points = nullptr; g->cap_points = 0; }
-	const size_t bytes = kHeaderBytes + words_of(cap) * 8 + (size_t) cap * 3 * sizeof(int);
+	const size_t bytes = kHeaderBytes + words_of(cap) * 8 + (size_t) cap * 2 * sizeof(int);
 	if (!MDNS_HIP(hipMalloc((void **) &g->d_points, bytes))) return false;
 	g->cap_points = cap;
 	g->last_M = -1;
 	return MDNS_HIP(hipMemsetAsync(g->d_points, 0, kHeaderBytes, c->stream));
+}
+
+// mapped host block with room for `ids` distinct ids
+static bool groups_fit_box(mdns_groups *g, long long ids)
+{
+	if (g->h_box && ids <= g->box_cap) return true;
+	Context *c = ctx();
+	long long cap = g->box_cap > 0 ? g->box_cap : 4096;
+	while (cap < ids) cap *= 2;
+	if (g->h_box) { (void) hipStreamSynchronize(c->stream); (void) hipHostFree(g->h_box); g->h_box = nullptr; g->box_cap = 0; }
+	const size_t bytes = sizeof(GroupsBox) + (size_t) cap * sizeof(int);
+	if (!MDNS_HIP(hipHostMalloc((void **) &g->h_box, bytes, hipHostMallocMapped | hipHostMallocCoherent)) ||
+	    !MDNS_HIP(hipHostGetDevicePointer((void **) &g->h_box_dev, g->h_box, 0))) return false;
+	memset(g->h_box, 0, sizeof(GroupsBox));
+	g->h_box->seq = g->box_seq;
+	g->box_cap = cap;
+	return true;
 }
 
 extern "C" void mdns_groups_destroy(mdns_groups *g)
@@ -253,6 +286,7 @@ extern "C" void mdns_groups_destroy(mdns_groups *g)
 	if (!g) return;
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
+	if (g->h_box) (void) hipHostFree(g->h_box);
 	void *bufs[] = {g->d_idsT, g->d_tmp, g->d_label, g->d_rows, g->d_labels, g->d_points};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	if (g->h_pin) (void) hipHostFree(g->h_pin);
@@ -354,13 +388,13 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
 	}
 	const size_t nw = words_of(npoints);
-	// the most this selection can hold, and how much of the list travels with the header
-	long long most = (long long) M * g->nlive < npoints ? (long long) M * g->nlive : npoints;
-	long long guess = distinct ? (g->distinct_hint < most ? g->distinct_hint : most) : 0;
-	char *pin = groups_pin(g, (size_t) M * 4 + 16 + kHeaderBytes + (size_t) most * 4);
+	// the most this selection can hold
+	const long long most = (long long) M * g->nlive < npoints ? (long long) M * g->nlive : npoints;
+	if (!groups_fit_box(g, most)) return 1;
+	char *pin = groups_pin(g, (size_t) M * 4);
 	if (!pin) return 1;
-	if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;             // the staging block is free again
 	if (rows) {
+		if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;         // the staging block is free again
 		memcpy(pin, rows, (size_t) M * 4);
 		if (!MDNS_HIP(hipMemcpyAsync(g->d_rows, pin, (size_t) M * 4, hipMemcpyHostToDevice, c->stream))) return 1;
 	}
@@ -368,8 +402,7 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 	// round flags and counts cleared (not the failure bits), no live point labelled
 	if (!MDNS_HIP(hipMemsetAsync(&hdr_of(g)->changed[0], 0, sizeof(int) * kMaxRounds, c->stream)) ||
 	    !MDNS_HIP(hipMemsetAsync(plabel_of(g), 0x7f, (size_t) npoints * sizeof(int), c->stream))) return 1;
-	char *out = pin + (((size_t) M * 4 + 15) & ~(size_t) 15);
-	const GroupsHeader *h = (const GroupsHeader *) out;
+	const GroupsHeader *h = &g->h_box->header;
 	int done = 0, batch = g->rounds_hint;
 	while (true) {
 		if (done + batch > kMaxRounds) batch = kMaxRounds - done;
@@ -384,10 +417,20 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		                   g->d_label, d_rows, M, g->d_labels, hdr_of(g));
 		hipLaunchKernelGGL(k_groups_touched, dim3((unsigned) ((npoints + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
 		                   plabel_of(g), npoints, touched_of(g));
-		hipLaunchKernelGGL(k_groups_compact, dim3(1), dim3(1024), 0, c->stream, touched_of(g), (long long) nw, distinct_of(g), hdr_of(g));
+		hipLaunchKernelGGL(k_groups_compact, dim3(1), dim3(1024), 0, c->stream, touched_of(g), (long long) nw, hdr_of(g),
+		                   g->h_box_dev, ++g->box_seq);
 		if (!MDNS_HIP(hipGetLastError())) return 1;
-		if (!MDNS_HIP(hipMemcpyAsync(out, g->d_points, kHeaderBytes + (size_t) guess * 4, hipMemcpyDeviceToHost, c->stream)) ||
-		    !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
+		// counts, flags and the list arrive in mapped host memory: poll for `seq` (looking at the
+		// stream now and then: a failed launch shows up as an error instead of a hang)
+		volatile unsigned long long *seq = &g->h_box->seq;
+		for (unsigned spin = 0; *seq != g->box_seq; spin++) {
+			if ((spin & 1023) != 1023) continue;
+			const hipError_t e = hipStreamQuery(c->stream);
+			if (e == hipErrorNotReady) continue;
+			if (e != hipSuccess) { set_error("mdns_groups_components: %s", hipGetErrorString(e)); return 1; }
+			if (*seq != g->box_seq) { set_error("mdns_groups_components: finished without a result"); return 1; }
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
 		if (h->status) {
 			const int status = h->status;
 			(void) hipMemsetAsync(&hdr_of(g)->status, 0, sizeof(int), c->stream);
@@ -406,14 +449,9 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 	*ncomponents = h->ncomponents;
 	const long long nd = h->ndistinct;
 	if (ndistinct) *ndistinct = nd;
-	g->distinct_hint = nd + nd / 4 + 256;
 	if (distinct) {
 		if (nd > cap) { set_error("mdns_groups_components: %lld distinct ids, room for %lld", nd, cap); return 1; }
-		if (nd > guess) {                                            // the rest of the list
-			if (!MDNS_HIP(hipMemcpyAsync(out + kHeaderBytes + (size_t) guess * 4, distinct_of(g) + guess, (size_t) (nd - guess) * 4,
-			                             hipMemcpyDeviceToHost, c->stream)) || !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
-		}
-		memcpy(distinct, out + kHeaderBytes, (size_t) nd * 4);
+		memcpy(distinct, (const void *) g->h_box->distinct, (size_t) nd * 4);
 	}
 	if (touched) {
 		if (!MDNS_HIP(hipMemcpyAsync(touched, touched_of(g), nw * 8, hipMemcpyDeviceToHost, c->stream)) ||
