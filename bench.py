@@ -269,9 +269,31 @@ def setup_dist(args):
         if os.environ.get("MDNS_BENCH_COLLECTIVES", "rccl") != "torch":
             from massivedatans_amd import rccl
             try:
-                COMM["rccl"], COMM["direct"] = rccl, rccl.from_torch_distributed()
+                comm = rccl.from_torch_distributed()
             except (rccl.RcclError, OSError, AttributeError) as e:
+                comm = None
                 print("bench.py: direct RCCL unavailable (%s), using torch.distributed" % e, file=sys.stderr)
+            # one tiny MAX all-reduce and one all-gather, checked on every rank; the direct path is
+            # used only if they came out right everywhere (decided through torch.distributed)
+            ok = 0
+            if comm is not None:
+                try:
+                    a = torch.full((8,), rank + 1, dtype=torch.int32, device="cuda")
+                    b = torch.full((3,), 7 * rank + 5, dtype=torch.int64, device="cuda")
+                    g = torch.zeros(3 * world, dtype=torch.int64, device="cuda")
+                    comm.all_reduce(a.data_ptr(), a.data_ptr(), 8, rccl.INT32, rccl.MAX, bench_stream.cuda_stream)
+                    comm.all_gather(b.data_ptr(), g.data_ptr(), 3, rccl.INT64, bench_stream.cuda_stream)
+                    bench_stream.synchronize()
+                    want = torch.arange(world, dtype=torch.int64).repeat_interleave(3) * 7 + 5
+                    ok = int(bool((a == world).all().item()) and bool((g.cpu() == want).all().item()))
+                except rccl.RcclError as e:
+                    print("bench.py: direct RCCL self-test failed (%s)" % e, file=sys.stderr)
+            agree = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 1:
+                COMM["rccl"], COMM["direct"] = rccl, comm
+            elif rank == 0:
+                print("bench.py: direct RCCL self-test not passed on every rank, using torch.distributed", file=sys.stderr)
     return world, rank, use_dist, torch, dist, lib, _lib
 
 
