@@ -147,7 +147,7 @@ def test_bad_arguments_are_refused():
     dg.close()
 
 
-@pytest.mark.parametrize("key", ["horns-graph_300_40_0", "nothing-graph_2000_100_0", "horns-graph_1000_100_600"])
+@pytest.mark.parametrize("key", ["horns-graph_100_40_400", "nothing-graph_100_40_400", "horns-graph_300_40_300"])
 def test_graph_variant_on_the_gpu_matches_the_cpu_path(key):
     """USE_GRAPH=1 (the reference's default grouping) end to end: the GPU run -- components and
     distinct ids from the device (csrc/mdns_groups.hip), draws decided on the device -- against
