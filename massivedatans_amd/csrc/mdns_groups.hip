@@ -21,12 +21,17 @@
 // component carries its lowest index" -- reached after a few rounds (the graphs are dense: a
 // live point is shared by ~100 data sets), detected by a round that changes nothing.
 //
-// No read-modify-write atomics: on this chip a million atomicMin on ~10^4 addresses take 70-100 us
-// and ten thousand on ONE address 3 ms (measured; the hot case is real -- early in a run every
-// data set holds the same initial points), and a lock-free union-find spends milliseconds
-// chasing and halving paths through the few hundred hot roots.  Relaxed device-scope loads and
-// stores cost 8 us per million.  A store that loses a race against a higher label is redone in
-// the next round by the edge that still sees the difference.
+// No read-modify-write atomics and no device-scope traffic in the rounds.  Measured on this chip:
+// a million atomicMin on ~10^4 addresses take 70-100 us and ten thousand on ONE address 3 ms
+// (the hot case is real -- early in a run every data set holds the same initial points); a
+// lock-free union-find spends milliseconds chasing and halving paths through a few hundred hot
+// roots; device-scope (sc1) stores cost 250 us per million.  So labels are read and written with
+// PLAIN cached accesses: an XCD sees its own stores at once and the others' at the next kernel
+// boundary.  That only costs rounds, never correctness: a store that loses a race against a
+// higher label is redone in the next round by the wave that still sees the difference, and the
+// deciding round starts from coherent memory (kernel boundary) and, storing nothing, has read a
+// consistent state.  Only the per-round "something moved" flag is a device-scope store, at
+// most one per wave.
 #include "mdns_internal.h"
 
 #include <atomic>
@@ -38,14 +43,14 @@ static constexpr int kBlock = 256;
 static constexpr int kMaxRounds = 64;                 // rounds whose "changed" flag the header holds
 static constexpr int kUnclaimed = 0x7f7f7f7f;         // memset pattern: above every data-set index
 
-// what a components call copies back first: counts, failure bits (1 = id out of range, 2 = bad
-// replacement) and, per round, whether it still moved a label
+// counts, failure bits (1 = id out of range, 2 = bad replacement) and, per round, whether it
+// still moved a label
 struct GroupsHeader { int ncomponents; int ndistinct; int status; int pad; int changed[kMaxRounds]; };
 // the same and the list of distinct ids in host memory mapped into the device: written by the
 // last kernel of a call (k_groups_compact), `seq` last; the host polls instead of copying
 struct GroupsBox { unsigned long long seq; unsigned long long pad; GroupsHeader header; int distinct[1]; };
 
-// Device-scope relaxed accesses: values move between the waves of one kernel.
+// Device-scope relaxed accesses (the rounds' "moved" flag).
 __device__ __forceinline__ int load_relaxed(const int *p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
