@@ -119,15 +119,15 @@ from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
 d = gen.horns(300)
 backend = parallel.ShardedGaussLine(d["x"], d["y"], lambda x, y: GaussLineSpectra(x, y, noise_level=0.01))
 out = {}
-for fused in (False, True):
+for name, fused, use_graph in (("classic", False, False), ("fused", True, False), ("graph", True, True)):
     problem = sample.GaussLineProblem(d["x"], d["y"], backend=backend)
-    sampler = sample.build_sampler(problem, nlive_points=40, use_graph=False, seed=1, batched=True, fused=fused)
+    sampler = sample.build_sampler(problem, nlive_points=40, use_graph=use_graph, seed=1, batched=True, fused=fused)
     with np.errstate(all="ignore"):
         res = multi_nested_integrator(tolerance=0.5, multi_sampler=sampler, min_samples=0, max_samples=120)
-    out["fused" if fused else "classic"] = dict(ndraws=int(sampler.ndraws), npoints=int(len(sampler.pointpile)),
-                                                pile=np.ascontiguousarray(sampler.pointpile).tobytes().hex()[:64],
-                                                logZ=[float(v) for v in res["logZ"][:5]],
-                                                joint=type(sampler.joint).__name__)
+    out[name] = dict(ndraws=int(sampler.ndraws), npoints=int(len(sampler.pointpile)),
+                     pile=np.ascontiguousarray(sampler.pointpile).tobytes().hex()[:64],
+                     logZ=[float(v) for v in res["logZ"][:5]], joint=type(sampler.joint).__name__,
+                     device_groups=sampler._dgroups is not None and sampler._dgroups.ncalls > 0)
 print("RESULT " + json.dumps(out))
 dist.destroy_process_group()
 '''
@@ -166,6 +166,13 @@ def test_two_ranks_share_the_gpu_with_hip_kernels(tmp_path):
     assert sampler.ndraws == res[0]["fused"]["ndraws"] and len(sampler.pointpile) == res[0]["fused"]["npoints"]
     assert np.ascontiguousarray(sampler.pointpile).tobytes().hex()[:64] == res[0]["fused"]["pile"]
     assert np.allclose(results["logZ"][:5], res[0]["fused"]["logZ"], rtol=0, atol=1e-9)
+    # the reference's default grouping, components computed on the device by every rank
+    assert res[0]["graph"]["device_groups"] and res[0]["graph"]["joint"] == "ShardedJointState"
+    with np.errstate(all="ignore"):
+        results, sampler, _, _ = sample.run(d["x"], d["y"], nlive_points=40, max_samples=120, use_graph=True)
+    assert sampler.ndraws == res[0]["graph"]["ndraws"] and len(sampler.pointpile) == res[0]["graph"]["npoints"]
+    assert np.ascontiguousarray(sampler.pointpile).tobytes().hex()[:64] == res[0]["graph"]["pile"]
+    assert np.allclose(results["logZ"][:5], res[0]["graph"]["logZ"], rtol=0, atol=1e-9)
 
 
 def test_rccl_binding_matches_the_header():
