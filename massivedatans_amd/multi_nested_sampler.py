@@ -145,6 +145,7 @@ class MultiNestedSampler(object):
         #: (massivedatans_amd.grouping, csrc/mdns_groups.hip) instead of the host walk
         self._device_groups_wanted = bool(device_groups)
         self._dgroups = None
+        self._last_selection = None         # (mask object, its members, their original indices) of the last grouping
         self.point_data_map = None          # point id -> set of data sets holding it (lazy)
         #: likelihood evaluations = (candidate, data set) pairs actually scored
         self.nevals = 0
@@ -516,9 +517,11 @@ class MultiNestedSampler(object):
             # (the reference's two shortcuts, :283-297, name cases that are connected: the
             # components say the same)
             running = self._running_indices()
-            rows = None if len(selected) == dg.ndata else running[selected]
+            real_rows = running[selected]
+            rows = None if len(selected) == dg.ndata else real_rows
             ncomp, ids = dg.components(rows, len(self.pointpile))
             if ncomp == 1:
+                self._last_selection = (data_mask, selected, real_rows)      # for _fill_shelves
                 yield data_mask, ids
                 return
             labels, point_labels = dg.labels()
@@ -616,6 +619,7 @@ class MultiNestedSampler(object):
         passes = 0
         while True:
             passes += 1
+            self._last_selection = None
             empty = self._shelves.empty()
             if not empty.any():
                 return
@@ -643,7 +647,12 @@ class MultiNestedSampler(object):
             rebuilding_draw = focussed or len(groups) > 1
 
             for joint_data_mask, joint_live_pointsp in groups:
-                joint_indices = numpy.where(joint_data_mask)[0]
+                # (the grouping may have listed the members of the mask it handed back already)
+                known = self._last_selection
+                if known is not None and known[0] is joint_data_mask:
+                    joint_indices, real_rows = known[1], known[2]
+                else:
+                    joint_indices, real_rows = numpy.where(joint_data_mask)[0], None
                 njoints = len(joint_indices)
                 firstd = joint_indices[0]
                 max_draws = 100000 if (njoints == 1 and self._shelves.n[firstd] == 0) else 1000
@@ -654,7 +663,9 @@ class MultiNestedSampler(object):
                 if njoints == 1:
                     draw = self.individual_draw_constrained(real_indices[firstd], self.global_iter, sampler=self)
                 elif rebuilding_draw:
-                    draw = self.draw_constrained(real_indices[joint_indices], self.real_data_mask_all,
+                    if real_rows is None:
+                        real_rows = real_indices[joint_indices]
+                    draw = self.draw_constrained(real_rows, self.real_data_mask_all,
                                                  joint_live_pointsp, self.global_iter)
                 else:
                     draw = self.superset_draw_constrained
@@ -663,7 +674,10 @@ class MultiNestedSampler(object):
                 if self.joint is not None:
                     # the whole chunk of proposed candidates goes to the joint state, which
                     # answers with the first acceptable one (thresholds and accept test there)
-                    rows = None if njoints == len(real_indices) == self.joint.ndata else real_indices[joint_indices]
+                    if njoints == len(real_indices) == self.joint.ndata:
+                        rows = None
+                    else:
+                        rows = real_rows if real_rows is not None else real_indices[joint_indices]
                     last = {}
                     extra['draw_batch'] = lambda us, hint, rows=rows, last=last: self._draw_batch(us, rows, last, hint)
                 elif self.multi_loglikelihood_batch is not None:

@@ -158,6 +158,7 @@ def _fake_sampler(lp, npoints, nlive):
     s._walk_stale = True
     s._device_groups_wanted = False
     s._dgroups = None
+    s._last_selection = None
     s._real_indices = None
     s.real_data_mask_all = np.ones(lp.shape[1], dtype=bool)
     s._refcount = np.bincount(lp.ravel(), minlength=npoints)
