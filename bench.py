@@ -405,7 +405,7 @@ def bench_gauss(args):
     if not region:
         raise _lib.MdnsError(_lib.last_error())
 
-    def step():
+    def step(with_row=False):
         if state["advanced"]:
             _lib.check(lib.mdns_joint_undo_advance_dev(joint), "undo advance")
         if direct is not None:
@@ -425,7 +425,9 @@ def bench_gauss(args):
             direct.all_reduce(d_flags, d_flags, B, rccl.INT32, rccl.MAX, stream)
         elif use_dist:
             dist.all_reduce(t_flags, op=dist.ReduceOp.MAX)
-        _lib.check(lib.mdns_joint_commit_dev(joint, None, nd), "commit")
+        # (the sampler needs the index and the fill bits of a draw, not its likelihood row: the
+        # commit takes both from what the accept pass kept of the candidates it flagged)
+        _lib.check((lib.mdns_joint_commit_dev if with_row else lib.mdns_joint_commit_bits_dev)(joint, None, nd), "commit")
         _lib.check(lib.mdns_joint_advance_dev(joint), "advance")
         state["advanced"] = True
         # the host bookkeeping of every rank needs the fill bits of all data sets
@@ -470,6 +472,12 @@ def bench_gauss(args):
     fence()
 
     # sanity: the timed steps decided what they were built to decide, with the right numbers
+    # (one more step that also writes the likelihood row, which is recomputed for the check)
+    polled_accepted, polled_fill = accepted_now.value, fill_now.copy()
+    step(with_row=True)
+    fence()
+    assert accepted_now.value == polled_accepted and np.array_equal(fill_now, polled_fill), \
+        "bench draw: the commit with and without the likelihood row disagree"
     _lib.check(lib.mdns_d2h(_lib.ptr(result), d_result, nres), "result")       # now with the likelihood row
     live_now = np.empty((NLIVE, nd))
     _lib.check(lib.mdns_joint_undo_advance_dev(joint), "undo advance")

@@ -299,6 +299,11 @@ int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B, double no
                          const int *d_row_ids, int M);
 int *mdns_joint_flags_dev(mdns_joint *j);
 int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M);
+/* The same without the likelihood row (Lrow in the result buffer is left as it was): who beats its
+ * threshold and with which likelihood is taken from what the score pass kept of the candidates it
+ * flagged, nothing is computed again.  This is what mdns_joint_draw_gauss / mdns_joint_commit do
+ * when called with Lrow == NULL. */
+int mdns_joint_commit_bits_dev(mdns_joint *j, const int *d_row_ids, int M);
 const void *mdns_joint_result_dev(mdns_joint *j);
 size_t mdns_joint_result_bytes(int M);
 /* The outcome of the last mdns_joint_commit_dev without a copy: a kernel behind the commit pass

@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "mdns_joint_create", "mdns_joint_destroy", "mdns_joint_init_gauss", "mdns_joint_set_live",
     "mdns_joint_get_live", "mdns_joint_set_running", "mdns_joint_prepare", "mdns_joint_keep_words",
     "mdns_joint_advance", "mdns_joint_reserve", "mdns_joint_shelf_cap", "mdns_joint_draw_gauss", "mdns_joint_score", "mdns_joint_commit",
-    "mdns_joint_get_thresholds", "mdns_joint_score_dev", "mdns_joint_flags_dev", "mdns_joint_commit_dev",
+    "mdns_joint_get_thresholds", "mdns_joint_score_dev", "mdns_joint_flags_dev", "mdns_joint_commit_dev", "mdns_joint_commit_bits_dev",
     "mdns_joint_result_dev", "mdns_joint_result_bytes", "mdns_joint_fetch", "mdns_joint_prepare_dev", "mdns_joint_advance_dev",
     "mdns_joint_restore_live_dev", "mdns_joint_undo_advance_dev", "mdns_joint_live_dev",
     "mdns_groups_create", "mdns_groups_destroy", "mdns_groups_set_ids", "mdns_groups_get_ids",
@@ -125,6 +125,7 @@ def _declare(lib):
         "mdns_joint_score_dev": (i, [vp, vp, i, d, vp, i]),
         "mdns_joint_flags_dev": (vp, [vp]),
         "mdns_joint_commit_dev": (i, [vp, vp, i]),
+        "mdns_joint_commit_bits_dev": (i, [vp, vp, i]),
         "mdns_joint_result_dev": (vp, [vp]),
         "mdns_joint_result_bytes": (sz, [i]),
         "mdns_joint_fetch": (i, [vp, i, vp, vp]),

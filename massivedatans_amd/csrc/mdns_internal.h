@@ -86,10 +86,23 @@ struct JointArrays {
 };
 // what a chunk of a constrained draw leaves for the host (mdns.h, mdns_joint_commit_dev)
 struct JointHeader { int accepted; int status; long long pad; };
+// What the accept pass leaves behind for the candidates it flags: per (candidate, tile of 64
+// selected spectra) in which some lane beat its threshold, the ballot word and the 64
+// likelihoods -- all a commit needs when nobody asks for the whole likelihood row.  Entries are
+// valid when their stamp is the current one (nothing is ever cleared).
+struct JointTrail {
+	int *stamp_of;                 // [candidates x tiles]      (nullptr: no trail)
+	unsigned long long *word;      // [candidates x tiles]
+	double *L;                     // [candidates x tiles][64]
+	int stamp;
+};
 // accept test fused into the lane kernel: flags[b] = 1 when candidate b beats a threshold
 bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
-                              const double *d_higher, int *d_flags);
+                              const double *d_higher, int *d_flags, const JointTrail &trail);
+// first flagged candidate from the trail of the accept pass: fill bits, shelf appends, thresholds
+bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,
+                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits);
 // first flagged candidate: its likelihood row, fill bits, shelf appends, new thresholds
 bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M, const int *d_flags,

@@ -200,6 +200,11 @@ struct mdns_joint {
 	JointMailbox *h_box = nullptr, *h_box_dev = nullptr;
 	unsigned long long box_seq = 0;
 	bool box_pending = false;          // a commit was launched whose mailbox has not been read
+	// the trail of the accept pass (JointTrail): grown to candidates x tiles of the largest chunk
+	int *d_trail_stamp = nullptr;  unsigned long long *d_trail_word = nullptr;  double *d_trail_L = nullptr;
+	size_t trail_cap = 0;              // entries (candidate, tile)
+	int trail_stamp = 0;
+	bool trail_valid = false;          // the last score left a trail for its chunk
 	// staging of the host-pointer draw
 	double *d_params = nullptr;
 	int *d_rows = nullptr;             // inside d_params' block, behind the candidates
@@ -230,6 +235,8 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	void *bufs[] = {j->st.live, j->st.shelfL, j->st.shelfn, j->st.higher, j->d_running, j->d_Lmin, j->d_argmin_run,
 	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params};
 	for (void *b : bufs) if (b) (void) hipFree(b);
+	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
+	for (void *b : trail) if (b) (void) hipFree(b);
 	if (j->h_box) (void) hipHostFree(j->h_box);
 	if (j->h_pin) (void) hipHostFree(j->h_pin);
 	delete j;
@@ -465,6 +472,33 @@ extern "C" int mdns_joint_advance(mdns_joint *j)
 // ---------------------------------------------------------------------------------------
 // the draw
 // ---------------------------------------------------------------------------------------
+// room for the trail of a chunk of B candidates over M selected spectra; a fresh stamp
+static bool joint_trail(mdns_joint *j, int B, int M, JointTrail *out)
+{
+	Context *c = ctx();
+	const size_t need = (size_t) B * ((M + 63) / 64);
+	if (need > j->trail_cap) {
+		(void) hipStreamSynchronize(c->stream);
+		void *old[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
+		for (void *b : old) if (b) (void) hipFree(b);
+		j->d_trail_stamp = nullptr; j->d_trail_word = nullptr; j->d_trail_L = nullptr; j->trail_cap = 0;
+		const size_t cap = need + need / 2 + 1024;
+		if (!MDNS_HIP(hipMalloc((void **) &j->d_trail_stamp, cap * sizeof(int))) ||
+		    !MDNS_HIP(hipMalloc((void **) &j->d_trail_word, cap * sizeof(unsigned long long))) ||
+		    !MDNS_HIP(hipMalloc((void **) &j->d_trail_L, cap * 64 * sizeof(double))) ||
+		    !MDNS_HIP(hipMemsetAsync(j->d_trail_stamp, 0, cap * sizeof(int), c->stream))) return false;
+		j->trail_cap = cap;
+		j->trail_stamp = 0;
+	}
+	if (j->trail_stamp == 0x7fffffff) {                                 // stamps start over
+		if (!MDNS_HIP(hipMemsetAsync(j->d_trail_stamp, 0, j->trail_cap * sizeof(int), c->stream))) return false;
+		j->trail_stamp = 0;
+	}
+	out->stamp_of = j->d_trail_stamp; out->word = j->d_trail_word; out->L = j->d_trail_L;
+	out->stamp = ++j->trail_stamp;
+	return true;
+}
+
 static bool check_draw(const mdns_joint *j, int B, int M, const char *who)
 {
 	if (!j) { set_error("%s: null handle", who); return false; }
@@ -482,6 +516,7 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 	if (!c || !check_draw(j, B, M, "mdns_joint_score_dev")) return 1;
 	mdns_spectra *s = j->s;
 	j->last_B = 0;
+	j->trail_valid = false;
 	if (B == 0 || M == 0) {
 		// nothing to score: no flag can be set; still hand commit a clean header
 		return MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kZeroInts * sizeof(int), c->stream)) ? 0 : 1;
@@ -501,7 +536,10 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 		yT = s->d_sel;
 		gather = nullptr;
 	}
-	if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags)) return 1;
+	JointTrail trail;
+	if (!joint_trail(j, B, M, &trail)) return 1;
+	if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, trail)) return 1;
+	j->trail_valid = true;
 	j->last_yT = yT; j->last_gather = gather; j->last_bt = bt; j->last_B = B; j->last_scale = scale;
 	return 0;
 }
@@ -509,10 +547,10 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 extern "C" int *mdns_joint_flags_dev(mdns_joint *j) { return j ? j->d_flags : nullptr; }
 extern "C" const void *mdns_joint_result_dev(mdns_joint *j) { return j ? j->d_result : nullptr; }
 
-extern "C" int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M)
+static int joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M, bool want_row, const char *who)
 {
 	Context *c = ctx();
-	if (!c || !check_draw(j, 0, M, "mdns_joint_commit_dev")) return 1;
+	if (!c || !check_draw(j, 0, M, who)) return 1;
 	if (j->last_B == 0 || M == 0) {
 		// an empty chunk accepts nothing (no kernel runs: the mailbox is filled from here, once
 		// whatever may still be writing to it has finished)
@@ -526,12 +564,28 @@ extern "C" int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M)
 	char *base = j->d_result;
 	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
 	double *Lrow = (double *) (base + sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8);
-	if (!launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
-	                              d_row_ids, M, j->d_flags, j->st, base, bits, Lrow)) return 1;
+	if (!want_row && j->trail_valid) {
+		// who beats its threshold, and with which likelihood, is in the trail of the accept pass:
+		// nothing is computed again
+		const JointTrail trail = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L, j->trail_stamp};
+		if (!launch_joint_commit_trail(d_row_ids, M, j->last_B, j->d_flags, trail, j->st, base, bits)) return 1;
+	} else if (!launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
+	                                     d_row_ids, M, j->d_flags, j->st, base, bits, Lrow)) return 1;
+	j->trail_valid = false;                                             // a chunk is committed once
 	hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
 	                   j->h_box_dev, ++j->box_seq);
 	j->box_pending = true;
 	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
+}
+
+extern "C" int mdns_joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M)
+{
+	return joint_commit_dev(j, d_row_ids, M, true, "mdns_joint_commit_dev");
+}
+
+extern "C" int mdns_joint_commit_bits_dev(mdns_joint *j, const int *d_row_ids, int M)
+{
+	return joint_commit_dev(j, d_row_ids, M, false, "mdns_joint_commit_bits_dev");
 }
 
 // waits for the mailbox of the last commit (see JointMailbox)
@@ -605,7 +659,7 @@ static int joint_commit_and_fetch(mdns_joint *j, int *accepted, double *Lrow, un
 	Context *c = ctx();
 	if (!c || !j) return 1;
 	const int M = j->staged_M;
-	if (mdns_joint_commit_dev(j, j->staged_rows ? j->d_rows : nullptr, M) != 0) return 1;
+	if (joint_commit_dev(j, j->staged_rows ? j->d_rows : nullptr, M, Lrow != nullptr, who) != 0) return 1;
 	if (!Lrow) {
 		// no likelihood row wanted: the kernel leaves {accepted, status, fill words} in mapped host
 		// memory -- no copy, no stream synchronisation

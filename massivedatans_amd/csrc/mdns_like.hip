@@ -530,7 +530,8 @@ template <int BT, bool DEEP>
 __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_accept(
     const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
     double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
-    int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, int *__restrict__ flags)
+    int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, int *__restrict__ flags,
+    JointTrail trail)
 {
 	const int lane = threadIdx.x & 63;
 	int tile, bt;
@@ -554,9 +555,79 @@ __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_accept(
 	const double thr = live ? higher[thr_rows ? thr_rows[kk] : kk] : __builtin_nan("");
 #pragma unroll
 	for (int b = 0; b < BT; b++) {
-		const bool beats = acc[0][b] * scale > thr;
-		if (__ballot(beats) != 0ull && lane == 0 && bt * BT + b < B) flags[bt * BT + b] = 1;
+		const double L = acc[0][b] * scale;
+		const unsigned long long word = __ballot(L > thr);
+		if (word != 0ull && bt * BT + b < B) {                         // rare: a candidate some data set accepts
+			const size_t at = (size_t) (bt * BT + b) * ntiles + tile;
+			if (trail.stamp_of) trail.L[at * 64 + lane] = L;
+			if (lane == 0) {
+				flags[bt * BT + b] = 1;
+				if (trail.stamp_of) { trail.word[at] = word; trail.stamp_of[at] = trail.stamp; }
+			}
+		}
 	}
+}
+
+// The commit when nobody wants the whole likelihood row: the first flagged candidate is THE
+// accepted point (hiermetriclearn.py:193-196); what its data sets need -- who beats the threshold,
+// and with which likelihood -- the accept pass left in the trail.  One wave per tile of 64
+// positions of the selection, one lane per data set.  Same shelf / threshold update as
+// k_gauss_cols_commit (multi_nested_sampler.py:482-485, :438-447).
+__global__ __launch_bounds__(kBlock) void k_joint_commit_trail(
+    const int *__restrict__ thr_rows, int M, int B, int ntiles, const int *__restrict__ flags, JointTrail trail,
+    JointArrays st, JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits)
+{
+	__shared__ int s_first;
+	if (threadIdx.x == 0) s_first = 0x7fffffff;
+	__syncthreads();
+	for (int b = threadIdx.x; b < B; b += kBlock)
+		if (flags[b]) { atomicMin(&s_first, b); break; }      // ascending per thread: its first is its lowest
+	__syncthreads();
+	const int bstar = s_first;
+	if (blockIdx.x == 0 && threadIdx.x == 0) header->accepted = bstar < B ? bstar : -1;
+	if (bstar >= B) return;
+	const int lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (tile >= ntiles) return;
+	const size_t at = (size_t) bstar * ntiles + tile;
+	// (a candidate flagged by another rank's data sets only has no entry here: nobody beats)
+	const unsigned long long word = trail.stamp_of[at] == trail.stamp ? trail.word[at] : 0ull;
+	const int k = tile * 64 + lane;
+	if (k < M && (word >> lane & 1ull)) {
+		const int d = thr_rows ? thr_rows[k] : k;
+		const double L = trail.L[at * 64 + lane];
+		const double thr = st.higher[d];
+		const int n = st.shelfn[d];
+		if (n >= st.cap) {
+			atomicOr(&header->status, 1);
+		} else {
+			// With n waiting the threshold was the (n+1)-th smallest of live + shelf, and L lies
+			// above it: the (n+2)-th smallest of the enlarged set is the old threshold again when
+			// it occurs more than once, else the smaller of L and the next value above it.
+			int at_most = 0;
+			double next = INFINITY;
+			int p = 0;
+			for (; p + 8 <= st.nlive; p += 8) {                      // eight loads in flight
+				double v[8];
+#pragma unroll
+				for (int u = 0; u < 8; u++) v[u] = st.live[(size_t) (p + u) * st.ndata + d];
+#pragma unroll
+				for (int u = 0; u < 8; u++) { if (v[u] <= thr) at_most++; else next = fmin(next, v[u]); }
+			}
+			for (; p < st.nlive; p++) {
+				const double v = st.live[(size_t) p * st.ndata + d];
+				if (v <= thr) at_most++; else next = fmin(next, v);
+			}
+			for (int e = 0; e < n; e++) {
+				const double v = st.shelfL[(size_t) e * st.ndata + d];
+				if (v <= thr) at_most++; else next = fmin(next, v);
+			}
+			st.shelfL[(size_t) n * st.ndata + d] = L;
+			st.shelfn[d] = n + 1;
+			st.higher[d] = at_most >= n + 2 ? thr : fmin(L, next);
+		}
+	}
+	if (lane == 0) fillbits[tile] = word;
 }
 
 // Second half of a draw chunk: the first flagged candidate is THE accepted point
@@ -984,7 +1055,7 @@ bool launch_gauss_cols(const mdns_spectra *s, const double *d_yT, const double *
 
 bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
-                              const double *d_higher, int *d_flags)
+                              const double *d_higher, int *d_flags, const JointTrail &trail)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
@@ -1000,7 +1071,7 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 	const size_t tpl_bytes = (size_t) cols_nx(s->nx) * bt * sizeof(double);
 	const bool deep = (long long) ntiles * nbt < 8LL * c->num_cus && bt <= 4 && tpl_bytes <= 48 * 1024;
 #define ACCEPT_LAUNCH(BT, DEEP) hipLaunchKernelGGL((k_gauss_cols_accept<BT, DEEP>), dim3(blocks), dim3(64 * wpb), DEEP ? tpl_bytes : 0, c->stream, \
-	d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags)
+	d_yT, cols_nx(s->nx), d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags, trail)
 	switch (bt) {
 	case 16: ACCEPT_LAUNCH(16, false); break;
 	case 8: ACCEPT_LAUNCH(8, false); break;
@@ -1024,6 +1095,16 @@ bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const d
 	                   d_yT, cols_nx(s->nx), d_model_t, mstride, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, cu_slots,
 	                   d_flags, st, (JointHeader *) d_header, d_fillbits, d_Lrow);
 	return launched("k_gauss_cols_commit");
+}
+
+bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,
+                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits)
+{
+	Context *c = ctx();
+	const int ntiles = (M + 63) / 64;
+	hipLaunchKernelGGL(k_joint_commit_trail, dim3((ntiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
+	                   d_thr_rows, M, B, ntiles, d_flags, trail, st, (JointHeader *) d_header, d_fillbits);
+	return launched("k_joint_commit_trail");
 }
 
 bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B, double *d_model, int ldm)
