@@ -40,7 +40,8 @@
 namespace mdns {
 
 static constexpr int kBlock = 256;
-static constexpr int kMaxRounds = 64;                 // rounds whose "changed" flag the header holds
+static constexpr int kMaxRounds = 64;                 // rounds per batch: their "changed" flags are in the header
+static constexpr int kRoundLimit = 1 << 20;           // a call gives up after this many rounds (never seen)
 static constexpr int kUnclaimed = 0x7f7f7f7f;         // memset pattern: above every data-set index
 
 // counts, failure bits (1 = id out of range, 2 = bad replacement) and, per round, whether it
@@ -100,8 +101,17 @@ __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__
 	if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(status, 1); return; }
 	m = wave_min(m);
 	if (!first) {
-		const int lm = label[m];                                      // m is a data set of this component: jump to ITS label
-		m = lm < m ? lm : m;
+		// m is a data set of this component: follow ITS label down to a data set that keeps its
+		// own (labels only point to lower indices, so this ends) ...
+		while (true) {
+			const int lm = label[m];
+			if (lm >= m) break;
+			m = lm;
+		}
+		// ... and hang the data set d stood under below it too: everybody who still points at
+		// that one gets there with the next jump (without this a path of n data sets in random
+		// order needs ~n rounds; with it a few dozen for n = 20 000)
+		if (lane == 0 && m < l && m < label[l]) label[l] = m;
 	}
 	bool moved = false;
 	for (int p = lane; p < nlive; p += 64) {
@@ -408,14 +418,16 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 	if (!MDNS_HIP(hipMemsetAsync(&hdr_of(g)->changed[0], 0, sizeof(int) * kMaxRounds, c->stream)) ||
 	    !MDNS_HIP(hipMemsetAsync(plabel_of(g), 0x7f, (size_t) npoints * sizeof(int), c->stream))) return 1;
 	const GroupsHeader *h = &g->h_box->header;
-	int done = 0, batch = g->rounds_hint;
+	long long total = 0;
+	int batch = g->rounds_hint, needed = 0;
 	while (true) {
-		if (done + batch > kMaxRounds) batch = kMaxRounds - done;
-		for (int r = done; r < done + batch; r++)
+		// the flags of this batch start cleared (the first batch's were cleared above)
+		if (total > 0 && !MDNS_HIP(hipMemsetAsync(&hdr_of(g)->changed[0], 0, sizeof(int) * kMaxRounds, c->stream))) return 1;
+		for (int r = 0; r < batch; r++)
 			hipLaunchKernelGGL(k_groups_round, dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, r == 0 ? 1 : 0,
+			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, total == 0 && r == 0 ? 1 : 0,
 			                   &hdr_of(g)->changed[r], &hdr_of(g)->status);
-		done += batch;
+		total += batch;
 		// optimistically everything that follows a converged state, in the same round trip
 		if (!MDNS_HIP(hipMemsetAsync(hdr_of(g), 0, 2 * sizeof(int), c->stream))) return 1;      // the two counts
 		hipLaunchKernelGGL(k_groups_finish, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
@@ -443,14 +455,17 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 			                     : "mdns_groups_components: an id outside [0, %lld) was met", npoints);
 			return 1;
 		}
-		if (h->changed[done - 1] == 0) break;                        // the last round found nothing to do
-		if (done >= kMaxRounds) { set_error("mdns_groups_components: labels still moving after %d rounds", kMaxRounds); return 1; }
-		batch = 4;
+		if (h->changed[batch - 1] == 0) {                            // the last round found nothing to do
+			int clean = batch - 1;
+			while (clean > 0 && h->changed[clean - 1] == 0) clean--;
+			needed = (int) (total - batch) + clean + 1;              // the deciding round is part of it
+			break;
+		}
+		if (total >= kRoundLimit) { set_error("mdns_groups_components: labels still moving after %lld rounds", total); return 1; }
+		batch = batch * 2 > kMaxRounds ? kMaxRounds : batch * 2;     // a slow graph: look less often
 	}
-	int clean = done - 1;
-	while (clean > 0 && h->changed[clean - 1] == 0) clean--;
-	g->rounds_hint = clean + 1 < 2 ? 2 : (clean + 1 > 16 ? 16 : clean + 1);   // the deciding round is part of it
-	g->rounds_total += clean + 1; g->calls_total++;
+	g->rounds_hint = needed < 2 ? 2 : (needed > 16 ? 16 : needed);
+	g->rounds_total += needed; g->calls_total++;
 	*ncomponents = h->ncomponents;
 	const long long nd = h->ndistinct;
 	if (ndistinct) *ndistinct = nd;

@@ -106,6 +106,27 @@ def test_components_against_scipy_full_size(ndata, nlive, nclusters):
     dg.close()
 
 
+@pytest.mark.parametrize("n", [10, 1000, 20000])
+def test_long_chains_converge(n):
+    """The worst case for label propagation: data set d holds ids d and d + 1, a path whose diameter
+    is the number of data sets -- in order and with the data sets shuffled along the path.  One
+    component, every id; the rounds stay in the dozens (pointer chase + hooking), and a call is not
+    limited to one batch of rounds."""
+    from massivedatans_amd.grouping import DeviceGroups
+    rng = np.random.RandomState(n)
+    lp = np.vstack([np.arange(n), np.arange(n) + 1])
+    for mat in (lp, lp[:, rng.permutation(n)]):
+        dg = DeviceGroups(mat)
+        ncomp, ids = dg.components(None, n + 1)
+        assert ncomp == 1 and np.array_equal(ids, np.arange(n + 1))
+        assert dg.mean_rounds() < 64
+        # and cut in two: the data sets holding id n // 2 left out
+        keep = np.flatnonzero(~(mat == n // 2).any(axis=0))
+        if len(keep) >= 2:
+            same(dg.groups(keep, n + 1), cpu_groups(mat, keep))
+        dg.close()
+
+
 def test_replacements_follow_the_host_matrix():
     """mdns_groups_replace (the end of an iteration: one id per running data set changes) keeps
     the device matrix equal to the host's, and the components follow -- a bridge point joins two
