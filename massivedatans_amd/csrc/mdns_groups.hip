@@ -35,6 +35,7 @@
 #include "mdns_internal.h"
 
 #include <atomic>
+#include <cstddef>
 #include <cstring>
 
 namespace mdns {
@@ -46,7 +47,7 @@ static constexpr int kUnclaimed = 0x7f7f7f7f;         // memset pattern: above e
 
 // counts, failure bits (1 = id out of range, 2 = bad replacement) and, per round, whether it
 // still moved a label
-struct GroupsHeader { int ncomponents; int ndistinct; int status; int pad; int changed[kMaxRounds]; };
+struct GroupsHeader { int status; int pad; int ncomponents; int ndistinct; int changed[kMaxRounds]; };   // a call clears [ncomponents, end)
 // the same and the list of distinct ids in host memory mapped into the device: written by the
 // last kernel of a call (k_groups_compact), `seq` last; the host polls instead of copying
 struct GroupsBox { unsigned long long seq; unsigned long long pad; GroupsHeader header; int distinct[1]; };
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(kBlock) void k_groups_touched(const int *__restrict
 // (multi_nested_sampler.py:279) -- by ONE workgroup: popcounts of contiguous runs of words, a scan
 // over the 1024 run totals, then every thread writes out its run.
 __global__ __launch_bounds__(1024) void k_groups_compact(const unsigned long long *__restrict__ touched, long long nwords,
-                                                         GroupsHeader *__restrict__ header, GroupsBox *__restrict__ box,
-                                                         unsigned long long seq)
+                                                         int *scratch, GroupsHeader *__restrict__ header,
+                                                         GroupsBox *__restrict__ box, unsigned long long seq)
 {
 	__shared__ int wave_total[16];
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -181,21 +182,26 @@ __global__ __launch_bounds__(1024) void k_groups_compact(const unsigned long lon
 	int before = 0;
 	for (int k = 0; k < wave; k++) before += wave_total[k];
 	int at = before + incl - mine;
-	// the list goes straight to the host: `box` is host memory mapped into the device
 	for (long long w = w0; w < w1; w++) {
 		unsigned long long bits = touched[w];
 		while (bits) {
-			box->distinct[at++] = (int) (w * 64 + __builtin_ctzll(bits));
+			scratch[at++] = (int) (w * 64 + __builtin_ctzll(bits));
 			bits &= bits - 1;
 		}
 	}
-	__threadfence_system();
+	__shared__ int s_total;
+	if (t == 1023) s_total = before + incl;
+	__threadfence_block();
 	__syncthreads();
-	// counts, failure bits and the rounds' flags follow, `seq` last: the host polls for it
+	// the list goes to the host in one sweep of coalesced stores (`box` is host memory mapped into
+	// the device; every thread writing its own run there 4 bytes at a time took 3x as long)
+	const int total = s_total;
+	for (int e = t; e < total; e += 1024) box->distinct[e] = scratch[e];
+	// counts, failure bits and the rounds' flags with it; `seq` last: the host polls for it
 	if (t < kMaxRounds) box->header.changed[t] = header->changed[t];
 	if (t == 1023) {
 		box->header.ncomponents = header->ncomponents;
-		box->header.ndistinct = before + incl;
+		box->header.ndistinct = total;
 		box->header.status = header->status;
 	}
 	__threadfence_system();
@@ -414,27 +420,27 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		if (!MDNS_HIP(hipMemcpyAsync(g->d_rows, pin, (size_t) M * 4, hipMemcpyHostToDevice, c->stream))) return 1;
 	}
 	const int *d_rows = rows ? g->d_rows : nullptr;
-	// round flags and counts cleared (not the failure bits), no live point labelled
-	if (!MDNS_HIP(hipMemsetAsync(&hdr_of(g)->changed[0], 0, sizeof(int) * kMaxRounds, c->stream)) ||
+	// counts and round flags cleared (not the failure bits), no live point labelled
+	const size_t clear_bytes = sizeof(GroupsHeader) - offsetof(GroupsHeader, ncomponents);
+	if (!MDNS_HIP(hipMemsetAsync(&hdr_of(g)->ncomponents, 0, clear_bytes, c->stream)) ||
 	    !MDNS_HIP(hipMemsetAsync(plabel_of(g), 0x7f, (size_t) npoints * sizeof(int), c->stream))) return 1;
 	const GroupsHeader *h = &g->h_box->header;
 	long long total = 0;
-	int batch = g->rounds_hint, needed = 0;
+	int batch = g->rounds_hint + 1, needed = 0;                      // one spare round costs 5 us, a second look 40
 	while (true) {
-		// the flags of this batch start cleared (the first batch's were cleared above)
-		if (total > 0 && !MDNS_HIP(hipMemsetAsync(&hdr_of(g)->changed[0], 0, sizeof(int) * kMaxRounds, c->stream))) return 1;
+		// counts and flags of this batch start cleared (the first batch's were cleared above)
+		if (total > 0 && !MDNS_HIP(hipMemsetAsync(&hdr_of(g)->ncomponents, 0, clear_bytes, c->stream))) return 1;
 		for (int r = 0; r < batch; r++)
 			hipLaunchKernelGGL(k_groups_round, dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
 			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, total == 0 && r == 0 ? 1 : 0,
 			                   &hdr_of(g)->changed[r], &hdr_of(g)->status);
 		total += batch;
 		// optimistically everything that follows a converged state, in the same round trip
-		if (!MDNS_HIP(hipMemsetAsync(hdr_of(g), 0, 2 * sizeof(int), c->stream))) return 1;      // the two counts
 		hipLaunchKernelGGL(k_groups_finish, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
 		                   g->d_label, d_rows, M, g->d_labels, hdr_of(g));
 		hipLaunchKernelGGL(k_groups_touched, dim3((unsigned) ((npoints + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
 		                   plabel_of(g), npoints, touched_of(g));
-		hipLaunchKernelGGL(k_groups_compact, dim3(1), dim3(1024), 0, c->stream, touched_of(g), (long long) nw, hdr_of(g),
+		hipLaunchKernelGGL(k_groups_compact, dim3(1), dim3(1024), 0, c->stream, touched_of(g), (long long) nw, pout_of(g), hdr_of(g),
 		                   g->h_box_dev, ++g->box_seq);
 		if (!MDNS_HIP(hipGetLastError())) return 1;
 		// counts, flags and the list arrive in mapped host memory: poll for `seq` (looking at the
@@ -462,7 +468,8 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 			break;
 		}
 		if (total >= kRoundLimit) { set_error("mdns_groups_components: labels still moving after %lld rounds", total); return 1; }
-		batch = batch * 2 > kMaxRounds ? kMaxRounds : batch * 2;     // a slow graph: look less often
+		// not there yet: a few more rounds, then more and more (a slow graph: look less often)
+		batch = total <= g->rounds_hint + 1 ? 2 : (batch * 2 > kMaxRounds ? kMaxRounds : batch * 2);
 	}
 	g->rounds_hint = needed < 2 ? 2 : (needed > 16 ? 16 : needed);
 	g->rounds_total += needed; g->calls_total++;
