@@ -81,3 +81,33 @@ def test_host_helper_library_is_built_and_used(built):
     assert os.path.exists(path), "run make -C massivedatans_amd/csrc"
     assert hasattr(C.CDLL(path), "mdns_host_group_walk")
     assert mns._host_lib() is not None
+
+
+def test_committed_bench_lines_keep_the_contract():
+    """The bench lines kept under profiles/ (what `python bench.py [--workload muse]` printed on the
+    GPU box) carry every key the driver's contract names, the roofline and cpu_baseline objects
+    included, and a fraction that is a fraction."""
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    paths = sorted(glob.glob(os.path.join(root, "profiles", "r02_bench*.json")))
+    assert paths
+    for path in paths:
+        line = json.load(open(path))
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                    "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+            assert key in line, (path, key)
+        assert line["unit"] == "likelihood evals/s" and line["higher_is_better"] is True and line["scaling"] == "weak"
+        assert line["vs_baseline"] is None and line["dtype"] == "f64" and line["data"] == "synthetic"
+        assert "workload" in line["config"] and "model" not in line["config"]
+        r = line["roofline"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in r, (path, key)
+        assert r["bound"] in ("hbm", "fp64_valu") and 0.0 < r["frac"] < 1.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+        # value = units per step / time per step
+        assert abs(line["value"] * line["ms_per_step"] * 1e-3 / (line["config"]["candidates_per_step"] * line["config"]["spectra_per_gpu"] * line["n_gpus"]) - 1) < 1e-6
+        if "cpu_baseline" in line:
+            for key in ("value", "unit", "cores", "kind", "sample"):
+                assert key in line["cpu_baseline"], (path, key)
+            assert line["cpu_baseline"]["kind"] in ("reference", "port")
