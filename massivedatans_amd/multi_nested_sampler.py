@@ -514,13 +514,17 @@ class MultiNestedSampler(object):
             if len(selected) == 1:
                 yield data_mask, self.live_pointsp[:, selected[0]]
                 return
-            # (the reference's two shortcuts, :283-297, name cases that are connected: the
-            # components say the same)
             running = self._running_indices()
             real_rows = running[selected]
             rows = None if len(selected) == dg.ndata else real_rows
             ncomp, ids = dg.components(rows, len(self.pointpile))
-            if ncomp == 1:
+            # The reference's two shortcuts (:283-297) return ONE group without looking at the
+            # graph.  "Fewer than 2 nlive distinct ids" does imply one component; "superpoints
+            # known" does not: a point enters `superpoints` when it lands on every shelf (:486-488),
+            # before it is live anywhere, and leaves only when it dies somewhere -- so the list can
+            # be non-empty while the live-id graph is split.  The reference (and the host paths
+            # here) then still draw jointly; so must this one.
+            if ncomp == 1 or len(ids) < 2 * self.nlive_points or len(self.superpoints) > 0:
                 self._last_selection = (data_mask, selected, real_rows)      # for _fill_shelves
                 yield data_mask, ids
                 return

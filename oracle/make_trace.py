@@ -43,7 +43,87 @@ STUBS = {
                       "    def update(self, *a, **k):\n        pass\n    def start(self):\n        return self\n"
                       "    def finish(self):\n        pass\n"
                       "Timer = Bar = Percentage = ETA = Widget = ProgressBar = _W\n",
-    "igraph.py": "class Graph(object):\n    def __init__(self, *a, **k):\n        raise RuntimeError('igraph stub')\n",
+    # igraph is absent from this image.  With use_graph=True the reference needs six things of it
+    # (multi_nested_sampler.py:175-192,268-355,430,503,529): Graph(directed=False), add_vertex(name,
+    # **attributes), add_edges / delete_edges on (name, name) pairs, subgraph(names), clusters() and
+    # vs[i].attributes().  This stand-in provides exactly those on plain Python containers, with
+    # igraph's DOCUMENTED numbering: vertex ids in insertion order; an induced subgraph renumbers
+    # its vertices keeping their relative order; clusters() numbers the components by their lowest
+    # vertex id and lists each component's vertex ids ascending.  Everything else on that path --
+    # the shortcuts, the subgraph re-use, which vertices enter, how clusters become (mask, ids)
+    # groups -- is the reference's own code, run unmodified.  The traces made with it therefore pin
+    # those lines and do NOT pin igraph's numbering contract itself.
+    "igraph.py": """
+class _Vertex(object):
+    def __init__(self, attrs):
+        self._attrs = attrs
+
+    def attributes(self):
+        return dict(self._attrs)
+
+
+class Graph(object):
+    def __init__(self, directed=False):
+        assert not directed
+        self.vs = []
+        self._index = {}
+        self._adj = []
+
+    def _id(self, v):
+        return v if isinstance(v, int) else self._index[v]
+
+    def add_vertex(self, name=None, **attrs):
+        attrs = dict(attrs, name=name)
+        self._index.setdefault(name, len(self.vs))
+        self.vs.append(_Vertex(attrs))
+        self._adj.append({})
+
+    def add_edges(self, edges):
+        for a, b in edges:
+            a, b = self._id(a), self._id(b)
+            self._adj[a][b] = self._adj[a].get(b, 0) + 1
+            self._adj[b][a] = self._adj[b].get(a, 0) + 1
+
+    def delete_edges(self, edges):
+        for a, b in edges:
+            a, b = self._id(a), self._id(b)
+            if self._adj[a].get(b, 0) <= 0:
+                raise ValueError('no such edge')
+            for x, y in ((a, b), (b, a)):
+                self._adj[x][y] -= 1
+                if self._adj[x][y] == 0:
+                    del self._adj[x][y]
+
+    def subgraph(self, vertices):
+        keep = sorted(set(self._id(v) for v in vertices))
+        new_id = dict((old, new) for new, old in enumerate(keep))
+        g = Graph()
+        for old in keep:
+            attrs = self.vs[old].attributes()
+            g.add_vertex(attrs.pop('name'), **attrs)
+        for old in keep:
+            for other, count in self._adj[old].items():
+                if other in new_id:
+                    g._adj[new_id[old]][new_id[other]] = count
+        return g
+
+    def clusters(self):
+        seen = [False] * len(self.vs)
+        out = []
+        for start in range(len(self.vs)):
+            if seen[start]:
+                continue
+            seen[start] = True
+            members, stack = [start], [start]
+            while stack:
+                for other in self._adj[stack.pop()]:
+                    if not seen[other]:
+                        seen[other] = True
+                        members.append(other)
+                        stack.append(other)
+            out.append(sorted(members))
+        return out
+""",
     "nestle.py": "def bounding_ellipsoid(*a, **k):\n    raise RuntimeError('nestle stub')\n"
                  "bounding_ellipsoids = sample_ellipsoids = bounding_ellipsoid\n",
 }
@@ -75,6 +155,12 @@ class Recorder(object):
         self.__dict__["Ls"] = []
         self.__dict__["us"] = []
         self.__dict__["ndraws_after"] = []
+        # live points of every data set at the moment it left the run (the integrator's
+        # cut_down, multi_nested_sampler.py:148-173): by ORIGINAL data-set index
+        nlive, ndata = sampler.live_pointsp.shape
+        self.__dict__["active"] = numpy.ones(ndata, dtype=bool)
+        self.__dict__["term_p"] = numpy.full((nlive, ndata), -1, dtype=int)
+        self.__dict__["term_L"] = numpy.full((nlive, ndata), numpy.nan)
 
     def __getattr__(self, name):
         return getattr(self._s, name)
@@ -91,8 +177,16 @@ class Recorder(object):
 
     next = __next__
 
+    def cut_down(self, surviving):
+        surviving = numpy.asarray(surviving, dtype=bool)
+        leaving = numpy.flatnonzero(self.active)[~surviving]
+        self.term_p[:, leaving] = numpy.asarray(self._s.live_pointsp)[:, ~surviving]
+        self.term_L[:, leaving] = numpy.asarray(self._s.live_pointsL)[:, ~surviving]
+        self.active[leaving] = False
+        return self._s.cut_down(surviving)
 
-def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horns"):
+
+def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horns", use_graph=False):
     import cachedconstrainer
     import hiermetriclearn
     from clustering.radfriendsregion import RadFriendsRegion
@@ -147,7 +241,7 @@ def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horn
         nlive_points=nlive, priortransform=priortransform, multi_loglikelihood=multi_loglikelihood,
         ndim=3, ndata=ndata, superset_draw_constrained=superset_constrainer.draw_constrained,
         individual_draw_constrained=individual_draw_constrained, draw_constrained=cc.get,
-        nsuperset_draws=nsuperset_draws, use_graph=False)
+        nsuperset_draws=nsuperset_draws, use_graph=use_graph)
     superset_constrainer.sampler = sampler
     cc.sampler = sampler
     rec = Recorder(sampler)
@@ -155,12 +249,15 @@ def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horn
     rng_probe = numpy.random.uniform()
     return dict(
         ndata=ndata, nlive=nlive, max_samples=max_samples, nsuperset_draws=nsuperset_draws,
+        use_graph=int(use_graph),
         logZ=results["logZ"], logZerr=results["logZerr"], information=results["information"],
         ndraws=sampler.ndraws, nweights=len(results["weights"]),
         iter_nrunning=numpy.array([len(L) for L in rec.Ls]),
         iter_L=numpy.concatenate(rec.Ls), iter_u=numpy.concatenate(rec.us),
         iter_ndraws=numpy.array(rec.ndraws_after),
-        final_live_pointsp=sampler.live_pointsp, final_live_pointsL=sampler.live_pointsL,
+        # (after the integrator's last cut_down the sampler's own matrices are [nlive, 0]: what is
+        # stored is every data set's column as it stood when that data set left)
+        final_live_pointsp=rec.term_p, final_live_pointsL=rec.term_L,
         npoints=len(sampler.pointpile), rng_probe=rng_probe)
 
 
@@ -173,8 +270,13 @@ CASES = {
     # BASELINE.json configs[0] (100 spectra, 50 live points; 300 iterations as in SURVEY 3.3):
     # 44 272 likelihood calls in the reference.  Stored without the per-iteration arrays.
     "horns100": (100, 50, 300, 10, "horns"),
+    # the reference's DEFAULT grouping (USE_GRAPH=1, generate_subsets_graph) through the igraph
+    # stand-in above: pins multi_nested_sampler.py:268-355 up to igraph's numbering contract
+    "horns12_graph": (12, 24, 260, 10, "horns", True),
+    "nothing4_graph": (4, 40, 1500, 3, "nothing", True),
+    "horns100_graph": (100, 50, 300, 10, "horns", True),
 }
-LIGHT = {"horns100"}          # cases kept small: no iter_L / iter_u
+LIGHT = {"horns100", "horns100_graph"}          # cases kept small: no iter_L / iter_u
 
 
 def main():
@@ -182,10 +284,11 @@ def main():
     stage_reference()
     wanted = sys.argv[1:] or list(CASES)
     for name in wanted:
-        ndata, nlive, max_samples, nsd, generator = CASES[name]
+        ndata, nlive, max_samples, nsd, generator = CASES[name][:5]
+        use_graph = len(CASES[name]) > 5 and CASES[name][5]
         t0 = time.time()
         with contextlib.redirect_stdout(io.StringIO()):
-            out = run_reference(ndata, nlive, max_samples, nsd, generator)
+            out = run_reference(ndata, nlive, max_samples, nsd, generator, use_graph)
         if name in LIGHT:
             out = {k: v for k, v in out.items() if k not in ("iter_L", "iter_u")}
         path = os.path.join(ROOT, "tests", "golden", "trace_%s.npz" % name)

@@ -152,6 +152,28 @@ def test_replacements_follow_the_host_matrix():
     dg.close()
 
 
+def test_superpoint_shortcut_on_the_device_path():
+    """`superpoints` non-empty while the live-id graph is split (a point that landed
+    on every shelf and is live nowhere yet): the reference returns one joint group
+    (multi_nested_sampler.py:284-297); the device branch of generate_subsets_graph must too."""
+    from test_sampler_units import _fake_sampler, _graph_groups, _split_with_superpoint
+    lp, npoints = _split_with_superpoint()
+    mask = np.ones(lp.shape[1], dtype=bool)
+    allp = sorted(set(int(p) for p in lp.ravel()))
+    for planted in (False, True):
+        host = _fake_sampler(lp, npoints, lp.shape[0])
+        dev = _fake_sampler(lp, npoints, lp.shape[0])
+        dev._device_groups_wanted = True
+        if planted:
+            host.superpoints = {150}
+            dev.superpoints = {150}
+        got = _graph_groups(dev, mask)
+        assert dev._dgroups is not None and dev._dgroups.ncalls == 1
+        assert got == _graph_groups(host, mask)
+        assert (got == [(list(range(lp.shape[1])), allp)]) == planted
+        dev._dgroups.close()
+
+
 def test_bad_arguments_are_refused():
     from massivedatans_amd import _lib
     from massivedatans_amd.grouping import DeviceGroups

@@ -272,36 +272,41 @@ def test_geometry_full_size_properties(nb):
 
 # ---------------------------------------------------------------- end to end ---------------
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("case", ["nothing4", "horns3", "horns12", "horns100"])
+@pytest.mark.parametrize("case", ["nothing4", "horns3", "horns12", "horns100", "nothing4_graph", "horns12_graph", "horns100_graph"])
 def test_end_to_end_against_reference_trace(case, fused):
     """The whole analysis on the GPU (HIP likelihood + HIP geometry + host orchestration) against
     the trace recorded from the reference's Python + C.  Geometry is bit-exact and likelihoods
     agree to ~1e-15, so the integer bookkeeping is expected to coincide (a last-bit tie in an
-    accept test could fork a run; none occurs in these cases) and the evidences must agree within
-    the 1e-6 relative bar of BASELINE.json.  ``fused``: live-point likelihoods, shelves, thresholds,
-    accept test and shelf fill on the device (mdns_joint_*), one launch sequence per draw chunk."""
-    import os
+    accept test could fork a run; none occurs in these cases): per-iteration draw counts, the
+    accepted points and the ids of every data set's live points at its termination EXACTLY, the
+    position of the global RNG stream exactly, per-iteration dead-point likelihoods and the
+    live-point likelihoods within 1e-12, evidences within the 1e-6 relative bar of BASELINE.json
+    (and 1e-9 absolute).  ``fused``: live-point likelihoods, shelves, thresholds, accept test and
+    shelf fill on the device (mdns_joint_*).  ``*_graph``: the reference's default grouping
+    (USE_GRAPH=1) -- with ``fused`` its components come from the device (csrc/mdns_groups.hip)."""
     from massivedatans_amd import sample
     from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with np.load(os.path.join(root, "tests", "golden", "trace_%s.npz" % case)) as f:
-        g = {k: f[k] for k in f.files}
+    from tracing import Recorder, check_bookkeeping, check_floats, load_trace
+    g = load_trace(case)
     ndata, nlive = int(g["ndata"]), int(g["nlive"])
+    use_graph = bool(g.get("use_graph", 0))
     data = (gen.horns if "horns" in case else gen.nothing)(ndata)
     problem = sample.GaussLineProblem(data["x"], data["y"])          # HIP backend
     sampler = sample.build_sampler(problem, nlive_points=nlive, nsuperset_draws=int(g["nsuperset_draws"]),
-                                   use_graph=False, seed=1, batched=True, fused=fused)
+                                   use_graph=use_graph, seed=1, batched=True, fused=fused)
+    rec = Recorder(sampler)
     with np.errstate(all="ignore"):
-        results = multi_nested_integrator(tolerance=0.5, multi_sampler=sampler, min_samples=0,
+        results = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0,
                                           max_samples=int(g["max_samples"]))
+    rng_probe = np.random.uniform()
     if fused:
         assert type(sampler.joint).__name__ == "GaussJointState"
-    assert sampler.ndraws == int(g["ndraws"])
-    assert np.array_equal(sampler.live_pointsp, g["final_live_pointsp"])
-    assert rel_err(sampler.live_pointsL, g["final_live_pointsL"]) < 1e-12
+        assert (sampler._dgroups is not None) == use_graph
+    check_bookkeeping(g, sampler, rec, results)
+    assert rng_probe == float(g["rng_probe"])
+    check_floats(g, rec, results, rtol=1e-12)
     assert rel_err(results["logZ"], g["logZ"]) < 1e-6
     assert np.max(np.abs(results["logZ"] - g["logZ"])) < 1e-9
-    assert np.allclose(results["logZerr"], g["logZerr"], rtol=1e-6, atol=1e-9)
 
 
 def test_region_handle_bit_exact(hip, nb, oracle):

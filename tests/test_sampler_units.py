@@ -312,6 +312,52 @@ def test_graph_grouping_against_networkx():
     assert multi > 5
 
 
+def _split_with_superpoint(nlive=6):
+    """Two blocks of data sets with DISJOINT live points and enough distinct ids (>= 2 nlive) --
+    plus a point recorded as a superpoint although it is live nowhere: it landed on every shelf
+    (multi_nested_sampler.py:486-488) and is not live anywhere yet."""
+    half = nlive // 2
+    cols = [np.arange(nlive), np.arange(nlive) + half]                          # data sets 0, 1 overlap
+    cols += [100 + np.arange(nlive) + k * half for k in range(3)]               # data sets 2, 3, 4 chain
+    lp = np.array(cols, dtype=np.int64).T
+    return lp, 200
+
+
+def _graph_groups(s, mask):
+    return [(np.flatnonzero(m).tolist(), [int(p) for p in pts]) for m, pts in s.generate_subsets_graph(mask, None)]
+
+
+def test_superpoint_shortcut_holds_while_the_graph_is_split():
+    """multi_nested_sampler.py:284-297: with superpoints known the reference returns ONE group
+    (all selected data sets, numpy.unique of their ids) without looking at the graph -- also when
+    the live-id graph is split, which can happen because a point enters `superpoints` on landing
+    on all shelves, before it is live.  The native host path and the Python path must both do so
+    (the device path: tests/test_groups.py)."""
+    from massivedatans_amd import multi_nested_sampler as mns
+    lp, npoints = _split_with_superpoint()
+    mask = np.ones(lp.shape[1], dtype=bool)
+    allp = sorted(set(int(p) for p in lp.ravel()))
+    for planted in (False, True):
+        want_one = [(list(range(lp.shape[1])), allp)]
+        s = _fake_sampler(lp, npoints, lp.shape[0])
+        if planted:
+            s.superpoints = {150}                       # on every shelf, live nowhere
+        native = _graph_groups(s, mask)
+        lib, mns._host._LIB = mns._host._LIB, False     # the Python statement
+        try:
+            s2 = _fake_sampler(lp, npoints, lp.shape[0])
+            if planted:
+                s2.superpoints = {150}
+            python = _graph_groups(s2, mask)
+        finally:
+            mns._host._LIB = lib
+        assert native == python
+        if planted:
+            assert native == want_one
+        else:
+            assert len(native) == 2 and native[0][0] == [0, 1] and native[1][0] == [2, 3, 4]
+
+
 def _muse_case(seed=4, nd=23, nx=61):
     rng = np.random.RandomState(seed)
     x = np.linspace(4750, 9350, nx)
