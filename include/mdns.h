@@ -372,6 +372,121 @@ int mdns_groups_labels(mdns_groups *g, int32_t *labels, int32_t *point_labels);
 /* rounds of label propagation per mdns_groups_components call so far, on average */
 double mdns_groups_mean_rounds(const mdns_groups *g);
 
+/* ------------------------------------------------------------------------------------------
+ * Part 5 -- one native call per constrained draw (libmdns_host.so, csrc/host_constrainer.cpp).
+ *
+ * The reference's MLFriends constrainer (hiermetriclearn.py:27-211 over
+ * clustering/radfriendsregion.py:58-182 and clustering/sdml.py:60-88) as ONE object behind the C
+ * ABI: rebuild policy (:152-166,198-211), region construction with its bootstrap draws
+ * (:48-92; neighbors.py:170-177), the candidate generators (radfriendsregion.py:117-182,
+ * hiermetriclearn.py:104-137) and the accept loop (:181-196).  Every random number is taken from
+ * numpy's OWN Mersenne-Twister state (the address the caller passes: `mt19937_state` behind
+ * numpy.random's global legacy RandomState), with numpy's legacy algorithms, in the reference's
+ * call order -- the stream advances exactly as if the reference had run.  The kernels are reached
+ * through a table of C function pointers: on the GPU the mdns_backend_* entry points of
+ * libmdns_hip.so below; tests put the CPU oracle behind the same table.
+ * ------------------------------------------------------------------------------------------ */
+#define MDNS_MAX_DIM 16
+
+/* Device work of a draw.  `user` is passed back as the first argument of every function. */
+typedef struct mdns_draw_backend {
+	void *user;
+	/* RadFriendsRegion(members, maxdistance) (radfriendsregion.py:59-70): members f64[K, ndim] in
+	 * the metric's coordinates.  packed != NULL: K6 with that bootstrap choice (bit b of packed[i] =
+	 * point i chosen in round b; cneighbors.c:125-179), *radius receives the result; packed == NULL:
+	 * the region gets the radius *radius holds.  Returns an opaque region, NULL on failure. */
+	void *(*region_create)(void *user, const double *members, int K, int ndim,
+	                       const unsigned *packed, int nbootstraps, double *radius);
+	void (*region_destroy)(void *user, void *region);
+	/* K3 with the region's radius (cneighbors.c:95-119, no early stop): counts int32[n]. */
+	int (*region_count)(void *user, void *region, const double *points, int n, int *counts);
+	/* A constrained draw over the data sets rows int32[M] (ascending ORIGINAL indices; NULL: all,
+	 * M = their number) begins: called once before its chunks. */
+	int (*draw_begin)(void *user, const int *rows, int M);
+	/* One chunk: params f64[B, nparams] of ALREADY proposed candidates, in order.  *accepted = the
+	 * first that beats the threshold of some selected data set (hiermetriclearn.py:193), or -1;
+	 * fillbits uint64[ceil(M/64)]: bit k set when it beats the k-th selected data set's
+	 * (multi_nested_sampler.py:482-485); those data sets take the point in.  *nscored = candidates
+	 * looked at (B, or fewer when the scorer stops at the accepted one). */
+	int (*draw_chunk)(void *user, const double *params, int B, int *accepted,
+	                  unsigned long long *fillbits, int *nscored);
+	/* How many of `offered` candidates one chunk should hold for M selected data sets when the last
+	 * draw of this constrainer needed `hint` tries (a speed choice: results do not depend on it). */
+	int (*chunk_size)(void *user, int offered, int M, int hint);
+} mdns_draw_backend;
+
+/* The prior transform of the problem (sample.py:52-58) and the kernel's parameters (sample.py:103),
+ * per dimension:  x[k] = a[k] * u[k] + b[k]  (the addition skipped when b[k] == 0), then
+ * x[k] = 10 ** x[k] where pow10[k];  kernel parameter k = x[k], or 10 ** x[k] where
+ * kernel_pow10[k].  `custom`, when set, replaces all of that: it fills x f64[B, ndim] and
+ * params f64[B, nparams] from u f64[B, ndim] (a problem definition kept in Python). */
+typedef struct mdns_prior {
+	int ndim, nparams;
+	double a[MDNS_MAX_DIM], b[MDNS_MAX_DIM];
+	int pow10[MDNS_MAX_DIM], kernel_pow10[MDNS_MAX_DIM];
+	void (*custom)(void *user, const double *u, int B, double *x, double *params);
+	void *user;
+} mdns_prior;
+
+/* numpy operations the constrainer leaves to numpy itself so that its numbers ARE numpy's (numpy
+ * dispatches power/log2 to SIMD code whose last bits differ from the C library's):
+ * vec_pow: inout[i] = numpy.power(inout[i], exponent)  (radfriendsregion.py:156);
+ * fit_metric: mean f64[ndim], scale f64[ndim] of sdml.py:44-49 (kind 1) / :68-82 (kind 2) fitted to
+ * u f64[K, ndim] shifted to its mean (hiermetriclearn.py:63-80); returns 0. */
+typedef struct mdns_numpy_ops {
+	void *user;
+	void (*vec_pow)(void *user, double *inout, int n, double exponent);
+	int (*fit_metric)(void *user, int kind, const double *u, int K, int ndim, double *mean, double *scale);
+} mdns_numpy_ops;
+
+typedef struct mdns_constrainer mdns_constrainer;
+
+#define MDNS_METRIC_NONE 0
+#define MDNS_METRIC_SIMPLESCALING 1
+#define MDNS_METRIC_TRUNCATEDSCALING 2
+
+/* MetricLearningFriendsConstrainer(metriclearner, rebuild_every, metric_rebuild_every,
+ * force_shrink) (hiermetriclearn.py:28-46). */
+mdns_constrainer *mdns_constrainer_create(int ndim, int metriclearner, int rebuild_every,
+                                          int metric_rebuild_every, int force_shrink);
+void mdns_constrainer_destroy(mdns_constrainer *c, const mdns_draw_backend *be);
+/* `constrainer.region = None` (cachedconstrainer.py:104-105): the next draw builds a new region. */
+void mdns_constrainer_forget_region(mdns_constrainer *c);
+
+/* draw_constrained (hiermetriclearn.py:173-211).  live points: rows `ids` (int32 or int64 by
+ * ids_itemsize, K of them, in the caller's order) of pile_u f64[npile, ndim]; selection rows/M as in
+ * mdns_draw_backend.draw_begin.  Out: u f64[ndim] the accepted unit-cube point, x f64[ndim] its
+ * prior transform, *ntries the likelihood calls the reference would have made (its `ntoaccept`),
+ * fillbits uint64[ceil(M/64)].  Returns 0; on failure non-zero and mdns_host_last_error(). */
+int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, const mdns_prior *prior,
+                          const mdns_numpy_ops *np, void *mt19937_state,
+                          const double *pile_u, const void *ids, int ids_itemsize, int K,
+                          const int *rows, int M,
+                          double *u, double *x, long long *ntries, unsigned long long *fillbits);
+/* counters since creation: out[0] draws, [1] chunks, [2] candidates scored, [3] (candidate, data
+ * set) pairs scored, [4] regions built, [5] radius computations (K6), [6] membership calls (K3),
+ * [7] raw proposals */
+void mdns_constrainer_stats(const mdns_constrainer *c, long long *out8);
+const char *mdns_host_last_error(void);
+/* The cached second deviate of numpy's legacy Gaussian generator (legacy-distributions.c,
+ * `has_gauss` / `gauss`): the constrainer keeps it for the process like numpy's global RandomState
+ * does; callers that mix their own numpy.random.normal calls with native draws hand it over. */
+void mdns_host_rng_get_gauss(int *has_gauss, double *gauss);
+void mdns_host_rng_set_gauss(int has_gauss, double gauss);
+
+/* The backend of a Gaussian-line joint state on the GPU (libmdns_hip.so): the functions to put
+ * into mdns_draw_backend, user = the mdns_joint handle.  region_create = K6 + resident members
+ * (mdns_region_create_bootstrapped / mdns_region_create + mdns_region_set_radius), region_count =
+ * mdns_region_count, draw_chunk = mdns_joint_draw_gauss without the likelihood row. */
+void *mdns_backend_region_create(void *joint, const double *members, int K, int ndim,
+                                 const unsigned *packed, int nbootstraps, double *radius);
+void mdns_backend_region_destroy(void *joint, void *region);
+int mdns_backend_region_count(void *joint, void *region, const double *points, int n, int *counts);
+int mdns_backend_draw_begin(void *joint, const int *rows, int M);
+int mdns_backend_draw_chunk(void *joint, const double *params, int B, int *accepted,
+                            unsigned long long *fillbits, int *nscored);
+int mdns_backend_chunk_size(void *joint, int offered, int M, int hint);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,15 @@ ABI_SYMBOLS = (
     "mdns_joint_restore_live_dev", "mdns_joint_undo_advance_dev", "mdns_joint_live_dev",
     "mdns_groups_create", "mdns_groups_destroy", "mdns_groups_set_ids", "mdns_groups_get_ids",
     "mdns_groups_replace", "mdns_groups_components", "mdns_groups_labels", "mdns_groups_mean_rounds",
+    "mdns_backend_region_create", "mdns_backend_region_destroy", "mdns_backend_region_count",
+    "mdns_backend_draw_begin", "mdns_backend_draw_chunk", "mdns_backend_chunk_size",
+)
+
+#: the symbols of include/mdns.h Part 5 that live in libmdns_host.so (plain host code, no GPU)
+HOST_ABI_SYMBOLS = (
+    "mdns_constrainer_create", "mdns_constrainer_destroy", "mdns_constrainer_forget_region",
+    "mdns_constrainer_draw", "mdns_constrainer_stats", "mdns_host_last_error",
+    "mdns_host_rng_get_gauss", "mdns_host_rng_set_gauss",
 )
 
 #: mdns.h MDNS_JOINT_MAX_BATCH
@@ -142,6 +151,12 @@ def _declare(lib):
         "mdns_groups_components": (i, [vp, vp, i, C.c_longlong, vp, vp, vp, C.c_longlong, vp]),
         "mdns_groups_labels": (i, [vp, vp, vp]),
         "mdns_groups_mean_rounds": (d, [vp]),
+        "mdns_backend_region_create": (vp, [vp, vp, i, i, vp, i, vp]),
+        "mdns_backend_region_destroy": (None, [vp, vp]),
+        "mdns_backend_region_count": (i, [vp, vp, vp, i, vp]),
+        "mdns_backend_draw_begin": (i, [vp, vp, i]),
+        "mdns_backend_draw_chunk": (i, [vp, vp, i, vp, vp, vp]),
+        "mdns_backend_chunk_size": (i, [vp, i, i, i]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

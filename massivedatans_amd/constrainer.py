@@ -1,0 +1,357 @@
+"""One native call per constrained draw.
+
+``NativeConstrainer`` is the reference's ``MetricLearningFriendsConstrainer``
+(hiermetriclearn.py:27-211) with its whole ``draw_constrained`` -- rebuild policy, region
+construction with the bootstrap draws, candidate generators, prior transform, chunked accept
+loop -- behind ``mdns_constrainer_draw`` (include/mdns.h Part 5, csrc/host_constrainer.cpp).
+Python keeps what the reference keeps outside the constrainer: which constrainer serves which
+group of data sets (cachedconstrainer.py) and the sampler's bookkeeping.
+
+The random numbers come from numpy's own global legacy stream (its Mersenne-Twister state is
+stepped in place), so Python code before, between and after native draws sees the stream
+exactly where the reference would have left it.
+
+``NativeContext`` holds what all constrainers of a sampler share: the table of device entry
+points (``hip_backend``: libmdns_hip.so for a ``GaussJointState``; ``python_backend``: any
+joint state / member-set implementation in Python -- the CPU oracle in tests), the prior
+transform and the two numpy operations the constrainer leaves to numpy.
+"""
+import ctypes as C
+
+import numpy
+
+from . import _host, _lib
+
+MAX_DIM = 16
+
+_REGION_CREATE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int,
+                             C.POINTER(C.c_uint), C.c_int, C.POINTER(C.c_double))
+_REGION_DESTROY = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+_REGION_COUNT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int))
+_DRAW_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int)
+_DRAW_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int),
+                          C.POINTER(C.c_ulonglong), C.POINTER(C.c_int))
+_CHUNK_SIZE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+_CUSTOM_PRIOR = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
+_VEC_POW = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double)
+_FIT_METRIC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int,
+                          C.POINTER(C.c_double), C.POINTER(C.c_double))
+
+
+class DrawBackend(C.Structure):            # mdns_draw_backend
+    _fields_ = [("user", C.c_void_p), ("region_create", _REGION_CREATE), ("region_destroy", _REGION_DESTROY),
+                ("region_count", _REGION_COUNT), ("draw_begin", _DRAW_BEGIN), ("draw_chunk", _DRAW_CHUNK),
+                ("chunk_size", _CHUNK_SIZE)]
+
+
+class Prior(C.Structure):                  # mdns_prior
+    _fields_ = [("ndim", C.c_int), ("nparams", C.c_int), ("a", C.c_double * MAX_DIM), ("b", C.c_double * MAX_DIM),
+                ("pow10", C.c_int * MAX_DIM), ("kernel_pow10", C.c_int * MAX_DIM), ("custom", _CUSTOM_PRIOR),
+                ("user", C.c_void_p)]
+
+
+class NumpyOps(C.Structure):               # mdns_numpy_ops
+    _fields_ = [("user", C.c_void_p), ("vec_pow", _VEC_POW), ("fit_metric", _FIT_METRIC)]
+
+
+METRICS = {'none': 0, 'simplescaling': 1, 'truncatedscaling': 2}
+
+_HOST = None
+
+
+def host_lib():
+    """libmdns_host.so with the constrainer entry points declared, or None."""
+    global _HOST
+    if _HOST is None:
+        L = _host.lib()
+        if L is None or not hasattr(L, "mdns_constrainer_draw"):
+            _HOST = False
+        else:
+            L.mdns_constrainer_create.restype = C.c_void_p
+            L.mdns_constrainer_create.argtypes = [C.c_int] * 5
+            L.mdns_constrainer_destroy.restype = None
+            L.mdns_constrainer_destroy.argtypes = [C.c_void_p, C.c_void_p]
+            L.mdns_constrainer_forget_region.restype = None
+            L.mdns_constrainer_forget_region.argtypes = [C.c_void_p]
+            L.mdns_constrainer_draw.restype = C.c_int
+            L.mdns_constrainer_draw.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4
+            L.mdns_constrainer_stats.restype = None
+            L.mdns_constrainer_stats.argtypes = [C.c_void_p, C.c_void_p]
+            L.mdns_host_last_error.restype = C.c_char_p
+            L.mdns_host_last_error.argtypes = []
+            L.mdns_host_rng_get_gauss.restype = None
+            L.mdns_host_rng_get_gauss.argtypes = [C.c_void_p, C.c_void_p]
+            L.mdns_host_rng_set_gauss.restype = None
+            L.mdns_host_rng_set_gauss.argtypes = [C.c_int, C.c_double]
+            _HOST = L
+    return _HOST or None
+
+
+def available():
+    """The native constrainer can run: library built and numpy's global stream is an MT19937 whose
+    state the in-place stepping reproduces (checked once, massivedatans_amd/_host.py)."""
+    return host_lib() is not None and bool(_host._mt_state_address())
+
+
+def sample_py_prior():
+    """priortransform of sample.py:52-58 -- A = 10**(2u - 2), mu = 400u + 400, log10 sig = 2u -- and the
+    kernel's (A, mu, sig = 10**log_sig) of sample.py:103."""
+    p = Prior()
+    p.ndim, p.nparams = 3, 3
+    for k, (a, b, p10, k10) in enumerate(((2.0, -2.0, 1, 0), (400.0, 400.0, 0, 0), (2.0, 0.0, 0, 1))):
+        p.a[k], p.b[k], p.pow10[k], p.kernel_pow10[k] = a, b, p10, k10
+    return p
+
+
+def custom_prior(ndim, nparams, priortransform_batch, kernel_params):
+    """A problem definition kept in Python: ``priortransform_batch(us[B, ndim]) -> xs[B, ndim]`` and
+    ``kernel_params(xs) -> params[B, nparams]`` called once per chunk."""
+    def call(_user, u_ptr, B, x_ptr, p_ptr):
+        us = numpy.ctypeslib.as_array(u_ptr, (B, ndim))
+        xs = numpy.asarray(priortransform_batch(us), dtype=float)
+        numpy.ctypeslib.as_array(x_ptr, (B, ndim))[:] = xs
+        numpy.ctypeslib.as_array(p_ptr, (B, nparams))[:] = kernel_params(xs)
+    p = Prior()
+    p.ndim, p.nparams = ndim, nparams
+    p.custom = _CUSTOM_PRIOR(call)
+    p._keep = call
+    return p
+
+
+def _numpy_ops():
+    """The two operations whose numbers must be numpy's own (see include/mdns.h, mdns_numpy_ops)."""
+    from .clustering.sdml import SimpleScaling, TruncatedScaling
+
+    def vec_pow(_user, ptr, n, exponent):
+        a = numpy.ctypeslib.as_array(ptr, (n,))
+        a[:] = a ** exponent                                  # radfriendsregion.py:156
+
+    def fit_metric(_user, kind, u_ptr, K, ndim, mean_ptr, scale_ptr):
+        try:
+            u = numpy.ctypeslib.as_array(u_ptr, (K, ndim))
+            metric = SimpleScaling() if kind == 1 else TruncatedScaling()
+            metric.fit(u - numpy.mean(u, axis=0))             # hiermetriclearn.py:63-65,70-72
+            numpy.ctypeslib.as_array(mean_ptr, (ndim,))[:] = metric.mean
+            numpy.ctypeslib.as_array(scale_ptr, (ndim,))[:] = metric.scale
+            return 0
+        except Exception:       # noqa: BLE001 -- reported by the caller as a failed draw
+            return 1
+
+    ops = NumpyOps()
+    ops.vec_pow = _VEC_POW(vec_pow)
+    ops.fit_metric = _FIT_METRIC(fit_metric)
+    ops._keep = (vec_pow, fit_metric)
+    return ops
+
+
+def hip_backend(joint):
+    """The device entry points of libmdns_hip.so for a :class:`jointstate.GaussJointState`."""
+    lib = _lib.require_device()
+    be = DrawBackend()
+    be.user = joint._h
+    for field, proto, name in (("region_create", _REGION_CREATE, "mdns_backend_region_create"),
+                               ("region_destroy", _REGION_DESTROY, "mdns_backend_region_destroy"),
+                               ("region_count", _REGION_COUNT, "mdns_backend_region_count"),
+                               ("draw_begin", _DRAW_BEGIN, "mdns_backend_draw_begin"),
+                               ("draw_chunk", _DRAW_CHUNK, "mdns_backend_draw_chunk"),
+                               ("chunk_size", _CHUNK_SIZE, "mdns_backend_chunk_size")):
+        setattr(be, field, C.cast(getattr(lib, name), proto))
+    be._keep = joint
+    return be
+
+
+def python_backend(joint, member_set_factory=None):
+    """The same table over Python objects: ``joint`` with ``draw(params-less xs?)`` -- any joint state of
+    :mod:`massivedatans_amd.jointstate` -- and ``member_set_factory(members) -> object`` with
+    ``bootstrap_radius_packed(masks, n)``, ``set_radius(r)``, ``count(points)`` (default:
+    ``clustering.neighbors.MemberSet``, resolved at call time so that tests can patch it)."""
+    from .clustering import neighbors
+    regions = {}
+    state = {"rows": None, "M": 0, "next": 1}
+
+    def region_create(_user, members_ptr, K, ndim, packed_ptr, nboot, radius_ptr):
+        try:
+            members = numpy.ctypeslib.as_array(members_ptr, (K, ndim)).copy()
+            factory = member_set_factory or neighbors.MemberSet
+            if packed_ptr:
+                masks = numpy.ctypeslib.as_array(packed_ptr, (K,)).astype(numpy.uint32)
+                if hasattr(factory, "bootstrapped"):
+                    ms, r = factory.bootstrapped(members, masks, nboot)
+                else:
+                    ms = factory(members)
+                    r = ms.bootstrap_radius_packed(masks, nboot)
+                radius_ptr[0] = r
+            else:
+                ms = factory(members)
+                ms.set_radius(radius_ptr[0])
+            key = state["next"]
+            state["next"] += 1
+            regions[key] = ms
+            return key
+        except Exception:       # noqa: BLE001
+            return None
+
+    def region_destroy(_user, key):
+        ms = regions.pop(key, None)
+        if ms is not None and hasattr(ms, "close"):
+            ms.close()
+
+    def region_count(_user, key, points_ptr, n, counts_ptr):
+        try:
+            ms = regions[key]
+            points = numpy.ctypeslib.as_array(points_ptr, (n, ms_ndim(ms)))
+            numpy.ctypeslib.as_array(counts_ptr, (n,))[:] = ms.count(points)
+            return 0
+        except Exception:       # noqa: BLE001
+            return 1
+
+    def ms_ndim(ms):
+        return ms.ndim if hasattr(ms, "ndim") else numpy.shape(ms.members)[1]
+
+    def draw_begin(_user, rows_ptr, M):
+        state["rows"] = numpy.ctypeslib.as_array(rows_ptr, (M,)).copy() if rows_ptr else None
+        state["M"] = M
+        return 0
+
+    def draw_chunk(_user, params_ptr, B, accepted_ptr, bits_ptr, nscored_ptr):
+        try:
+            nparams = joint_nparams(joint)
+            params = numpy.ctypeslib.as_array(params_ptr, (B, nparams)).copy()
+            idx, _, beats, nscored = joint.draw_params(params, state["rows"])
+            accepted_ptr[0] = idx
+            nscored_ptr[0] = nscored
+            if idx >= 0:
+                M = state["M"]
+                words = numpy.zeros((M + 63) // 64, dtype=numpy.uint64)
+                packed = numpy.packbits(numpy.asarray(beats, dtype=numpy.uint8), bitorder='little')
+                words.view(numpy.uint8)[:len(packed)] = packed
+                numpy.ctypeslib.as_array(bits_ptr, (len(words),))[:] = words
+            return 0
+        except Exception:       # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def joint_nparams(j):
+        return getattr(j, "nparams", 3)
+
+    def chunk_size(_user, offered, M, hint):
+        return int(joint.chunk_size(offered, M, hint))
+
+    be = DrawBackend()
+    be.user = None
+    be.region_create = _REGION_CREATE(region_create)
+    be.region_destroy = _REGION_DESTROY(region_destroy)
+    be.region_count = _REGION_COUNT(region_count)
+    be.draw_begin = _DRAW_BEGIN(draw_begin)
+    be.draw_chunk = _DRAW_CHUNK(draw_chunk)
+    be.chunk_size = _CHUNK_SIZE(chunk_size)
+    be._keep = (region_create, region_destroy, region_count, draw_begin, draw_chunk, chunk_size, regions, joint)
+    return be
+
+
+class NativeContext(object):
+    """What the constrainers of one sampler share."""
+
+    def __init__(self, backend, prior, ndata):
+        self.lib = host_lib()
+        if self.lib is None:
+            raise RuntimeError("libmdns_host.so lacks the native constrainer (make -C massivedatans_amd/csrc)")
+        self.mt = _host._mt_state_address()
+        if not self.mt:
+            raise RuntimeError("numpy's global random stream cannot be stepped natively (not an MT19937?)")
+        self.backend, self.prior, self.ops = backend, prior, _numpy_ops()
+        self.ndim = int(prior.ndim)
+        self._be, self._prior, self._ops = C.addressof(backend), C.addressof(prior), C.addressof(self.ops)
+        self.u = numpy.empty(self.ndim)
+        self.x = numpy.empty(self.ndim)
+        self.bits = numpy.zeros((int(ndata) + 63) // 64 + 1, dtype=numpy.uint64)
+        self.ntries = C.c_longlong(0)
+        self._u, self._x, self._bits, self._ntries = self.u.ctypes.data, self.x.ctypes.data, self.bits.ctypes.data, C.addressof(self.ntries)
+        self.sync_gauss_from_numpy()
+
+    # the cached second Gaussian deviate of numpy's legacy generator travels with the stream
+    def sync_gauss_from_numpy(self):
+        st = numpy.random.get_state(legacy=False)
+        self.lib.mdns_host_rng_set_gauss(int(st["has_gauss"]), float(st["gauss"]))
+
+    def sync_gauss_to_numpy(self):
+        has, val = C.c_int(0), C.c_double(0)
+        self.lib.mdns_host_rng_get_gauss(C.addressof(has), C.addressof(val))
+        st = numpy.random.get_state(legacy=False)
+        if int(st["has_gauss"]) != has.value or (has.value and float(st["gauss"]) != val.value):
+            st["has_gauss"], st["gauss"] = has.value, val.value
+            numpy.random.set_state(st)
+
+    def fresh_constrainer(self, **kwargs):
+        return NativeConstrainer(self, **kwargs)
+
+
+class NativeConstrainer(object):
+    """Same constructor arguments and attributes the rest of the host code touches as
+    ``hiermetriclearn.MetricLearningFriendsConstrainer``; the draw itself is
+    :meth:`draw_native` (the sampler calls it instead of ``draw_constrained(**kwargs)``)."""
+
+    def __init__(self, context, metriclearner, rebuild_every=50, metric_rebuild_every=50, verbose=False,
+                 keep_phantom_points=False, optimize_phantom_points=False, force_shrink=False):
+        self.context = context
+        self.metriclearner = metriclearner
+        self.rebuild_every, self.metric_rebuild_every = int(rebuild_every), int(metric_rebuild_every)
+        self.force_shrink = force_shrink
+        self.sampler = None
+        self._lib = context.lib
+        self._h = self._lib.mdns_constrainer_create(context.ndim, METRICS[metriclearner], self.rebuild_every,
+                                                    self.metric_rebuild_every, 1 if force_shrink else 0)
+        if not self._h:
+            raise RuntimeError("mdns_constrainer_create: " + self._lib.mdns_host_last_error().decode())
+
+    # `constrainers[i].region = None` (cachedconstrainer.py:104-105) drops the region
+    @property
+    def region(self):
+        raise AttributeError("the region of a native constrainer lives in the library")
+
+    @region.setter
+    def region(self, value):
+        if value is not None:
+            raise ValueError("only None can be assigned")
+        self._lib.mdns_constrainer_forget_region(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mdns_constrainer_destroy(self._h, self.context._be)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # noqa: BLE001
+            pass
+
+    def stats(self):
+        out = (C.c_longlong * 8)()
+        self._lib.mdns_constrainer_stats(self._h, out)
+        return dict(zip(("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals"), list(out)))
+
+    def draw_native(self, pile_u, ids, rows, M):
+        """One constrained draw: live points ``pile_u[ids]``, data sets ``rows`` (int32, ascending
+        original indices; None = all ``M``).  Returns ``(u, x, tries, fill bits uint64[ceil(M/64)])``;
+        u, x and the bits are views of buffers that the next draw overwrites."""
+        ctx = self.context
+        if ids.dtype.itemsize not in (4, 8) or not ids.flags.c_contiguous:
+            ids = numpy.ascontiguousarray(ids, dtype=numpy.int64)
+        rc = self._lib.mdns_constrainer_draw(self._h, ctx._be, ctx._prior, ctx._ops, ctx.mt, pile_u.ctypes.data,
+                                             ids.ctypes.data, ids.dtype.itemsize, len(ids),
+                                             rows.ctypes.data if rows is not None else None, M,
+                                             ctx._u, ctx._x, ctx._ntries, ctx._bits)
+        if rc != 0:
+            raise RuntimeError("mdns_constrainer_draw failed: %s | %s"
+                               % (self._lib.mdns_host_last_error().decode(), _lib.last_error() if _lib._lib is not None else ""))
+        return ctx.u, ctx.x, ctx.ntries.value, ctx.bits
+
+    def draw_constrained(self, **kwargs):
+        raise RuntimeError("a native constrainer is driven through draw_native (MultiNestedSampler does so when "
+                           "it is built with native=...)")
+
+
+__all__ = ['NativeConstrainer', 'NativeContext', 'available', 'hip_backend', 'python_backend', 'sample_py_prior',
+           'custom_prior']

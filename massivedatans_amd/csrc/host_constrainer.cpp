@@ -1,0 +1,788 @@
+// The MLFriends constrainer of the reference behind ONE native call per constrained draw
+// (include/mdns.h, Part 5).  Plain host C++: no GPU code here -- the kernels are reached through
+// the mdns_draw_backend table (libmdns_hip.so on a GPU box, the CPU oracle in tests).
+//
+// What is restated, and from where (paths under the reference checkout):
+//   hiermetriclearn.py:27-211        MetricLearningFriendsConstrainer: rebuild policy, region
+//                                    construction, candidate generator, accept loop
+//   clustering/radfriendsregion.py:58-182   RadFriendsRegion: bootstrap radius, bounding box,
+//                                    box / ball proposals
+//   clustering/sdml.py:25-88         the axis-scaling metrics (their FIT is left to numpy through
+//                                    mdns_numpy_ops: numpy's log2 is not the C library's)
+//   clustering/neighbors.py:170-177  the bootstrap choice
+// The sequence of random numbers is part of the results: every draw is taken
+// from numpy's own mt19937 state with numpy's LEGACY algorithms (numpy/random/src/legacy/
+// legacy-distributions.c, distributions.c) in the reference's call order, so the global stream is
+// left exactly where the reference would leave it.  Floating-point operations are written one per
+// statement in numpy's order (this file is compiled with -ffp-contract=off).
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <vector>
+
+#include "mdns.h"
+
+extern "C" int mdns_host_bootstrap_masks_mt(void *state, int64_t K, int rounds, uint32_t *masks);
+
+namespace {
+
+char g_error[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_error, sizeof g_error, fmt, ap);
+	va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------
+// numpy's legacy stream on its own Mersenne Twister state
+// ---------------------------------------------------------------------------------------
+struct MT { uint32_t key[624]; int pos; };        // numpy/random/src/mt19937/mt19937.h
+
+void mt_refill(MT *s)
+{
+	const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
+	uint32_t y;
+	int i;
+	for (i = 0; i < 624 - 397; i++) {
+		y = (s->key[i] & UP) | (s->key[i + 1] & LO);
+		s->key[i] = s->key[i + 397] ^ (y >> 1) ^ (-(y & 1) & A);
+	}
+	for (; i < 623; i++) {
+		y = (s->key[i] & UP) | (s->key[i + 1] & LO);
+		s->key[i] = s->key[i + (397 - 624)] ^ (y >> 1) ^ (-(y & 1) & A);
+	}
+	y = (s->key[623] & UP) | (s->key[0] & LO);
+	s->key[623] = s->key[396] ^ (y >> 1) ^ (-(y & 1) & A);
+	s->pos = 0;
+}
+
+inline uint32_t mt_next(MT *s)
+{
+	if (s->pos == 624) mt_refill(s);
+	uint32_t y = s->key[s->pos++];
+	y ^= (y >> 11);
+	y ^= (y << 7) & 0x9d2c5680u;
+	y ^= (y << 15) & 0xefc60000u;
+	y ^= (y >> 18);
+	return y;
+}
+
+// mt19937_next_double: 53 bits from two draws
+inline double mt_double(MT *s)
+{
+	const int32_t a = (int32_t) (mt_next(s) >> 5), b = (int32_t) (mt_next(s) >> 6);
+	return (a * 67108864.0 + b) / 9007199254740992.0;
+}
+
+// legacy_gauss keeps the second deviate of a pair (aug_bitgen_t.has_gauss / .gauss): one cache per
+// process, like the global RandomState's
+int g_has_gauss = 0;
+double g_gauss = 0.0;
+
+inline double legacy_gauss(MT *s)
+{
+	if (g_has_gauss) {
+		const double t = g_gauss;
+		g_has_gauss = 0;
+		g_gauss = 0.0;
+		return t;
+	}
+	double f, x1, x2, r2;
+	do {
+		x1 = 2.0 * mt_double(s) - 1.0;
+		x2 = 2.0 * mt_double(s) - 1.0;
+		r2 = x1 * x1 + x2 * x2;
+	} while (r2 >= 1.0 || r2 == 0.0);
+	f = std::sqrt(-2.0 * std::log(r2) / r2);
+	g_gauss = f * x1;
+	g_has_gauss = 1;
+	return f * x2;
+}
+
+// RandomState.randint(0, K, size=n) (random_bounded_uint64_fill, masked rejection, 32-bit draws)
+void legacy_randint(MT *s, int64_t K, int n, int32_t *out)
+{
+	const uint32_t top = (uint32_t) (K - 1);
+	if (top == 0) { for (int i = 0; i < n; i++) out[i] = 0; return; }
+	uint32_t cover = top;
+	cover |= cover >> 1; cover |= cover >> 2; cover |= cover >> 4; cover |= cover >> 8; cover |= cover >> 16;
+	for (int i = 0; i < n; i++) {
+		uint32_t v;
+		do { v = mt_next(s) & cover; } while (v > top);
+		out[i] = (int32_t) v;
+	}
+}
+
+// numpy's pairwise summation of a contiguous run (numpy/_core/src/umath/loops_utils.h.src):
+// what `a.sum(axis=-1)` performs per row, added to the identity 0.0
+double pairwise_sum(const double *a, int n)
+{
+	if (n < 8) {
+		double res = 0.;
+		for (int i = 0; i < n; i++) res += a[i];
+		return res;
+	}
+	if (n <= 128) {
+		double r[8];
+		for (int j = 0; j < 8; j++) r[j] = a[j];
+		int i;
+		for (i = 8; i < n - (n % 8); i += 8)
+			for (int j = 0; j < 8; j++) r[j] += a[i + j];
+		double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+		for (; i < n; i++) res += a[i];
+		return res;
+	}
+	int n2 = n / 2;
+	n2 -= n2 % 8;
+	return pairwise_sum(a, n2) + pairwise_sum(a + n2, n - n2);
+}
+
+// ---------------------------------------------------------------------------------------
+// metric (clustering/sdml.py)
+// ---------------------------------------------------------------------------------------
+struct Metric {
+	bool identity = true;
+	std::vector<double> mean, scale;
+	// (x - mean) / scale
+	void transform(const double *x, int n, int ndim, double *w) const
+	{
+		if (identity) { memcpy(w, x, (size_t) n * ndim * sizeof(double)); return; }
+		for (int i = 0; i < n; i++)
+			for (int k = 0; k < ndim; k++) {
+				const double d = x[(size_t) i * ndim + k] - mean[k];
+				w[(size_t) i * ndim + k] = d / scale[k];
+			}
+	}
+	// y * scale + mean
+	void untransform(const double *y, int n, int ndim, double *x) const
+	{
+		if (identity) { memcpy(x, y, (size_t) n * ndim * sizeof(double)); return; }
+		for (int i = 0; i < n; i++)
+			for (int k = 0; k < ndim; k++) {
+				const double p = y[(size_t) i * ndim + k] * scale[k];
+				x[(size_t) i * ndim + k] = p + mean[k];
+			}
+	}
+};
+
+// ---------------------------------------------------------------------------------------
+// region (clustering/radfriendsregion.py)
+// ---------------------------------------------------------------------------------------
+struct Counters {
+	long long draws = 0, chunks = 0, candidates = 0, pairs = 0, regions = 0, radii = 0, counts = 0, proposals = 0;
+};
+
+struct Region {
+	std::vector<double> members;          // [K, ndim], the metric's coordinates
+	int K = 0, ndim = 0;
+	bool has_radius = false;
+	double radius = 0;
+	std::vector<uint32_t> masks;          // the bootstrap choice, drawn at construction, until K6 has run
+	int nbootstraps = 10;
+	void *handle = nullptr;               // the backend's region (members resident), made when first needed
+	const mdns_draw_backend *be = nullptr;
+	std::vector<double> lo, hi;
+	bool has_box = false;
+	Counters *stat = nullptr;
+
+	~Region() { if (handle && be) be->region_destroy(be->user, handle); }
+
+	// `maxdistance` of the reference: the bootstrapped radius, computed when first asked for
+	bool maxdistance(double *out)
+	{
+		if (!has_radius) {
+			double r = 0;
+			handle = be->region_create(be->user, members.data(), K, ndim, masks.data(), nbootstraps, &r);
+			if (!handle) { set_error("region_create (K6) failed for %d points", K); return false; }
+			radius = r;
+			has_radius = true;
+			std::vector<uint32_t>().swap(masks);
+			if (stat) stat->radii++;
+		}
+		*out = radius;
+		return true;
+	}
+	bool member_set()
+	{
+		double r;
+		if (!maxdistance(&r)) return false;
+		if (!handle) {
+			handle = be->region_create(be->user, members.data(), K, ndim, nullptr, 0, &r);
+			if (!handle) { set_error("region_create failed for %d points", K); return false; }
+		}
+		return true;
+	}
+	bool count(const double *points, int n, int *counts)
+	{
+		if (!member_set()) return false;
+		if (stat) stat->counts++;
+		if (be->region_count(be->user, handle, points, n, counts) != 0) { set_error("region_count failed"); return false; }
+		return true;
+	}
+	// lo = min(members) - maxdistance, hi = max(members) + maxdistance (radfriendsregion.py:69-70)
+	bool box()
+	{
+		if (has_box) return true;
+		double r;
+		if (!maxdistance(&r)) return false;
+		lo.assign(ndim, 0.0);
+		hi.assign(ndim, 0.0);
+		for (int k = 0; k < ndim; k++) { lo[k] = members[k]; hi[k] = members[k]; }
+		for (int i = 1; i < K; i++)
+			for (int k = 0; k < ndim; k++) {
+				const double v = members[(size_t) i * ndim + k];
+				if (v < lo[k]) lo[k] = v;
+				if (v > hi[k]) hi[k] = v;
+			}
+		for (int k = 0; k < ndim; k++) { lo[k] = lo[k] - r; hi[k] = hi[k] + r; }
+		has_box = true;
+		return true;
+	}
+};
+
+typedef std::shared_ptr<Region> RegionRef;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// the constrainer (hiermetriclearn.py)
+// ---------------------------------------------------------------------------------------
+struct mdns_constrainer {
+	int ndim = 0;
+	int metriclearner = MDNS_METRIC_TRUNCATEDSCALING;
+	int rebuild_every = 50, metric_rebuild_every = 50;
+	bool force_shrink = false;
+	Metric metric;
+	RegionRef region;                      // `self.region` (may be empty: None)
+	bool has_prev = false;                 // `self.prev_maxdistance is not None`
+	double prev_maxdistance = 0;
+	bool has_last = false;                 // `self.last_cluster_points`
+	std::vector<double> last_cluster_points;
+	int last_K = 0;
+	long long iter_since_metric_rebuild = 0, ndraws_since_rebuild = 0;
+	bool direct_draws_efficient = true;
+	long long last_ntoaccept = 1;
+	// the generator of hiermetriclearn.py:104-137 with the one of radfriendsregion.py:117-182 inside,
+	// as a state machine
+	bool has_generator = false;
+	enum Phase { START_ROUND, BOX, BALL, COIN } phase = START_ROUND;
+	RegionRef gen_region;                  // the region whose generate() is running
+	double gen_maxdistance = 0;            // captured at its first step (radfriendsregion.py:118-120)
+	bool gen_started = false;
+	long long ntotal = 0, spent = 0, proposed = 0;
+	// candidates proposed and not yet consumed
+	std::vector<double> buf;
+	int buf_n = 0, buf_pos = 0;
+	long long buf_ntotal = 0;
+	bool has_buf = false;
+	Counters stat;
+	// scratch
+	std::vector<double> us, ws, dir, rad, coin, xs, params, wtmp;
+	std::vector<int32_t> idx;
+	std::vector<int> counts;
+};
+
+namespace {
+
+const int REGION_BATCH = 10000;          // hiermetriclearn.py:106
+const int BATCH = 1000;                  // radfriendsregion.py:124
+const double CUBE_PROBABILITY = 0.1;     // hiermetriclearn.py:126
+
+struct Env {
+	mdns_constrainer *c;
+	const mdns_draw_backend *be;
+	const mdns_prior *prior;
+	const mdns_numpy_ops *np;
+	MT *mt;
+};
+
+// RadFriendsRegion(members, maxdistance=None | value) (radfriendsregion.py:59-70)
+RegionRef new_region(Env &e, const double *members, int K, bool given, double maxdistance)
+{
+	RegionRef r = std::make_shared<Region>();
+	r->members.assign(members, members + (size_t) K * e.c->ndim);
+	r->K = K;
+	r->ndim = e.c->ndim;
+	r->be = e.be;
+	r->stat = &e.c->stat;
+	e.c->stat.regions++;
+	if (given) {
+		r->has_radius = true;
+		r->radius = maxdistance;
+	} else {
+		// nbootstraps x numpy.random.choice(arange(K), size=K) NOW (neighbors.py:173-174): the
+		// position of these draws in the stream is part of the results; K6 itself, which draws
+		// nothing, waits until somebody asks for the radius
+		r->masks.assign(K, 0u);
+		if (mdns_host_bootstrap_masks_mt(e.mt, K, r->nbootstraps, r->masks.data()) != 0) {
+			set_error("bootstrap choice for %d points failed", K);
+			return RegionRef();
+		}
+	}
+	return r;
+}
+
+// `force_shrink`: a rebuilt region may not have a larger radius than the one it replaces
+// (hiermetriclearn.py:53-54,88-90); `prev_maxdistance is None` counts as smaller than anything
+// (Python 2) and then the replacement draws its own bootstrap choice
+RegionRef never_grow(Env &e, RegionRef region, const double *members_old_metric, int K)
+{
+	mdns_constrainer *c = e.c;
+	if (!c->force_shrink) return region;
+	if (c->has_prev) {
+		double r;
+		if (!region->maxdistance(&r)) return RegionRef();
+		if (!(r > c->prev_maxdistance)) return region;
+		return new_region(e, members_old_metric, K, true, c->prev_maxdistance);
+	}
+	return new_region(e, members_old_metric, K, false, 0);
+}
+
+// cluster(u, keepMetric) (hiermetriclearn.py:48-92)
+bool cluster(Env &e, const double *u, int K, bool keepMetric)
+{
+	mdns_constrainer *c = e.c;
+	const int ndim = c->ndim;
+	std::vector<double> w_old((size_t) K * ndim);
+	c->metric.transform(u, K, ndim, w_old.data());
+	RegionRef region;
+	if (keepMetric) {
+		region = new_region(e, w_old.data(), K, false, 0);
+		if (!region) return false;
+		region = never_grow(e, region, w_old.data(), K);
+		if (!region) return false;
+	} else {
+		bool changed = false;
+		if (c->metriclearner != MDNS_METRIC_NONE) {
+			Metric m;
+			m.identity = false;
+			m.mean.assign(ndim, 0.0);
+			m.scale.assign(ndim, 1.0);
+			if (!e.np || !e.np->fit_metric ||
+			    e.np->fit_metric(e.np->user, c->metriclearner, u, K, ndim, m.mean.data(), m.scale.data()) != 0) {
+				set_error("fit_metric failed");
+				return false;
+			}
+			if (c->metriclearner == MDNS_METRIC_SIMPLESCALING) changed = true;
+			else {
+				changed = c->metric.identity;
+				if (!changed)
+					for (int k = 0; k < ndim; k++) if (c->metric.scale[k] != m.scale[k]) changed = true;
+			}
+			c->metric = m;
+		}
+		std::vector<double> w_new((size_t) K * ndim);
+		c->metric.transform(u, K, ndim, w_new.data());
+		region = new_region(e, w_new.data(), K, false, 0);
+		if (!region) return false;
+		// only a region in the SAME metric is comparable with the previous radius
+		if (!changed && c->has_prev) {
+			region = never_grow(e, region, w_old.data(), K);
+			if (!region) return false;
+		}
+	}
+	c->region = region;
+	double r;
+	if (!region->maxdistance(&r)) return false;
+	c->prev_maxdistance = r;
+	c->has_prev = true;
+	return true;
+}
+
+void reset_buffer(mdns_constrainer *c) { c->has_buf = false; c->buf_n = 0; c->buf_pos = 0; c->buf_ntotal = 0; }
+
+// rebuild(u, keepMetric) (hiermetriclearn.py:139-150)
+bool rebuild(Env &e, const double *u, int K, bool keepMetric)
+{
+	mdns_constrainer *c = e.c;
+	const size_t n = (size_t) K * c->ndim;
+	if (c->has_last && c->last_K == K && memcmp(c->last_cluster_points.data(), u, n * sizeof(double)) == 0) {
+		// (memcmp equality is numpy's element-wise == for the finite unit-cube points of a pile)
+		return true;                        // identical live points: keep region AND generator
+	}
+	if (!cluster(e, u, K, keepMetric)) return false;
+	c->last_cluster_points.assign(u, u + n);
+	c->last_K = K;
+	c->has_last = true;
+	c->has_generator = true;
+	c->phase = mdns_constrainer::START_ROUND;
+	c->gen_region.reset();
+	c->gen_started = false;
+	c->ntotal = 0;
+	reset_buffer(c);
+	return true;
+}
+
+// hands the candidates ws[n, ndim] (metric coordinates) of one region.generate() yield to the outer
+// generator (hiermetriclearn.py:111-119); true when that yields a batch
+bool deliver(Env &e, const double *ws, int n, long long nspent)
+{
+	mdns_constrainer *c = e.c;
+	const int ndim = c->ndim;
+	c->wtmp.resize((size_t) n * ndim);
+	c->metric.untransform(ws, n, ndim, c->wtmp.data());
+	c->ntotal = c->ntotal + nspent;
+	c->buf.clear();
+	int kept = 0;
+	for (int i = 0; i < n; i++) {
+		bool inside = true;
+		for (int k = 0; k < ndim; k++) {
+			const double v = c->wtmp[(size_t) i * ndim + k];
+			if (!(v < 1 && v > 0)) inside = false;
+		}
+		if (inside) {
+			c->buf.insert(c->buf.end(), c->wtmp.begin() + (size_t) i * ndim, c->wtmp.begin() + (size_t) (i + 1) * ndim);
+			kept++;
+		}
+	}
+	if (!kept) return false;
+	c->buf_n = kept;
+	c->buf_pos = 0;
+	c->buf_ntotal = c->ntotal;
+	c->has_buf = true;
+	c->ntotal = 0;
+	return true;
+}
+
+// next(self.generator): fills the buffer with the next batch of candidates (consumes RNG, exactly
+// on demand)
+bool next_batch(Env &e)
+{
+	mdns_constrainer *c = e.c;
+	const int ndim = c->ndim, N = BATCH;
+	if (!c->has_generator) { set_error("draw without a generator"); return false; }
+	for (;;) {
+		switch (c->phase) {
+		case mdns_constrainer::START_ROUND:
+			if (ndim < 40) {
+				if (!c->region) { set_error("the constrainer's region was dropped while its generator is in use (the reference raises AttributeError here)"); return false; }
+				c->gen_region = c->region;
+				c->gen_started = false;
+				c->spent = 0;
+				c->proposed = 0;
+				c->phase = mdns_constrainer::BOX;
+			} else c->phase = mdns_constrainer::COIN;
+			break;
+		case mdns_constrainer::BOX: {
+			Region *r = c->gen_region.get();
+			if (!c->gen_started) {
+				// like the reference, the ball proposals keep the members and the radius the generator
+				// started with (radfriendsregion.py:118-120)
+				if (!r->maxdistance(&c->gen_maxdistance)) return false;
+				c->gen_started = true;
+			}
+			if (!(c->proposed < REGION_BATCH)) {
+				c->gen_region.reset();
+				c->phase = mdns_constrainer::COIN;
+				break;
+			}
+			c->spent += N;
+			c->proposed += N;
+			c->stat.proposals += N;
+			if (!r->box()) return false;
+			// numpy.random.uniform(lo, hi, size=(N, ndim)): lo + (hi - lo) * double, row by row
+			c->us.resize((size_t) N * ndim);
+			double range[MDNS_MAX_DIM];
+			for (int k = 0; k < ndim; k++) range[k] = r->hi[k] - r->lo[k];
+			for (int i = 0; i < N; i++)
+				for (int k = 0; k < ndim; k++) {
+					const double t = range[k] * mt_double(e.mt);
+					c->us[(size_t) i * ndim + k] = r->lo[k] + t;
+				}
+			c->counts.resize(N);
+			if (!r->count(c->us.data(), N, c->counts.data())) return false;
+			c->phase = mdns_constrainer::BALL;
+			c->ws.clear();
+			int n = 0;
+			for (int i = 0; i < N; i++)
+				if (c->counts[i] > 0) {
+					c->ws.insert(c->ws.end(), c->us.begin() + (size_t) i * ndim, c->us.begin() + (size_t) (i + 1) * ndim);
+					n++;
+				}
+			if (n) {
+				const long long sp = c->spent;
+				c->spent = 0;
+				if (deliver(e, c->ws.data(), n, sp)) return true;
+			}
+			break;
+		}
+		case mdns_constrainer::BALL: {
+			Region *r = c->gen_region.get();
+			// members[numpy.random.randint(0, K, N)]
+			c->idx.resize(N);
+			legacy_randint(e.mt, r->K, N, c->idx.data());
+			c->spent += N;
+			c->proposed += N;
+			c->stat.proposals += N;
+			// direction = normal(0, 1, (N, ndim)); direction / sqrt((direction ** 2).sum(axis=1))
+			c->dir.resize((size_t) N * ndim);
+			for (size_t t = 0; t < (size_t) N * ndim; t++) {
+				const double g = 1.0 * legacy_gauss(e.mt);
+				c->dir[t] = 0.0 + g;
+			}
+			double sq[MDNS_MAX_DIM];
+			for (int i = 0; i < N; i++) {
+				double *d = &c->dir[(size_t) i * ndim];
+				for (int k = 0; k < ndim; k++) sq[k] = d[k] * d[k];
+				const double s = 0.0 + pairwise_sum(sq, ndim);
+				const double norm = std::sqrt(s);
+				for (int k = 0; k < ndim; k++) d[k] = d[k] / norm;
+			}
+			// radius = maxdistance * uniform(0, 1, (N, 1)) ** (1. / ndim)
+			c->rad.resize(N);
+			for (int i = 0; i < N; i++) {
+				const double t = 1.0 * mt_double(e.mt);
+				c->rad[i] = 0.0 + t;
+			}
+			// numpy's scalar-exponent fast paths: ** 1.0 leaves the values, ** 0.5 is sqrt
+			const double expo = 1. / ndim;
+			if (expo == 1.0) {
+			} else if (expo == 0.5) {
+				for (int i = 0; i < N; i++) c->rad[i] = std::sqrt(c->rad[i]);
+			} else {
+				if (!e.np || !e.np->vec_pow) { set_error("vec_pow missing"); return false; }
+				e.np->vec_pow(e.np->user, c->rad.data(), N, expo);
+			}
+			for (int i = 0; i < N; i++) c->rad[i] = c->gen_maxdistance * c->rad[i];
+			// us = centres + direction * radius
+			c->us.resize((size_t) N * ndim);
+			for (int i = 0; i < N; i++)
+				for (int k = 0; k < ndim; k++) {
+					const double p = c->dir[(size_t) i * ndim + k] * c->rad[i];
+					c->us[(size_t) i * ndim + k] = r->members[(size_t) c->idx[i] * ndim + k] + p;
+				}
+			c->counts.resize(N);
+			if (!r->count(c->us.data(), N, c->counts.data())) return false;
+			// accept = uniform(size=N) < 1. / nnear
+			c->ws.clear();
+			int n = 0;
+			for (int i = 0; i < N; i++) {
+				const double t = 1.0 * mt_double(e.mt);
+				const double coin = 0.0 + t;
+				const double inv = 1. / (double) c->counts[i];          // 1/0 = inf: accepted (never occurs: the centre is within reach)
+				if (coin < inv) {
+					c->ws.insert(c->ws.end(), c->us.begin() + (size_t) i * ndim, c->us.begin() + (size_t) (i + 1) * ndim);
+					n++;
+				}
+			}
+			c->phase = mdns_constrainer::BOX;
+			if (n) {
+				const long long sp = c->spent;
+				c->spent = 0;
+				if (deliver(e, c->ws.data(), n, sp)) return true;
+			}
+			break;
+		}
+		case mdns_constrainer::COIN: {
+			c->phase = mdns_constrainer::START_ROUND;
+			const double t = 1.0 * mt_double(e.mt);
+			const double coin = 0.0 + t;
+			if (coin < CUBE_PROBABILITY) {
+				// occasionally propose from the whole unit cube (hiermetriclearn.py:126-137)
+				const int NN = REGION_BATCH;
+				c->ntotal = c->ntotal + NN;
+				c->stat.proposals += NN;
+				c->us.resize((size_t) NN * ndim);
+				for (size_t q = 0; q < (size_t) NN * ndim; q++) {
+					const double v = 1.0 * mt_double(e.mt);
+					c->us[q] = 0.0 + v;
+				}
+				if (!c->region) { set_error("the constrainer's region was dropped while its generator is in use"); return false; }
+				c->ws.resize((size_t) NN * ndim);
+				c->metric.transform(c->us.data(), NN, ndim, c->ws.data());
+				c->counts.resize(NN);
+				if (!c->region->count(c->ws.data(), NN, c->counts.data())) return false;
+				c->buf.clear();
+				int n = 0;
+				for (int i = 0; i < NN; i++)
+					if (c->counts[i] > 0) {
+						c->buf.insert(c->buf.end(), c->us.begin() + (size_t) i * ndim, c->us.begin() + (size_t) (i + 1) * ndim);
+						n++;
+					}
+				if (n) {
+					c->buf_n = n;
+					c->buf_pos = 0;
+					c->buf_ntotal = c->ntotal;
+					c->has_buf = true;
+					c->ntotal = 0;
+					return true;
+				}
+			}
+			break;
+		}
+		}
+	}
+}
+
+// priortransform + kernel parameters of candidates us[B, ndim]
+void transform(const mdns_prior *p, const double *us, int B, double *xs, double *params)
+{
+	if (p->custom) { p->custom(p->user, us, B, xs, params); return; }
+	const int ndim = p->ndim;
+	for (int i = 0; i < B; i++)
+		for (int k = 0; k < ndim; k++) {
+			double v = p->a[k] * us[(size_t) i * ndim + k];
+			if (p->b[k] != 0.0) v = v + p->b[k];
+			if (p->pow10[k]) v = std::pow(10.0, v);
+			xs[(size_t) i * ndim + k] = v;
+			if (k < p->nparams) params[(size_t) i * p->nparams + k] = p->kernel_pow10[k] ? std::pow(10.0, v) : v;
+		}
+}
+
+}  // namespace
+
+extern "C" const char *mdns_host_last_error(void) { return g_error; }
+
+extern "C" void mdns_host_rng_get_gauss(int *has_gauss, double *gauss)
+{
+	if (has_gauss) *has_gauss = g_has_gauss;
+	if (gauss) *gauss = g_gauss;
+}
+
+extern "C" void mdns_host_rng_set_gauss(int has_gauss, double gauss)
+{
+	g_has_gauss = has_gauss ? 1 : 0;
+	g_gauss = has_gauss ? gauss : 0.0;
+}
+
+extern "C" mdns_constrainer *mdns_constrainer_create(int ndim, int metriclearner, int rebuild_every,
+                                                     int metric_rebuild_every, int force_shrink)
+{
+	if (ndim <= 0 || ndim > MDNS_MAX_DIM || metriclearner < 0 || metriclearner > 2) {
+		set_error("mdns_constrainer_create: ndim=%d (1..%d), metriclearner=%d", ndim, MDNS_MAX_DIM, metriclearner);
+		return nullptr;
+	}
+	mdns_constrainer *c = new mdns_constrainer();
+	c->ndim = ndim;
+	c->metriclearner = metriclearner;
+	c->rebuild_every = rebuild_every;
+	c->metric_rebuild_every = metric_rebuild_every;
+	c->force_shrink = force_shrink != 0;
+	return c;
+}
+
+extern "C" void mdns_constrainer_destroy(mdns_constrainer *c, const mdns_draw_backend *be)
+{
+	(void) be;                                  // regions carry the backend they were made with
+	delete c;
+}
+
+extern "C" void mdns_constrainer_forget_region(mdns_constrainer *c)
+{
+	if (c) c->region.reset();
+}
+
+extern "C" void mdns_constrainer_stats(const mdns_constrainer *c, long long *out)
+{
+	if (!c || !out) return;
+	const Counters &s = c->stat;
+	const long long v[8] = {s.draws, s.chunks, s.candidates, s.pairs, s.regions, s.radii, s.counts, s.proposals};
+	memcpy(out, v, sizeof v);
+}
+
+extern "C" int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, const mdns_prior *prior,
+                                     const mdns_numpy_ops *np, void *mt19937_state,
+                                     const double *pile_u, const void *ids, int ids_itemsize, int K,
+                                     const int *rows, int M,
+                                     double *u_out, double *x_out, long long *ntries, unsigned long long *fillbits)
+{
+	if (!c || !be || !prior || !mt19937_state || !pile_u || !ids || K <= 0 || M <= 0 || !u_out || !x_out || !ntries || !fillbits) {
+		set_error("mdns_constrainer_draw: bad arguments (K=%d M=%d)", K, M);
+		return 1;
+	}
+	if (prior->ndim != c->ndim || prior->nparams <= 0 || prior->nparams > MDNS_MAX_DIM || (ids_itemsize != 4 && ids_itemsize != 8)) {
+		set_error("mdns_constrainer_draw: prior of %d dimensions for a constrainer of %d (ids of %d bytes)", prior->ndim, c->ndim, ids_itemsize);
+		return 1;
+	}
+	MT *mt = (MT *) mt19937_state;
+	if (mt->pos < 0 || mt->pos > 624) { set_error("mdns_constrainer_draw: not an mt19937 state (pos=%d)", mt->pos); return 1; }
+	Env e = {c, be, prior, np, mt};
+	const int ndim = c->ndim;
+	// live_pointsu = pointpile[ids]
+	std::vector<double> u((size_t) K * ndim);
+	for (int i = 0; i < K; i++) {
+		const long long id = ids_itemsize == 4 ? (long long) ((const int32_t *) ids)[i] : (long long) ((const int64_t *) ids)[i];
+		memcpy(&u[(size_t) i * ndim], pile_u + (size_t) id * ndim, (size_t) ndim * sizeof(double));
+	}
+	c->stat.draws++;
+	// rebuild policy at the start of a draw (hiermetriclearn.py:152-166)
+	c->iter_since_metric_rebuild += 1;
+	const bool region_due = !c->region || c->ndraws_since_rebuild > c->rebuild_every;
+	const bool metric_due = c->iter_since_metric_rebuild > c->metric_rebuild_every;
+	bool region_rebuilt = false, metric_rebuilt = false;
+	if (region_due) {
+		if (!rebuild(e, u.data(), K, !metric_due)) return 1;
+		c->ndraws_since_rebuild = 0;
+		if (metric_due) c->iter_since_metric_rebuild = 0;
+		region_rebuilt = true;
+		metric_rebuilt = metric_due;
+	}
+	if (!c->has_generator) { set_error("mdns_constrainer_draw: no generator"); return 1; }
+	if (be->draw_begin && be->draw_begin(be->user, rows, M) != 0) { set_error("draw_begin failed"); return 1; }
+	// the accept loop of hiermetriclearn.py:181-211 with the candidates handed over in chunks: a
+	// chunk never reaches past the candidate after which the reference would rebuild its region
+	// (:198-211), so regions, RNG draws and results are those of the one-candidate-at-a-time loop
+	long long tries = 0;
+	for (;;) {
+		if (!c->has_buf || c->buf_pos >= c->buf_n) {
+			if (!next_batch(e)) return 1;
+			if (c->buf_ntotal > 100000) c->direct_draws_efficient = false;
+		}
+		long long room = c->buf_n - c->buf_pos;
+		if (!region_rebuilt) {
+			long long lim = c->rebuild_every - c->ndraws_since_rebuild + 1;
+			if (lim < 1) lim = 1;
+			if (room > lim) room = lim;
+		}
+		if (!metric_rebuilt) {
+			long long lim = 201 - tries;
+			if (lim < 1) lim = 1;
+			if (room > lim) room = lim;
+		}
+		int B = (int) room;
+		if (be->chunk_size) {
+			const long long hint = c->last_ntoaccept > 1 ? c->last_ntoaccept : 1;
+			B = be->chunk_size(be->user, B, M, (int) (hint > 0x3fffffff ? 0x3fffffff : hint));
+			if (B < 1 || B > room) { set_error("chunk_size returned %d of %lld", B, room); return 1; }
+		}
+		const double *chunk = &c->buf[(size_t) c->buf_pos * ndim];
+		c->xs.resize((size_t) B * ndim);
+		c->params.resize((size_t) B * prior->nparams);
+		transform(prior, chunk, B, c->xs.data(), c->params.data());
+		int accepted = -1, nscored = B;
+		if (be->draw_chunk(be->user, c->params.data(), B, &accepted, fillbits, &nscored) != 0) { set_error("draw_chunk failed"); return 1; }
+		c->stat.chunks++;
+		c->stat.candidates += nscored;
+		c->stat.pairs += (long long) nscored * M;
+		const long long used = accepted >= 0 ? accepted + 1 : nscored;
+		if (used <= 0 || used > B || accepted >= B) { set_error("draw_chunk: accepted %d, scored %d of %d", accepted, nscored, B); return 1; }
+		tries += used;
+		c->ndraws_since_rebuild += used;
+		c->buf_pos += (int) used;
+		if (accepted >= 0) {
+			c->last_ntoaccept = tries;
+			memcpy(u_out, chunk + (size_t) accepted * ndim, (size_t) ndim * sizeof(double));
+			memcpy(x_out, &c->xs[(size_t) accepted * ndim], (size_t) ndim * sizeof(double));
+			*ntries = tries;
+			return 0;
+		}
+		// a long unsuccessful streak tightens the region -- each kind at most once per draw
+		// (hiermetriclearn.py:198-211); the candidate stream restarts from the new region
+		if (!region_rebuilt && c->ndraws_since_rebuild > c->rebuild_every) {
+			region_rebuilt = true;
+			if (!rebuild(e, u.data(), K, true)) return 1;
+			c->ndraws_since_rebuild = 0;
+		} else if (!metric_rebuilt && tries > 200) {
+			metric_rebuilt = true;
+			if (!rebuild(e, u.data(), K, false)) return 1;
+			c->iter_since_metric_rebuild = 0;
+		}
+	}
+}

@@ -219,6 +219,15 @@ struct mdns_joint {
 	bool staged_rows = false;
 	int staged_M = 0;
 	size_t staged_in_bytes = 0;
+	double noise_level = 0;            // of mdns_joint_init_gauss (the backend entry points score with it)
+	// the draw in progress through the mdns_backend_* entry points: its selection, uploaded once
+	int *d_sel_rows = nullptr;  size_t sel_rows_cap = 0;
+	bool sel_rows = false;
+	int sel_M = 0;
+	bool sel_open = false;
+	// no shelf holds more than this many entries (set by prepare from the purge's keep bits, +1 per
+	// accepted chunk, -1 per advance): when it reaches the capacity the shelves are grown
+	int shelf_bound = 0;
 };
 
 static size_t result_bytes(int M) { return sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8 + (size_t) M * 8; }
@@ -235,6 +244,7 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	void *bufs[] = {j->st.live, j->st.shelfL, j->st.shelfn, j->st.higher, j->d_running, j->d_Lmin, j->d_argmin_run,
 	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params};
 	for (void *b : bufs) if (b) (void) hipFree(b);
+	if (j->d_sel_rows) (void) hipFree(j->d_sel_rows);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
 	for (void *b : trail) if (b) (void) hipFree(b);
 	if (j->h_box) (void) hipHostFree(j->h_box);
@@ -326,6 +336,7 @@ static int joint_reset(mdns_joint *j)
 {
 	Context *c = ctx();
 	j->prepared = false;
+	j->shelf_bound = 0;
 	return MDNS_HIP(hipMemsetAsync(j->st.shelfn, 0, (size_t) j->ndata * sizeof(int), c->stream)) &&
 	       MDNS_HIP(hipMemsetAsync(j->d_status, 0, sizeof(int), c->stream)) ? 0 : 1;
 }
@@ -337,6 +348,7 @@ extern "C" int mdns_joint_init_gauss(mdns_joint *j, const double *params, double
 	if (j->nlive > MDNS_JOINT_MAX_BATCH) { set_error("mdns_joint_init_gauss: nlive=%d > %d", j->nlive, MDNS_JOINT_MAX_BATCH); return 1; }
 	char *pin = joint_pin(j, (size_t) j->nlive * 24);
 	if (!pin) return 1;
+	j->noise_level = noise_level;
 	memcpy(pin, params, (size_t) j->nlive * 24);
 	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, (size_t) j->nlive * 24, hipMemcpyHostToDevice, c->stream))) return 1;
 	// always the lane kernel: every likelihood of a run is then the same chain of operations
@@ -445,6 +457,15 @@ extern "C" int mdns_joint_prepare(mdns_joint *j, double *Lmin, int *argmin, unsi
 	if (Lmin) memcpy(Lmin, pin, n * 8);
 	if (argmin) memcpy(argmin, pin + o1, n * 4);
 	if (keep) memcpy(keep, pin + o2, n * kw * 8);
+	// what stays on the longest shelf (entries kept = set bits)
+	int longest = 0;
+	const unsigned long long *kwords = (const unsigned long long *) (pin + o2);
+	for (size_t r = 0; r < n; r++) {
+		int kept = 0;
+		for (int w = 0; w < kw; w++) kept += __builtin_popcountll(kwords[r * kw + w]);
+		if (kept > longest) longest = kept;
+	}
+	j->shelf_bound = longest;
 	return 0;
 }
 
@@ -466,6 +487,7 @@ extern "C" int mdns_joint_advance(mdns_joint *j)
 	int status = 0;
 	if (!MDNS_HIP(hipMemcpyAsync(&status, j->d_status, sizeof(int), hipMemcpyDeviceToHost, c->stream)) || !joint_sync(c)) return 1;
 	if (status) { set_error("mdns_joint_advance: a running data set had an empty shelf"); return 1; }
+	if (j->shelf_bound > 0) j->shelf_bound--;
 	return 0;
 }
 
@@ -708,4 +730,103 @@ extern "C" int mdns_joint_draw_gauss(mdns_joint *j, const double *params, int B,
 	if (B == 0 || M == 0) return 0;
 	if (joint_stage_and_score(j, params, B, noise_level, row_ids, M, "mdns_joint_draw_gauss") != 0) return 1;
 	return joint_commit_and_fetch(j, accepted, Lrow, fillbits, "mdns_joint_draw_gauss");
+}
+
+// ---------------------------------------------------------------------------------------
+// the device work of a native constrainer (include/mdns.h Part 5: mdns_draw_backend), user = the
+// joint handle
+// ---------------------------------------------------------------------------------------
+extern "C" void *mdns_backend_region_create(void *joint, const double *members, int K, int ndim,
+                                            const unsigned *packed, int nbootstraps, double *radius)
+{
+	(void) joint;
+	if (!radius) { set_error("mdns_backend_region_create: null radius"); return nullptr; }
+	if (packed) return mdns_region_create_bootstrapped(members, K, ndim, packed, nbootstraps, radius);
+	mdns_region *r = mdns_region_create(members, K, ndim);
+	if (r && mdns_region_set_radius(r, *radius) != 0) { mdns_region_destroy(r); return nullptr; }
+	return r;
+}
+
+extern "C" void mdns_backend_region_destroy(void *joint, void *region)
+{
+	(void) joint;
+	mdns_region_destroy((mdns_region *) region);
+}
+
+extern "C" int mdns_backend_region_count(void *joint, void *region, const double *points, int n, int *counts)
+{
+	(void) joint;
+	return mdns_region_count((mdns_region *) region, points, n, counts);
+}
+
+extern "C" int mdns_backend_draw_begin(void *joint, const int *rows, int M)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !check_draw(j, 0, M, "mdns_backend_draw_begin")) return 1;
+	if (!j->prepared) { set_error("mdns_backend_draw_begin: thresholds are not set (call mdns_joint_prepare first)"); return 1; }
+	j->sel_open = false;
+	if (rows) {
+		for (int k = 0; k < M; k++)
+			if (rows[k] < 0 || rows[k] >= j->ndata || (k > 0 && rows[k] <= rows[k - 1])) {
+				set_error("mdns_backend_draw_begin: rows must be ascending indices below %d (rows[%d]=%d)", j->ndata, k, rows[k]);
+				return 1;
+			}
+		if ((size_t) M > j->sel_rows_cap) {
+			if (j->d_sel_rows) { (void) hipStreamSynchronize(c->stream); (void) hipFree(j->d_sel_rows); j->d_sel_rows = nullptr; j->sel_rows_cap = 0; }
+			if (!MDNS_HIP(hipMalloc((void **) &j->d_sel_rows, (size_t) j->ndata * sizeof(int)))) return 1;
+			j->sel_rows_cap = (size_t) j->ndata;
+		}
+		// (pageable source: the runtime stages it, the call returns when the caller's array is free)
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, rows, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
+	} else if (M != j->ndata) {
+		set_error("mdns_backend_draw_begin: M=%d without rows (ndata=%d)", M, j->ndata);
+		return 1;
+	}
+	j->sel_rows = rows != nullptr;
+	j->sel_M = M;
+	j->sel_open = true;
+	return 0;
+}
+
+extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B, int *accepted,
+                                       unsigned long long *fillbits, int *nscored)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !j || !accepted) return 1;
+	*accepted = -1;
+	if (!j->sel_open) { set_error("mdns_backend_draw_chunk: no draw begun"); return 1; }
+	const int M = j->sel_M;
+	if (!check_draw(j, B, M, "mdns_backend_draw_chunk")) return 1;
+	if (nscored) *nscored = B;
+	if (B == 0 || M == 0) return 0;
+	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
+	const size_t pbytes = (size_t) B * 24;
+	char *pin = joint_pin(j, pbytes);
+	if (!pin) return 1;
+	memcpy(pin, params, pbytes);
+	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+	if (mdns_joint_score_dev(j, j->d_params, B, j->noise_level, d_rows, M) != 0) return 1;
+	if (joint_commit_dev(j, d_rows, M, false, "mdns_backend_draw_chunk") != 0) return 1;
+	if (mdns_joint_fetch(j, M, accepted, fillbits) != 0) return 1;
+	if (*accepted >= 0) j->shelf_bound++;
+	return 0;
+}
+
+// candidates per chunk: four times the tries the last draw needed, within a budget of (candidate,
+// spectrum) pairs (~50 us of GPU time) -- a speed choice only
+extern "C" int mdns_backend_chunk_size(void *joint, int offered, int M, int hint)
+{
+	(void) joint;
+	const long long EVAL_BUDGET = 2560000;
+	const int MIN_CHUNK = 32;
+	long long budget = EVAL_BUDGET / (M > 0 ? M : 1);
+	if (budget < MIN_CHUNK) budget = MIN_CHUNK;
+	long long want = 4LL * (hint > 0 ? hint : 1);
+	if (want < MIN_CHUNK) want = MIN_CHUNK;
+	if (budget > want) budget = want;
+	if (budget > MDNS_JOINT_MAX_BATCH) budget = MDNS_JOINT_MAX_BATCH;
+	return offered < budget ? offered : (int) budget;
 }

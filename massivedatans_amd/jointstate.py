@@ -88,12 +88,18 @@ class HostJointState(object):
     def chunk_size(self, offered, M, hint=None):
         return offered
 
+    def took(self, rows, beats):
+        """(a native constrainer's draw ended in this state's ``draw_params``: nothing to add)"""
+
     def draw(self, xs, rows):
+        return self.draw_params(self.to_kernel_params(xs), rows)
+
+    def draw_params(self, params, rows):
+        """``draw`` for candidates given as kernel parameter rows."""
         rows = numpy.arange(self.ndata) if rows is None else numpy.asarray(rows, dtype=int)
         mask = numpy.zeros(self.ndata, dtype=bool)
         mask[rows] = True
         thr = self.higher[rows]
-        params = self.to_kernel_params(xs)
         pos, chunk = 0, 1
         while pos < len(params):
             Ls = self.scorer.loglike_batch(params[pos:pos + chunk], mask)
@@ -239,10 +245,23 @@ class GaussJointState(object):
             budget = min(budget, max(self.MIN_CHUNK, 4 * int(hint)))
         return int(min(offered, budget, _lib.JOINT_MAX_BATCH))
 
+    def took(self, rows, beats):
+        """A draw made through the native constrainer (mdns_backend_draw_chunk on this state's
+        handle) put its point on the shelves of ``rows[beats]``: keep the mirror of the sizes."""
+        if rows is None:
+            self.shelf_n[beats] += 1
+        else:
+            self.shelf_n[rows[beats]] += 1
+
     def draw(self, xs, rows):
-        M = self.ndata if rows is None else len(rows)
         B = min(len(xs), _lib.JOINT_MAX_BATCH)
-        params = _lib.as_f64(self.to_kernel_params(xs[:B]))
+        return self.draw_params(self.to_kernel_params(xs[:B]), rows)
+
+    def draw_params(self, params, rows):
+        """``draw`` for candidates given as kernel parameter rows (A, mu, sig)."""
+        M = self.ndata if rows is None else len(rows)
+        B = min(len(params), _lib.JOINT_MAX_BATCH)
+        params = _lib.as_f64(params[:B])
         if rows is not None:
             rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
             nmax = int(self.shelf_n[rows].max()) if M else 0

@@ -126,7 +126,7 @@ class MultiNestedSampler(object):
                  individual_draw_constrained, draw_constrained, ndata, ndim, nlive_points=200,
                  draw_global_uniform=None, nsuperset_draws=10, use_graph=False,
                  multi_loglikelihood_batch=None, joint_state=None, priortransform_batch=None,
-                 device_groups=False):
+                 device_groups=False, native=None):
         self.nlive_points = nlive_points
         self.nsuperset_draws = nsuperset_draws
         self.priortransform = priortransform
@@ -152,6 +152,9 @@ class MultiNestedSampler(object):
         #: optional: an object keeping live_pointsL, the shelves' likelihoods and the thresholds
         #: (massivedatans_amd.jointstate); a constrained draw is then scored AND decided there
         self.joint = joint_state
+        #: optional: a constrainer.NativeContext -- constrainers that are NativeConstrainer objects then
+        #: make their whole draw in ONE native call (region, proposals, chunks, commit)
+        self.native = native
         self.priortransform_batch = priortransform_batch
         self._live_cache = None
         self.ndraw_calls = 0                # constrained draws made (accepted points)
@@ -674,6 +677,22 @@ class MultiNestedSampler(object):
                 else:
                     draw = self.superset_draw_constrained
 
+                constrainer = getattr(draw, '__self__', None) if self.native is not None else None
+                if constrainer is not None and hasattr(constrainer, 'draw_native'):
+                    # the whole draw in one native call (include/mdns.h Part 5)
+                    if njoints == len(real_indices) == self.joint.ndata:
+                        rows = None
+                    else:
+                        rows = real_rows if real_rows is not None else real_indices[joint_indices]
+                        rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
+                    t_draw = time.perf_counter()
+                    uj, xj, n, bits = constrainer.draw_native(self._pile_u, joint_live_pointsp, rows, njoints)
+                    self.draw_seconds += time.perf_counter() - t_draw
+                    beats = numpy.unpackbits(bits[:(njoints + 63) // 64].view(numpy.uint8), bitorder='little')[:njoints].view(numpy.bool_)
+                    self.joint.took(rows, beats)
+                    self._accept(uj, xj, n, njoints, joint_indices, beats, None)
+                    continue
+
                 extra = {}
                 if self.joint is not None:
                     # the whole chunk of proposed candidates goes to the joint state, which
@@ -697,33 +716,37 @@ class MultiNestedSampler(object):
                     iter=self.global_iter, nlive_points=self.nlive_points, **extra)
                 self.draw_seconds += time.perf_counter() - t_draw
 
-                self.ndraws += int(n)
-                self.ndraw_calls += 1
-                self.nevals += int(n) * njoints
-                ppi = len(self.pointpile)
-                if ppi == len(self._pile_u):
-                    room = numpy.empty((max(1024, ppi), self._pile_u.shape[1]))
-                    self._pile_u = numpy.vstack((self._pile_u, room))
-                    self._pile_x = numpy.vstack((self._pile_x, room))
-                self._pile_u[ppi] = uj
-                self._pile_x[ppi] = xj
-                self.pointpile = self._pile_u[:ppi + 1]
-                self.pointpilex = self._pile_x[:ppi + 1]
                 if self.joint is not None:
-                    beats = last['beats']             # decided where the thresholds are
-                    # (the likelihoods of the waiting points stay with the joint state; the host
-                    # queues carry them only when the state hands the row over)
-                    self._shelves.append(joint_indices[beats], ppi, Lj[beats] if Lj is not None else numpy.nan)
+                    self._accept(uj, xj, n, njoints, joint_indices, last['beats'], Lj)      # decided where the thresholds are
                 else:
                     beats = Lj > Lmins_higher
-                    self._shelves.append(joint_indices[beats], ppi, Lj[beats])
+                    self._accept(uj, xj, n, njoints, joint_indices, beats, Lj)
                     self._refresh_thresholds(joint_indices[beats])
-                nfilled = int(beats.sum())
-                if len(self._refcount) <= ppi:
-                    self._refcount = numpy.concatenate((self._refcount, numpy.zeros(max(1024, ppi), dtype=int)))
-                if nfilled == self.ndata:
-                    self.superpoints.add(ppi)
-                log.debug('iteration %d: accepted after %d tries, filled %d shelves', self.global_iter, n, nfilled)
+
+    def _accept(self, uj, xj, n, njoints, joint_indices, beats, Lj):
+        """A constrained draw delivered a point (multi_nested_sampler.py:474-489): it joins the pile
+        and the shelves of the data sets whose threshold it beats."""
+        self.ndraws += int(n)
+        self.ndraw_calls += 1
+        self.nevals += int(n) * njoints
+        ppi = len(self.pointpile)
+        if ppi == len(self._pile_u):
+            room = numpy.empty((max(1024, ppi), self._pile_u.shape[1]))
+            self._pile_u = numpy.vstack((self._pile_u, room))
+            self._pile_x = numpy.vstack((self._pile_x, room))
+        self._pile_u[ppi] = uj
+        self._pile_x[ppi] = xj
+        self.pointpile = self._pile_u[:ppi + 1]
+        self.pointpilex = self._pile_x[:ppi + 1]
+        # (with a joint state the likelihoods of the waiting points stay there; the host queues
+        # carry them only when the state hands the row over)
+        self._shelves.append(joint_indices[beats], ppi, Lj[beats] if Lj is not None else numpy.nan)
+        nfilled = int(numpy.count_nonzero(beats))
+        if len(self._refcount) <= ppi:
+            self._refcount = numpy.concatenate((self._refcount, numpy.zeros(max(1024, ppi), dtype=int)))
+        if nfilled == self.ndata:
+            self.superpoints.add(ppi)
+        log.debug('iteration %d: accepted after %d tries, filled %d shelves', self.global_iter, n, nfilled)
 
     def _draw_batch(self, us, rows, last, hint):
         """One chunk of proposed unit-cube candidates through the joint state: returns

@@ -121,17 +121,47 @@ class GaussLineProblem(object):
         return build(self.backend, self.ndata)
 
 
+def native_context(joint, prior, ndata):
+    """The shared part of the native constrainers (massivedatans_amd.constrainer) for a joint
+    state, or None where they cannot run (library not built, data sets sharded over ranks)."""
+    from . import constrainer
+    from .jointstate import GaussJointState, HostJointState
+    if not constrainer.available():
+        return None
+    if isinstance(joint, GaussJointState):
+        backend = constrainer.hip_backend(joint)
+    elif isinstance(joint, HostJointState):
+        backend = constrainer.python_backend(joint)
+    else:
+        return None
+    return constrainer.NativeContext(backend, prior, ndata)
+
+
 def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False, seed=1, batched=True,
-                  fused=False):
+                  fused=False, native=None):
     """Constrainers + sampler wired as sample.py:131-194 (CONSTRAINER=MLFRIENDS).  ``fused``: the
     likelihood matrix, the shelves' likelihoods and the thresholds live in a joint state
-    (``problem.joint_state``) and whole chunks of candidates are scored and decided there."""
-    cachedconstrainer.generate_fresh_constrainer = cachedconstrainer.generate_fresh_constrainer_mlfriends
-    superset_constrainer = cachedconstrainer.generate_fresh_constrainer_mlfriends()
-    cc = CachedConstrainer()
-    _, _, individual_draw_constrained = generate_individual_constrainer()
+    (``problem.joint_state``) and whole chunks of candidates are scored and decided there.
+    ``native`` (default with ``fused``: on, MDNS_NATIVE_CONSTRAINER=0 turns it off): the
+    constrainers are ``constrainer.NativeConstrainer`` objects -- one native call per draw."""
     numpy.random.seed(seed)                                      # sample.py:162
     joint = problem.joint_state(nlive_points) if fused else None
+    if native is None:
+        native = fused and os.environ.get('MDNS_NATIVE_CONSTRAINER', '1') != '0'
+    context = None
+    if native:
+        from . import constrainer
+        context = native_context(joint, constrainer.sample_py_prior(), problem.ndata)
+    if context is not None:
+        # every constrainer of this sampler: MLFriends with the reference driver's settings
+        # (sample.py:133-137), in the library
+        cachedconstrainer.generate_fresh_constrainer = lambda: context.fresh_constrainer(
+            metriclearner='truncatedscaling', force_shrink=True, rebuild_every=1000, metric_rebuild_every=20)
+    else:
+        cachedconstrainer.generate_fresh_constrainer = cachedconstrainer.generate_fresh_constrainer_mlfriends
+    superset_constrainer = cachedconstrainer.generate_fresh_constrainer()
+    cc = CachedConstrainer()
+    _, _, individual_draw_constrained = generate_individual_constrainer()
     # the graph variant of the grouping runs on the device when the likelihoods do
     from .jointstate import GaussJointState
     on_device = isinstance(joint, GaussJointState) or isinstance(getattr(joint, 'local', None), GaussJointState)
@@ -144,7 +174,7 @@ def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False
         draw_constrained=cc.get, nsuperset_draws=nsuperset_draws, use_graph=use_graph,
         multi_loglikelihood_batch=problem.multi_loglikelihood_batch if batched else None,
         joint_state=joint, priortransform_batch=priortransform_batch if fused else None,
-        device_groups=device_groups)
+        device_groups=device_groups, native=context)
     superset_constrainer.sampler = sampler
     cc.sampler = sampler
     return sampler
