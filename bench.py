@@ -297,6 +297,23 @@ def setup_dist(args):
     return world, rank, use_dist, torch, dist, lib, _lib
 
 
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks of this script through
+    torch.distributed.run (one per GPU, rendezvous on 127.0.0.1) BEFORE this process has touched
+    the GPU, relay what they print -- rank 0 prints the JSON line -- and return their exit code.
+    (Never an exec: a process that has initialised HIP must not be replaced, and this one has not
+    and does not.)"""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def timed(step, fence, args, use_dist, torch, dist, lib, _lib):
     for _ in range(args.warmup):
         step()
@@ -691,6 +708,8 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="no per-launch events in the timed loop (roofline empty)")
     ap.add_argument("--workload", default="horns", choices=["horns", "nothing", "muse"])
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     args.batch_given = args.batch is not None
     if args.batch is None:
         args.batch = 256

@@ -463,10 +463,14 @@ int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, cons
                           const double *pile_u, const void *ids, int ids_itemsize, int K,
                           const int *rows, int M,
                           double *u, double *x, long long *ntries, unsigned long long *fillbits);
-/* counters since creation: out[0] draws, [1] chunks, [2] candidates scored, [3] (candidate, data
- * set) pairs scored, [4] regions built, [5] radius computations (K6), [6] membership calls (K3),
- * [7] raw proposals */
-void mdns_constrainer_stats(const mdns_constrainer *c, long long *out8);
+/* counters since creation, out int64[MDNS_CONSTRAINER_COUNTERS]: [0] draws, [1] chunks, [2] candidates
+ * scored, [3] (candidate, data set) pairs scored, [4] regions built, [5] radius computations (K6),
+ * [6] membership calls (K3), [7] raw proposals, [8] proposals the region kept, [9] tries (the
+ * reference's likelihood calls).  mdns_constrainer_share_stats: every increment is also added to
+ * totals int64[MDNS_CONSTRAINER_COUNTERS] (the caller's: the sum over a sampler's constrainers). */
+#define MDNS_CONSTRAINER_COUNTERS 10
+void mdns_constrainer_stats(const mdns_constrainer *c, long long *out);
+void mdns_constrainer_share_stats(mdns_constrainer *c, long long *totals);
 const char *mdns_host_last_error(void);
 /* The cached second deviate of numpy's legacy Gaussian generator (legacy-distributions.c,
  * `has_gauss` / `gauss`): the constrainer keeps it for the process like numpy's global RandomState

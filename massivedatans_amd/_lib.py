@@ -45,7 +45,7 @@ ABI_SYMBOLS = (
 #: the symbols of include/mdns.h Part 5 that live in libmdns_host.so (plain host code, no GPU)
 HOST_ABI_SYMBOLS = (
     "mdns_constrainer_create", "mdns_constrainer_destroy", "mdns_constrainer_forget_region",
-    "mdns_constrainer_draw", "mdns_constrainer_stats", "mdns_host_last_error",
+    "mdns_constrainer_draw", "mdns_constrainer_stats", "mdns_constrainer_share_stats", "mdns_host_last_error",
     "mdns_host_rng_get_gauss", "mdns_host_rng_set_gauss",
 )
 

@@ -55,6 +55,8 @@ class NumpyOps(C.Structure):               # mdns_numpy_ops
 
 
 METRICS = {'none': 0, 'simplescaling': 1, 'truncatedscaling': 2}
+#: mdns_constrainer_stats (include/mdns.h)
+COUNTERS = ("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals", "inside", "tries")
 
 _HOST = None
 
@@ -77,6 +79,8 @@ def host_lib():
             L.mdns_constrainer_draw.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4
             L.mdns_constrainer_stats.restype = None
             L.mdns_constrainer_stats.argtypes = [C.c_void_p, C.c_void_p]
+            L.mdns_constrainer_share_stats.restype = None
+            L.mdns_constrainer_share_stats.argtypes = [C.c_void_p, C.c_void_p]
             L.mdns_host_last_error.restype = C.c_char_p
             L.mdns_host_last_error.argtypes = []
             L.mdns_host_rng_get_gauss.restype = None
@@ -267,6 +271,8 @@ class NativeContext(object):
         self.x = numpy.empty(self.ndim)
         self.bits = numpy.zeros((int(ndata) + 63) // 64 + 1, dtype=numpy.uint64)
         self.ntries = C.c_longlong(0)
+        #: counters summed over all constrainers of this context (see COUNTERS)
+        self.totals = numpy.zeros(len(COUNTERS), dtype=numpy.int64)
         self._u, self._x, self._bits, self._ntries = self.u.ctypes.data, self.x.ctypes.data, self.bits.ctypes.data, C.addressof(self.ntries)
         self.sync_gauss_from_numpy()
 
@@ -286,6 +292,9 @@ class NativeContext(object):
     def fresh_constrainer(self, **kwargs):
         return NativeConstrainer(self, **kwargs)
 
+    def stats(self):
+        return dict(zip(COUNTERS, self.totals.tolist()))
+
 
 class NativeConstrainer(object):
     """Same constructor arguments and attributes the rest of the host code touches as
@@ -304,6 +313,7 @@ class NativeConstrainer(object):
                                                     self.metric_rebuild_every, 1 if force_shrink else 0)
         if not self._h:
             raise RuntimeError("mdns_constrainer_create: " + self._lib.mdns_host_last_error().decode())
+        self._lib.mdns_constrainer_share_stats(self._h, context.totals.ctypes.data)
 
     # `constrainers[i].region = None` (cachedconstrainer.py:104-105) drops the region
     @property
@@ -328,9 +338,9 @@ class NativeConstrainer(object):
             pass
 
     def stats(self):
-        out = (C.c_longlong * 8)()
+        out = (C.c_longlong * len(COUNTERS))()
         self._lib.mdns_constrainer_stats(self._h, out)
-        return dict(zip(("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals"), list(out)))
+        return dict(zip(COUNTERS, list(out)))
 
     def draw_native(self, pile_u, ids, rows, M):
         """One constrained draw: live points ``pile_u[ids]``, data sets ``rows`` (int32, ascending

@@ -175,8 +175,17 @@ struct Metric {
 // ---------------------------------------------------------------------------------------
 // region (clustering/radfriendsregion.py)
 // ---------------------------------------------------------------------------------------
+// index of a counter in mdns_constrainer_stats' output
+enum { N_DRAWS, N_CHUNKS, N_CANDIDATES, N_PAIRS, N_REGIONS, N_RADII, N_COUNTS, N_PROPOSALS, N_INSIDE, N_TRIES, N_COUNTERS };
+
 struct Counters {
-	long long draws = 0, chunks = 0, candidates = 0, pairs = 0, regions = 0, radii = 0, counts = 0, proposals = 0;
+	long long v[N_COUNTERS] = {0};
+	long long *totals = nullptr;           // optional: the same counters summed over all constrainers of a sampler
+	void add(int which, long long n)
+	{
+		v[which] += n;
+		if (totals) totals[which] += n;
+	}
 };
 
 struct Region {
@@ -204,7 +213,7 @@ struct Region {
 			radius = r;
 			has_radius = true;
 			std::vector<uint32_t>().swap(masks);
-			if (stat) stat->radii++;
+			if (stat) stat->add(N_RADII, 1);
 		}
 		*out = radius;
 		return true;
@@ -222,7 +231,7 @@ struct Region {
 	bool count(const double *points, int n, int *counts)
 	{
 		if (!member_set()) return false;
-		if (stat) stat->counts++;
+		if (stat) stat->add(N_COUNTS, 1);
 		if (be->region_count(be->user, handle, points, n, counts) != 0) { set_error("region_count failed"); return false; }
 		return true;
 	}
@@ -312,7 +321,7 @@ RegionRef new_region(Env &e, const double *members, int K, bool given, double ma
 	r->ndim = e.c->ndim;
 	r->be = e.be;
 	r->stat = &e.c->stat;
-	e.c->stat.regions++;
+	e.c->stat.add(N_REGIONS, 1);
 	if (given) {
 		r->has_radius = true;
 		r->radius = maxdistance;
@@ -485,7 +494,7 @@ bool next_batch(Env &e)
 			}
 			c->spent += N;
 			c->proposed += N;
-			c->stat.proposals += N;
+			c->stat.add(N_PROPOSALS, N);
 			if (!r->box()) return false;
 			// numpy.random.uniform(lo, hi, size=(N, ndim)): lo + (hi - lo) * double, row by row
 			c->us.resize((size_t) N * ndim);
@@ -506,6 +515,7 @@ bool next_batch(Env &e)
 					c->ws.insert(c->ws.end(), c->us.begin() + (size_t) i * ndim, c->us.begin() + (size_t) (i + 1) * ndim);
 					n++;
 				}
+			c->stat.add(N_INSIDE, n);
 			if (n) {
 				const long long sp = c->spent;
 				c->spent = 0;
@@ -520,7 +530,7 @@ bool next_batch(Env &e)
 			legacy_randint(e.mt, r->K, N, c->idx.data());
 			c->spent += N;
 			c->proposed += N;
-			c->stat.proposals += N;
+			c->stat.add(N_PROPOSALS, N);
 			// direction = normal(0, 1, (N, ndim)); direction / sqrt((direction ** 2).sum(axis=1))
 			c->dir.resize((size_t) N * ndim);
 			for (size_t t = 0; t < (size_t) N * ndim; t++) {
@@ -573,6 +583,7 @@ bool next_batch(Env &e)
 				}
 			}
 			c->phase = mdns_constrainer::BOX;
+			c->stat.add(N_INSIDE, n);
 			if (n) {
 				const long long sp = c->spent;
 				c->spent = 0;
@@ -588,7 +599,7 @@ bool next_batch(Env &e)
 				// occasionally propose from the whole unit cube (hiermetriclearn.py:126-137)
 				const int NN = REGION_BATCH;
 				c->ntotal = c->ntotal + NN;
-				c->stat.proposals += NN;
+				c->stat.add(N_PROPOSALS, NN);
 				c->us.resize((size_t) NN * ndim);
 				for (size_t q = 0; q < (size_t) NN * ndim; q++) {
 					const double v = 1.0 * mt_double(e.mt);
@@ -606,6 +617,7 @@ bool next_batch(Env &e)
 						c->buf.insert(c->buf.end(), c->us.begin() + (size_t) i * ndim, c->us.begin() + (size_t) (i + 1) * ndim);
 						n++;
 					}
+				c->stat.add(N_INSIDE, n);
 				if (n) {
 					c->buf_n = n;
 					c->buf_pos = 0;
@@ -682,9 +694,12 @@ extern "C" void mdns_constrainer_forget_region(mdns_constrainer *c)
 extern "C" void mdns_constrainer_stats(const mdns_constrainer *c, long long *out)
 {
 	if (!c || !out) return;
-	const Counters &s = c->stat;
-	const long long v[8] = {s.draws, s.chunks, s.candidates, s.pairs, s.regions, s.radii, s.counts, s.proposals};
-	memcpy(out, v, sizeof v);
+	memcpy(out, c->stat.v, sizeof c->stat.v);
+}
+
+extern "C" void mdns_constrainer_share_stats(mdns_constrainer *c, long long *totals)
+{
+	if (c) c->stat.totals = totals;
 }
 
 extern "C" int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, const mdns_prior *prior,
@@ -711,7 +726,7 @@ extern "C" int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backen
 		const long long id = ids_itemsize == 4 ? (long long) ((const int32_t *) ids)[i] : (long long) ((const int64_t *) ids)[i];
 		memcpy(&u[(size_t) i * ndim], pile_u + (size_t) id * ndim, (size_t) ndim * sizeof(double));
 	}
-	c->stat.draws++;
+	c->stat.add(N_DRAWS, 1);
 	// rebuild policy at the start of a draw (hiermetriclearn.py:152-166)
 	c->iter_since_metric_rebuild += 1;
 	const bool region_due = !c->region || c->ndraws_since_rebuild > c->rebuild_every;
@@ -758,12 +773,13 @@ extern "C" int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backen
 		transform(prior, chunk, B, c->xs.data(), c->params.data());
 		int accepted = -1, nscored = B;
 		if (be->draw_chunk(be->user, c->params.data(), B, &accepted, fillbits, &nscored) != 0) { set_error("draw_chunk failed"); return 1; }
-		c->stat.chunks++;
-		c->stat.candidates += nscored;
-		c->stat.pairs += (long long) nscored * M;
+		c->stat.add(N_CHUNKS, 1);
+		c->stat.add(N_CANDIDATES, nscored);
+		c->stat.add(N_PAIRS, (long long) nscored * M);
 		const long long used = accepted >= 0 ? accepted + 1 : nscored;
 		if (used <= 0 || used > B || accepted >= B) { set_error("draw_chunk: accepted %d, scored %d of %d", accepted, nscored, B); return 1; }
 		tries += used;
+		c->stat.add(N_TRIES, used);
 		c->ndraws_since_rebuild += used;
 		c->buf_pos += (int) used;
 		if (accepted >= 0) {

@@ -96,6 +96,19 @@ struct JointTrail {
 	double *L;                     // [candidates x tiles][64]
 	int stamp;
 };
+// What a commit leaves for a caller that does not want the likelihood row, in host memory
+// mapped into the device: the host polls `seq` instead of copying and synchronising.
+struct JointMailbox { unsigned long long seq; int accepted; int status; unsigned long long bits[1]; /* ceil(M/64) words */ };
+// a draw chunk in two launches (mdns_chunk.hip): whether the shape qualifies, and the launchers.
+// Candidates (and, for the first chunk of a draw, the selection's row ids) are read from host
+// memory mapped into the device; accepted candidates get flags[b] = stamp.
+bool chunk_fits(const mdns_spectra *s, int M, int B);
+bool launch_chunk_accept(const mdns_spectra *s, const double *d_params_mapped, int B, double scale,
+                         const int *d_rows_in, int *d_rows_dev, int M, const double *d_higher,
+                         int *d_flags, int stamp, const JointTrail &trail);
+bool launch_chunk_commit(const int *d_thr_rows, int M, int B, const int *d_flags, int stamp, const JointTrail &trail,
+                         const JointArrays &st, void *d_header, unsigned long long *d_fillbits, void *box_dev,
+                         unsigned long long seq);
 // accept test fused into the lane kernel: flags[b] = 1 when candidate b beats a threshold
 bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,

@@ -149,10 +149,6 @@ __global__ __launch_bounds__(kBlock) void k_joint_undo_advance(JointArrays st, c
 	st.shelfn[d] = 0;
 }
 
-// What a commit leaves for a caller that does not want the likelihood row, in host memory
-// mapped into the device: the host polls `seq` instead of copying and synchronising.
-struct JointMailbox { unsigned long long seq; int accepted; int status; unsigned long long bits[1]; /* ceil(M/64) words */ };
-
 // Runs right behind the commit pass (stream order makes its results visible): one workgroup
 // copies {accepted, status} and the fill words into the mapped block and writes `seq` last.
 // (Doing this in the commit kernel itself -- last workgroup to finish -- needs a device- or
@@ -225,6 +221,10 @@ struct mdns_joint {
 	bool sel_rows = false;
 	int sel_M = 0;
 	bool sel_open = false;
+	bool sel_on_device = false;        // d_sel_rows holds the selection (a chunk kernel or a copy put it there)
+	// what the chunk kernels read directly: candidates, then the selection's row ids, in host
+	// memory mapped into the device
+	char *h_in = nullptr, *h_in_dev = nullptr;
 	// no shelf holds more than this many entries (set by prepare from the purge's keep bits, +1 per
 	// accepted chunk, -1 per advance): when it reaches the capacity the shelves are grown
 	int shelf_bound = 0;
@@ -245,6 +245,7 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	if (j->d_sel_rows) (void) hipFree(j->d_sel_rows);
+	if (j->h_in) (void) hipHostFree(j->h_in);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
 	for (void *b : trail) if (b) (void) hipFree(b);
 	if (j->h_box) (void) hipHostFree(j->h_box);
@@ -759,6 +760,8 @@ extern "C" int mdns_backend_region_count(void *joint, void *region, const double
 	return mdns_region_count((mdns_region *) region, points, n, counts);
 }
 
+static constexpr size_t kInParams = (size_t) MDNS_JOINT_MAX_BATCH * 24;      // bytes of the candidates' slot in h_in
+
 extern "C" int mdns_backend_draw_begin(void *joint, const int *rows, int M)
 {
 	Context *c = ctx();
@@ -766,24 +769,31 @@ extern "C" int mdns_backend_draw_begin(void *joint, const int *rows, int M)
 	if (!c || !check_draw(j, 0, M, "mdns_backend_draw_begin")) return 1;
 	if (!j->prepared) { set_error("mdns_backend_draw_begin: thresholds are not set (call mdns_joint_prepare first)"); return 1; }
 	j->sel_open = false;
+	if (!j->h_in) {
+		if (!MDNS_HIP(hipHostMalloc((void **) &j->h_in, kInParams + (size_t) j->ndata * sizeof(int), hipHostMallocMapped)) ||
+		    !MDNS_HIP(hipHostGetDevicePointer((void **) &j->h_in_dev, j->h_in, 0))) return 1;
+	}
+	if (!j->d_sel_rows) {
+		if (!MDNS_HIP(hipMalloc((void **) &j->d_sel_rows, (size_t) j->ndata * sizeof(int)))) return 1;
+		j->sel_rows_cap = (size_t) j->ndata;
+	}
 	if (rows) {
-		for (int k = 0; k < M; k++)
-			if (rows[k] < 0 || rows[k] >= j->ndata || (k > 0 && rows[k] <= rows[k - 1])) {
-				set_error("mdns_backend_draw_begin: rows must be ascending indices below %d (rows[%d]=%d)", j->ndata, k, rows[k]);
+		int *dst = (int *) (j->h_in + kInParams);
+		int prev = -1;
+		for (int k = 0; k < M; k++) {
+			const int r = rows[k];
+			if (r <= prev || r >= j->ndata) {
+				set_error("mdns_backend_draw_begin: rows must be ascending indices below %d (rows[%d]=%d)", j->ndata, k, r);
 				return 1;
 			}
-		if ((size_t) M > j->sel_rows_cap) {
-			if (j->d_sel_rows) { (void) hipStreamSynchronize(c->stream); (void) hipFree(j->d_sel_rows); j->d_sel_rows = nullptr; j->sel_rows_cap = 0; }
-			if (!MDNS_HIP(hipMalloc((void **) &j->d_sel_rows, (size_t) j->ndata * sizeof(int)))) return 1;
-			j->sel_rows_cap = (size_t) j->ndata;
+			dst[k] = prev = r;
 		}
-		// (pageable source: the runtime stages it, the call returns when the caller's array is free)
-		if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, rows, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
 	} else if (M != j->ndata) {
 		set_error("mdns_backend_draw_begin: M=%d without rows (ndata=%d)", M, j->ndata);
 		return 1;
 	}
 	j->sel_rows = rows != nullptr;
+	j->sel_on_device = false;
 	j->sel_M = M;
 	j->sel_open = true;
 	return 0;
@@ -803,13 +813,44 @@ extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B,
 	if (B == 0 || M == 0) return 0;
 	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
 	const size_t pbytes = (size_t) B * 24;
-	char *pin = joint_pin(j, pbytes);
-	if (!pin) return 1;
-	memcpy(pin, params, pbytes);
-	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
-	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
-	if (mdns_joint_score_dev(j, j->d_params, B, j->noise_level, d_rows, M) != 0) return 1;
-	if (joint_commit_dev(j, d_rows, M, false, "mdns_backend_draw_chunk") != 0) return 1;
+	static const char *no_fast = getenv("MDNS_CHUNK_PATH");           // "old": experiments only
+	if (chunk_fits(j->s, M, B) && !(no_fast && !strcmp(no_fast, "old"))) {
+		// two launches: the kernels read candidates and (first chunk of the draw) the selection
+		// from the mapped block; nothing is copied, nothing is cleared
+		memcpy(j->h_in, params, pbytes);
+		JointTrail trail;
+		if (!joint_trail(j, B, M, &trail)) return 1;
+		const int *rows_in = nullptr;
+		int *rows_out = nullptr;
+		if (j->sel_rows) {
+			if (j->sel_on_device) rows_in = j->d_sel_rows;
+			else { rows_in = (const int *) (j->h_in_dev + kInParams); rows_out = j->d_sel_rows; }
+		}
+		const double scale = -0.5 / (j->noise_level * j->noise_level);
+		if (!launch_chunk_accept(j->s, (const double *) j->h_in_dev, B, scale, rows_in, rows_out, M, j->st.higher,
+		                         j->d_flags, trail.stamp, trail)) return 1;
+		if (j->sel_rows) j->sel_on_device = true;
+		char *base = j->d_result;
+		unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
+		if (!launch_chunk_commit(j->sel_rows ? j->d_sel_rows : nullptr, M, B, j->d_flags, trail.stamp, trail, j->st, base, bits,
+		                         j->h_box_dev, ++j->box_seq)) return 1;
+		j->box_pending = true;
+		j->trail_valid = false;
+		j->last_B = 0;
+	} else {
+		char *pin = joint_pin(j, pbytes);
+		if (!pin) return 1;
+		memcpy(pin, params, pbytes);
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+		if (j->sel_rows && !j->sel_on_device) {
+			// (the mapped block is pinned: a plain asynchronous copy)
+			if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, j->h_in + kInParams, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
+			j->sel_on_device = true;
+		}
+		const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+		if (mdns_joint_score_dev(j, j->d_params, B, j->noise_level, d_rows, M) != 0) return 1;
+		if (joint_commit_dev(j, d_rows, M, false, "mdns_backend_draw_chunk") != 0) return 1;
+	}
 	if (mdns_joint_fetch(j, M, accepted, fillbits) != 0) return 1;
 	if (*accepted >= 0) j->shelf_bound++;
 	return 0;

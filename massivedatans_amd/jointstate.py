@@ -164,10 +164,14 @@ class GaussJointState(object):
     EVAL_BUDGET = 2560000
     MIN_CHUNK = 32
 
-    def __init__(self, spectra, nlive, to_kernel_params, shelf_cap=64, fetch_rows=True):
+    def __init__(self, spectra, nlive, to_kernel_params, shelf_cap=64, fetch_rows=True, via_backend=False):
         #: copy the accepted candidate's likelihood row to the host with every draw (the sampler
         #: itself needs only the index and the fill bits: sample.py turns this off)
         self.fetch_rows = fetch_rows
+        #: make ``draw`` go through the entry points a native constrainer calls
+        #: (mdns_backend_draw_begin / mdns_backend_draw_chunk; no likelihood row) -- tests
+        self.via_backend = via_backend
+        self._nscored = C.c_int(0)
         self._lib = _lib.require_device()
         self.spectra = spectra                             # keeps the spectra handle alive
         self.nlive, self.ndata = int(nlive), int(spectra.ndata)
@@ -264,6 +268,23 @@ class GaussJointState(object):
         params = _lib.as_f64(params[:B])
         if rows is not None:
             rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
+        if self.via_backend:
+            if B == 0 or M == 0:
+                return -1, None, None, B
+            self._check(self._lib.mdns_backend_draw_begin(self._h, _lib.ptr(rows) if rows is not None else None, M),
+                        "mdns_backend_draw_begin")
+            self._check(self._lib.mdns_backend_draw_chunk(self._h, _lib.ptr(params), B, C.addressof(self._accepted),
+                                                          _lib.ptr(self._bits), C.addressof(self._nscored)),
+                        "mdns_backend_draw_chunk")
+            self.ncalls += 1
+            self.nevals_scored += B * M
+            idx = self._accepted.value
+            if idx < 0:
+                return -1, None, None, B
+            beats = numpy.unpackbits(self._bits[:(M + 63) // 64].view(numpy.uint8), bitorder='little')[:M].astype(bool)
+            self.took(rows, beats)
+            return idx, None, beats, B
+        if rows is not None:
             nmax = int(self.shelf_n[rows].max()) if M else 0
         else:
             nmax = int(self.shelf_n.max())

@@ -170,8 +170,8 @@ class ShardedJointState(object):
     * one all-gather of the accepted candidate's block: likelihoods + fill bits of the selected
       data sets of each rank (M numbers in all), for the host bookkeeping every rank repeats.
 
-    Per iteration: the per-data-set minima / slots / purge decisions of ``prepare`` (an object
-    gather; once per iteration).  With the ``nccl`` backend the flags are reduced on the device
+    Per iteration: the per-data-set minima / slots / purge decisions of ``prepare`` (two tensor
+    all-gathers of fixed shape: lengths, then the padded vectors).  With the ``nccl`` backend the flags are reduced on the device
     (RCCL reduces the state's own flag buffer in place, on the library stream, which is torch's
     current stream); with ``gloo`` through the host.  Same interface as the single-process states."""
 
@@ -215,24 +215,48 @@ class ShardedJointState(object):
     def chunk_size(self, offered, M, hint=None):
         return self.local.chunk_size(offered, M, hint)       # from global numbers: the same on every rank
 
-    def prepare(self):
+    def _gather_vectors(self, vec):
+        """All-gather of one float64 vector per rank (lengths may differ): two tensor collectives
+        of fixed shape -- the lengths, then the vectors padded to the longest -- instead of a
+        pickled object gather.  Returns the list of the ranks' vectors."""
         torch, dist = _dist()
-        mine = self.local.prepare()
-        parts = [None] * self.world
-        dist.all_gather_object(parts, mine)
-        Lmin = np.concatenate([p[0] for p in parts])
-        arg = np.concatenate([p[1] for p in parts])
-        if all(p[2] is None for p in parts):
+        vec = np.ascontiguousarray(vec, dtype=np.float64).ravel()
+        n_t = torch.tensor([len(vec)], dtype=torch.int64, device=_device())
+        sizes_t = torch.empty(self.world, dtype=torch.int64, device=_device())
+        dist.all_gather_into_tensor(sizes_t, n_t)
+        sizes = sizes_t.cpu().numpy()
+        width = max(int(sizes.max()), 1)
+        padded = np.zeros(width)
+        padded[:len(vec)] = vec
+        out_t = torch.empty(self.world * width, dtype=torch.float64, device=_device())
+        dist.all_gather_into_tensor(out_t, torch.from_numpy(padded).to(_device()))
+        out = out_t.cpu().numpy().reshape(self.world, width)
+        return [out[r, :sizes[r]] for r in range(self.world)]
+
+    def prepare(self):
+        Lmin, arg, keep = self.local.prepare()
+        n = len(Lmin)
+        # one vector per rank: [kept-matrix width (0: nothing was dropped here), Lmin, argmin,
+        # kept bits row by row]; small integers are exact in float64
+        width = 0 if keep is None else keep.shape[1]
+        mine = np.concatenate(([float(width)], Lmin, np.asarray(arg, dtype=np.float64),
+                               np.zeros(0) if keep is None else keep.astype(np.float64).ravel()))
+        parts = self._gather_vectors(mine)
+        counts = [(len(p) - 1) // (2 + int(p[0])) for p in parts]
+        Lmin = np.concatenate([p[1:1 + c] for p, c in zip(parts, counts)])
+        arg = np.concatenate([p[1 + c:1 + 2 * c] for p, c in zip(parts, counts)]).astype(int)
+        widths = [int(p[0]) for p in parts]
+        if max(widths) == 0:
             return Lmin, arg, None
-        width = max(p[2].shape[1] for p in parts if p[2] is not None)
-        keep = np.ones((len(Lmin), max(width, 1)), dtype=bool)      # a rank that dropped nothing keeps everything
+        # a rank that dropped nothing reports no matrix: all of its entries stay (the sampler masks
+        # the columns past each shelf's length)
+        keep = np.ones((len(Lmin), max(widths)), dtype=bool)
         at = 0
-        for p in parts:
-            n = len(p[0])
-            if p[2] is not None:
-                keep[at:at + n, :] = False
-                keep[at:at + n, :p[2].shape[1]] = p[2]
-            at += n
+        for p, c, w in zip(parts, counts, widths):
+            if w:
+                keep[at:at + c, :] = False
+                keep[at:at + c, :w] = p[1 + 2 * c:].reshape(c, w) != 0
+            at += c
         return Lmin, arg, keep
 
     def _reduce_flags(self, B):
@@ -281,13 +305,11 @@ class ShardedJointState(object):
         self.local.advance()
 
     def live_matrix(self):
-        torch, dist = _dist()
-        parts = [None] * self.world
-        dist.all_gather_object(parts, self.local.live_matrix())
-        return np.concatenate(parts, axis=1)
+        parts = self._gather_vectors(np.ascontiguousarray(self.local.live_matrix()).ravel())
+        return np.concatenate([p.reshape(self.nlive, -1) for p in parts], axis=1)
 
     def thresholds(self):
-        torch, dist = _dist()
-        parts = [None] * self.world
-        dist.all_gather_object(parts, self.local.thresholds())
-        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+        higher, n = self.local.thresholds()
+        parts = self._gather_vectors(np.concatenate((higher, np.asarray(n, dtype=np.float64))))
+        return (np.concatenate([p[:len(p) // 2] for p in parts]),
+                np.concatenate([p[len(p) // 2:] for p in parts]).astype(int))

@@ -707,6 +707,10 @@ def test_c3_is_the_low_acceptance_stress_it_is_meant_to_be():
                 results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=400, use_graph=False)
         finally:
             neighbors.MemberSet.count, neighbors.MemberSet.any = orig_count, orig_any
+        if sampler.native is not None:           # the draws ran in the library: its own counters
+            t = sampler.native.stats()
+            assert t["draws"] == sampler.ndraw_calls and t["tries"] == sampler.ndraws - 100
+            seen = {"proposed": t["proposals"], "inside": t["inside"]}
         stats[kind] = dict(tries_per_draw=(sampler.ndraws - 100) / sampler.ndraw_calls,
                            k3_proposals_per_try=seen["proposed"] / (sampler.ndraws - 100),
                            inside_fraction=seen["inside"] / seen["proposed"])

@@ -85,17 +85,23 @@ def _drive(dev, host, ndata, rng, iterations, exact):
     return ndraws
 
 
-@pytest.mark.parametrize("fetch_rows", [True, False])
-@pytest.mark.parametrize("ndata,nlive,nx", [(1, 5, 200), (7, 9, 33), (100, 50, 200), (1000, 40, 200), (4100, 25, 64)])
+@pytest.mark.parametrize("fetch_rows", [True, False, "backend"])
+@pytest.mark.parametrize("ndata,nlive,nx", [(1, 5, 200), (7, 9, 33), (100, 50, 200), (1000, 40, 200), (4100, 25, 64), (700, 30, 201)])
 def test_joint_state_equals_its_numpy_statement(ndata, nlive, nx, fetch_rows):
-    """fetch_rows=False is what a real run uses: the outcome of a draw -- index, fill bits --
-    arrives in mapped host memory the commit kernel writes (mdns.h, mdns_joint_fetch), the
-    likelihood row stays on the device; True copies the result buffer back."""
+    """fetch_rows=False: the outcome of a draw -- index, fill bits -- arrives in mapped host memory
+    the commit kernel writes (mdns.h, mdns_joint_fetch), the likelihood row stays on the device;
+    True copies the result buffer back.  "backend" is what a real run uses: the entry points a
+    native constrainer calls (mdns_backend_draw_begin / _chunk) -- for selections of up to 4096
+    spectra the chunk is two launches (csrc/mdns_chunk.hip: templates computed in the accept
+    kernel, candidates and row ids read from mapped host memory, commit + mailbox in one
+    workgroup); the shelf capacity of 4 also makes it grow the shelves itself."""
     rng = np.random.RandomState(ndata * 7 + nlive)
     data = gen.horns(ndata)
-    x, y = data["x"][:nx], np.ascontiguousarray(data["y"][:nx])
+    x = np.linspace(400, 800, nx) if nx > 200 else data["x"][:nx]
+    y = np.ascontiguousarray(np.vstack([data["y"], data["y"][:1]])[:nx]) if nx > 200 else np.ascontiguousarray(data["y"][:nx])
     spectra = GaussLineSpectra(x, y, noise_level=0.01)
-    dev = jointstate.GaussJointState(spectra, nlive, sample.kernel_params, shelf_cap=4, fetch_rows=fetch_rows)
+    dev = jointstate.GaussJointState(spectra, nlive, sample.kernel_params, shelf_cap=4, fetch_rows=fetch_rows is True,
+                                     via_backend=fetch_rows == "backend")
     host = jointstate.HostJointState(LaneScorer(spectra), nlive, ndata, sample.kernel_params)
     xs0 = sample.priortransform_batch(rng.uniform(size=(nlive, 3)))
     dev.init(xs0)

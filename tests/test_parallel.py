@@ -236,3 +236,44 @@ def test_direct_rccl_on_the_library_stream(tmp_path):
     out = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=300,
                          env=dict(os.environ, MDNS_DEVICE="0"))
     assert out.returncode == 0 and "RCCL OK" in out.stdout, out.stderr[-2000:]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher must start two ranks itself (torch.distributed.run
+    on 127.0.0.1) -- on a box without GPUs that ends, in the RANKS, with "no HIP device", not with a
+    request to be launched differently."""
+    import subprocess
+    if _gpu_visible():
+        pytest.skip("a GPU is visible: the ranks would run the bench (covered by the -m gpu test below)")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300)
+    text = out.stdout + out.stderr
+    assert out.returncode != 0
+    assert "must be launched with" not in text
+    assert "No HIP GPUs are available" in text or "no HIP device" in text, text[-1500:]
+
+
+def _gpu_visible():
+    from massivedatans_amd import _lib
+    try:
+        return _lib.load().mdns_device_count() > 0
+    except _lib.MdnsError:
+        return False
+
+
+@pytest.mark.gpu
+def test_bench_step_with_collectives_on_one_gpu():
+    """bench.py's distributed step on hardware as far as one GPU allows: MDNS_BENCH_FORCE_DIST=1 makes a
+    one-rank process group, so the step runs its RCCL exchanges (pool all-gather, MAX all-reduce of the
+    accept flags in place, all-gather of the fill bits) on the kernels' stream, and the line keeps the
+    contract."""
+    import json
+    import subprocess
+    env = dict(os.environ, MDNS_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29700 + os.getpid() % 200),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-e2e",
+                          "--no-hbm-leg", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0
+    assert line["config"]["collectives"], line["config"]

@@ -43,10 +43,13 @@ _live["done"] = True
 print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nlive, cap), "wall_s": duration,
                   "setup_s": time.time() - t0 - duration, "iterations": int(results["nsamples"]),
                   "ndraws": int(sampler.ndraws), "evals_useful": int(sampler.nevals),
-                  "evals_scored": int(problem.nevals + (sampler.joint.nevals_scored if sampler.joint is not None else 0)),
+                  "evals_scored": int(problem.nevals + (sampler.joint.nevals_scored if sampler.joint is not None else 0)
+                                      + (sampler.native.stats()["pairs"] if sampler.native is not None else 0)),
                   "launches": int(problem.ncalls + (sampler.joint.ncalls if sampler.joint is not None else 0)),
                   "fused": sampler.joint is not None, "constrained_draws": int(sampler.ndraw_calls),
-                  "draw_chunks": int(sampler.ndraw_chunks),
+                  "draw_chunks": int(sampler.ndraw_chunks + (sampler.native.stats()["chunks"] if sampler.native is not None else 0)),
+                  "native_constrainer": sampler.native.stats() if sampler.native is not None else None,
+                  "draw_constrained_wall_s": sampler.draw_seconds,
                   "grouping": ("graph (components on the device, %d calls)" % sampler._dgroups.ncalls) if sampler._dgroups is not None
                   else ("graph (host)" if sampler.use_graph else "walk (host)"),
                   "useful_evals_per_s": sampler.nevals / duration,
