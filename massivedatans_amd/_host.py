@@ -14,7 +14,8 @@ def lib():
     """The library handle, or None when it has not been built."""
     global _LIB
     if _LIB is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdns_host.so")
+        # (MDNS_HOST_LIB: another build of the same sources, e.g. the sanitizer build of tests/test_sanitizers.py)
+        path = os.environ.get("MDNS_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmdns_host.so")
         try:
             L = ctypes.CDLL(path)
             L.mdns_host_group_walk.restype = ctypes.c_int

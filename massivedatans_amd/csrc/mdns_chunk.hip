@@ -25,105 +25,109 @@ static constexpr int kCH = 8;              // channels per stage
 
 typedef JointMailbox ChunkMailbox;          // what the host finds in mapped memory after a chunk
 
-template <int BT, int NB>
+// quad broadcast: every lane of a quad gets the value lane Q of the quad holds (DPP quad_perm)
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v)
+{
+	constexpr int ctrl = Q | (Q << 2) | (Q << 4) | (Q << 6);
+	const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, 0xf, 0xf, true);
+	const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, 0xf, 0xf, true);
+	return __hiloint2double(hi, lo);
+}
+
+// Work of one workgroup: 64 selected spectra (one tile of the selection) x 4 candidates (one
+// candidate tile).  A quad of lanes shares ONE spectrum: lane q of the quad LOADS the q-th quarter
+// of every 64-byte stage of the row (so four adjacent lanes read one cache line and a wave's load
+// touches 16 lines -- with one lane per spectrum it would be 64 lines four times over, and the
+// texture-address unit, one line per clock, was the bound: 33 us measured), and SCORES candidate q
+// of the tile against the whole spectrum, the other three quarters of a stage arriving by quad
+// broadcasts (DPP moves inside the VALU).  The chain of a (candidate, spectrum) pair is unchanged:
+// one accumulator, channels ascending, d = m - y, acc = fma(d, d, acc).
+// NST = stages held in registers: the whole row is requested before the first sum starts.
+template <int NST>
 __global__ __launch_bounds__(256) void k_chunk_accept(
     const double *__restrict__ Y, int ld, int nx, int nxp, const double *__restrict__ xgrid,
     const double *__restrict__ params, int B, double scale,
     const int *__restrict__ rows, int *__restrict__ rows_dev, int M, int ntiles,
-    const double *__restrict__ higher, int *__restrict__ flags, int stamp, JointTrail trail)
+    const double *__restrict__ higher, int *__restrict__ flags, int stamp, JointTrail trail, JointHeader *__restrict__ header)
 {
 	extern __shared__ __attribute__((aligned(16))) double lds[];
-	double *tpl = lds;                                  // [nxp][BT]
-	double *par = lds + (size_t) nxp * BT;              // [BT][3]
+	if (blockIdx.x == 0 && threadIdx.x == 0) header->status = 0;       // the commit pass may raise it
+	double2 *tpl = reinterpret_cast<double2 *>(lds);            // [nxp / 2][4 candidates] pairs of channels
+	double *par = lds + (size_t) nxp * 4;                       // [4][3]
+	unsigned long long *votes = reinterpret_cast<unsigned long long *>(par + 12);   // [4 waves]
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-	const int nquads = (ntiles + 3) >> 2;
-	const int bt = blockIdx.x / nquads, quad = blockIdx.x - bt * nquads;
-	const int tile = quad * 4 + wave;
-	// 1. the candidates of this tile (host memory: issue first, the latency is the PCIe round trip)
+	const int q = lane & 3;                                     // quarter loaded, candidate scored
+	const int bt = blockIdx.x / ntiles, tile = blockIdx.x - bt * ntiles;
+	// 1. the candidates of this tile (host memory: issued first, the latency is the PCIe round trip)
 	double pv = 0.0;
-	if (threadIdx.x < BT * 3) {
-		const int b = bt * BT + threadIdx.x / 3;
+	if (threadIdx.x < 12) {
+		const int b = bt * 4 + threadIdx.x / 3;
 		pv = b < B ? params[(size_t) b * 3 + threadIdx.x % 3] : 0.0;
 	}
-	// 2. this lane's spectrum
-	const int k = tile * 64 + lane;
-	const bool live = tile < ntiles && k < M;
-	int row = 0;
-	if (tile < ntiles) {
-		const int kk = k < M ? k : M - 1;
-		row = rows ? rows[kk] : kk;
-		if (rows_dev && bt == 0 && k < M) rows_dev[k] = row;          // for the commit kernel
-	}
+	// 2. this quad's spectrum: all of its row requested at once
+	const int r = wave * 16 + (lane >> 2);                     // position in the tile
+	const int k = tile * 64 + r;
+	const bool live = k < M;
+	const int kk = live ? k : M - 1;
+	const int row = rows ? rows[kk] : kk;
+	if (rows_dev && bt == 0 && live && q == 0) rows_dev[k] = row;      // for the commit kernel
 	const double *yr = Y + (size_t) row * ld;
 	const int nst = nxp / kCH;
-	double y[NB][kCH];
-	// channels at or beyond the row's length are padding: read a valid pair, use zeros
-	auto load_stage = [&](double (&dst)[kCH], int s) {
+	double2 y[NST];
 #pragma unroll
-		for (int c = 0; c < kCH; c += 2) {
-			const int j = s * kCH + c;
-			const int jj = j < ld ? j : 0;
-			const double2 v = *reinterpret_cast<const double2 *>(yr + jj);
-			dst[c] = j < ld ? v.x : 0.0;
-			dst[c + 1] = j < ld ? v.y : 0.0;
-		}
-	};
-	if (tile < ntiles) {
-#pragma unroll
-		for (int i = 0; i < NB - 1; i++) load_stage(y[i], i < nst ? i : nst - 1);
+	for (int s = 0; s < NST; s++) {
+		const int j = s * kCH + 2 * q;
+		const double2 v = *reinterpret_cast<const double2 *>(yr + (j < ld ? j : 0));
+		// channels at or beyond the row's length are padding: zeros
+		y[s].x = j < ld ? v.x : 0.0;
+		y[s].y = j < ld ? v.y : 0.0;
 	}
 	const double thr = live ? higher[row] : __builtin_nan("");          // NaN compares false: no vote
 	// 3. templates of the candidate tile, computed here (clike.c:65: A exp(-0.5 ((mu - x)/sig)^2))
-	if (threadIdx.x < BT * 3) par[threadIdx.x] = pv;
+	if (threadIdx.x < 12) par[threadIdx.x] = pv;
 	__syncthreads();
-	for (int e = threadIdx.x; e < nxp * BT; e += 256) {
-		const int j = e / BT, bb = e - j * BT;
+	for (int e = threadIdx.x; e < nxp * 4; e += 256) {
+		const int j = e >> 2, bb = e & 3;
 		double m = 0.0;
-		if (j < nx && bt * BT + bb < B) {
+		if (j < nx && bt * 4 + bb < B) {
 			const double A = par[bb * 3], mu = par[bb * 3 + 1], sig = par[bb * 3 + 2];
 			const double t = (mu - xgrid[j]) / sig;
 			m = A * exp(-0.5 * (t * t));
 		}
-		tpl[e] = m;
+		lds[((size_t) (j >> 1) * 4 + bb) * 2 + (j & 1)] = m;
 	}
 	__syncthreads();
-	if (tile >= ntiles) return;
-	// 4. the sums, NB - 1 stages of spectra in flight
-	double acc[BT];
+	// 4. the sum of (candidate q, this spectrum)
+	double acc = 0.0;
 #pragma unroll
-	for (int b = 0; b < BT; b++) acc[b] = 0.0;
-#pragma unroll 1
-	for (int s0 = 0; s0 < nst; s0 += NB) {
-#pragma unroll
-		for (int i = 0; i < NB; i++) {
-			const int s = s0 + i;                                   // wave-uniform
-			if (s < nst) {
-				const int ahead = s + NB - 1;
-				load_stage(y[(i + NB - 1) % NB], ahead < nst ? ahead : nst - 1);
-				const double *m = tpl + s * kCH * BT;
-#pragma unroll
-				for (int c = 0; c < kCH; c++)
-#pragma unroll
-					for (int b = 0; b < BT; b++) {
-						const double d = m[c * BT + b] - y[i][c];
-						acc[b] = fma(d, d, acc[b]);
-					}
-			}
+	for (int s = 0; s < NST; s++) {
+		if (s < nst) {                                              // wave-uniform
+			const double2 *m = tpl + (size_t) s * 16 + q;           // 4 channel pairs x 4 candidates per stage
+			double d;
+#define QUARTER(QQ) { const double2 mv = m[QQ * 4]; \
+			d = mv.x - quad_bcast<QQ>(y[s].x); acc = fma(d, d, acc); \
+			d = mv.y - quad_bcast<QQ>(y[s].y); acc = fma(d, d, acc); }
+			QUARTER(0) QUARTER(1) QUARTER(2) QUARTER(3)
+#undef QUARTER
 		}
 	}
-	// 5. accept test
-#pragma unroll
-	for (int b = 0; b < BT; b++) {
-		const double L = acc[b] * scale;
-		const unsigned long long word = __ballot(L > thr);
-		if (word != 0ull && bt * BT + b < B) {
-			const size_t at = (size_t) (bt * BT + b) * ntiles + tile;
-			trail.L[at * 64 + lane] = L;
-			if (lane == 0) {
-				flags[bt * BT + b] = stamp;
-				trail.word[at] = word;
-				trail.stamp_of[at] = trail.stamp;
-			}
+	// 5. accept test: lane (spectrum r, candidate q)
+	const double L = acc * scale;
+	const bool beat = L > thr && bt * 4 + q < B;
+	const unsigned long long vote = __ballot(beat);                 // bit 4 i + q: spectrum wave * 16 + i, candidate q
+	if (lane == 0) votes[wave] = vote;
+	if (beat) trail.L[((size_t) (bt * 4 + q) * ntiles + tile) * 64 + r] = L;
+	__syncthreads();
+	// wave w' puts together the word of candidate w': lane l = spectrum l of the tile
+	{
+		const int cand = wave;
+		const unsigned long long word = __ballot((votes[lane >> 4] >> (4 * (lane & 15) + cand)) & 1ull);
+		if (word != 0ull && lane == 0) {
+			const size_t at = (size_t) (bt * 4 + cand) * ntiles + tile;
+			flags[bt * 4 + cand] = stamp;
+			trail.word[at] = word;
+			trail.stamp_of[at] = trail.stamp;
 		}
 	}
 }
@@ -202,46 +206,32 @@ static bool launched(const char *name)
 	return false;
 }
 
-// candidates per workgroup of the small-chunk accept kernel
-int chunk_tile(int M, int B)
-{
-	(void) M;
-	return B >= 4 ? 4 : (B >= 2 ? 2 : 1);
-}
-
 // whether a chunk of B candidates over M selected spectra takes the two-launch path
 bool chunk_fits(const mdns_spectra *s, int M, int B)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
-	const int bt = chunk_tile(M, B);
-	const long long waves = (long long) ntiles * ((B + bt - 1) / bt);
-	const size_t lds = ((size_t) cols_nx(s->nx) * bt + 3 * bt) * sizeof(double);
-	return ntiles <= 64 && waves <= 16LL * c->num_cus && lds <= 60 * 1024 && s->d_x != nullptr;
+	const long long groups = (long long) ntiles * ((B + 3) / 4);
+	return ntiles <= 64 && groups <= 16LL * c->num_cus && cols_nx(s->nx) <= 8 * 32 && s->d_x != nullptr;
 }
 
 bool launch_chunk_accept(const mdns_spectra *s, const double *d_params_mapped, int B, double scale,
-                         const int *d_rows_mapped, int *d_rows_dev, int M, const double *d_higher,
-                         int *d_flags, int stamp, const JointTrail &trail)
+                         const int *d_rows_in, int *d_rows_dev, int M, const double *d_higher,
+                         int *d_flags, int stamp, const JointTrail &trail, void *d_header)
 {
 	Context *c = ctx();
-	const int ntiles = (M + 63) / 64, nquads = (ntiles + 3) / 4;
-	const int bt = chunk_tile(M, B);
-	const int nbt = (B + bt - 1) / bt;
+	const int ntiles = (M + 63) / 64;
+	const int nbt = (B + 3) / 4;
 	const int nxp = cols_nx(s->nx);
-	const size_t lds = ((size_t) nxp * bt + 3 * bt) * sizeof(double);
-	// stages in flight: all of a 200-channel spectrum in two rounds
+	const size_t lds = ((size_t) nxp * 4 + 12 + 4) * sizeof(double);
 	const int nst = nxp / kCH;
 	ProfileScope prof(0);
-#define CHUNK_LAUNCH(BT, NB) hipLaunchKernelGGL((k_chunk_accept<BT, NB>), dim3(nquads * nbt), dim3(256), lds, c->stream, \
-	s->d_y, s->ld, s->nx, nxp, s->d_x, d_params_mapped, B, scale, d_rows_mapped, d_rows_dev, M, ntiles, d_higher, d_flags, stamp, trail)
-	if (nst > 8) {
-		note_kernel(0, "k_chunk_accept<%d, 13>", bt);
-		switch (bt) { case 4: CHUNK_LAUNCH(4, 13); break; case 2: CHUNK_LAUNCH(2, 13); break; default: CHUNK_LAUNCH(1, 13); break; }
-	} else {
-		note_kernel(0, "k_chunk_accept<%d, 4>", bt);
-		switch (bt) { case 4: CHUNK_LAUNCH(4, 4); break; case 2: CHUNK_LAUNCH(2, 4); break; default: CHUNK_LAUNCH(1, 4); break; }
-	}
+#define CHUNK_LAUNCH(NST) hipLaunchKernelGGL((k_chunk_accept<NST>), dim3(ntiles * nbt), dim3(256), lds, c->stream, \
+	s->d_y, s->ld, s->nx, nxp, s->d_x, d_params_mapped, B, scale, d_rows_in, d_rows_dev, M, ntiles, d_higher, d_flags, stamp, trail, (JointHeader *) d_header)
+	if (nst <= 8) { note_kernel(0, "k_chunk_accept<8>"); CHUNK_LAUNCH(8); }
+	else if (nst <= 16) { note_kernel(0, "k_chunk_accept<16>"); CHUNK_LAUNCH(16); }
+	else if (nst <= 26) { note_kernel(0, "k_chunk_accept<26>"); CHUNK_LAUNCH(26); }
+	else { note_kernel(0, "k_chunk_accept<32>"); CHUNK_LAUNCH(32); }
 #undef CHUNK_LAUNCH
 	return launched("k_chunk_accept");
 }

@@ -105,7 +105,7 @@ struct JointMailbox { unsigned long long seq; int accepted; int status; unsigned
 bool chunk_fits(const mdns_spectra *s, int M, int B);
 bool launch_chunk_accept(const mdns_spectra *s, const double *d_params_mapped, int B, double scale,
                          const int *d_rows_in, int *d_rows_dev, int M, const double *d_higher,
-                         int *d_flags, int stamp, const JointTrail &trail);
+                         int *d_flags, int stamp, const JointTrail &trail, void *d_header);
 bool launch_chunk_commit(const int *d_thr_rows, int M, int B, const int *d_flags, int stamp, const JointTrail &trail,
                          const JointArrays &st, void *d_header, unsigned long long *d_fillbits, void *box_dev,
                          unsigned long long seq);
@@ -114,8 +114,9 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
                               const double *d_higher, int *d_flags, const JointTrail &trail);
 // first flagged candidate from the trail of the accept pass: fill bits, shelf appends, thresholds
+// (flag_value: what the accept pass wrote into d_flags for an accepted candidate)
 bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,
-                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits);
+                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits, int flag_value = 1);
 // first flagged candidate: its likelihood row, fill bits, shelf appends, new thresholds
 bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M, const int *d_flags,

@@ -222,6 +222,9 @@ struct mdns_joint {
 	int sel_M = 0;
 	bool sel_open = false;
 	bool sel_on_device = false;        // d_sel_rows holds the selection (a chunk kernel or a copy put it there)
+	// accepted candidates of a two-launch chunk are flagged with the chunk's own number (never reused,
+	// never 1 -- the flag value of the other path -- so the flag buffer needs no clearing)
+	int chunk_seq = 1;
 	// what the chunk kernels read directly: candidates, then the selection's row ids, in host
 	// memory mapped into the device
 	char *h_in = nullptr, *h_in_dev = nullptr;
@@ -813,8 +816,8 @@ extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B,
 	if (B == 0 || M == 0) return 0;
 	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
 	const size_t pbytes = (size_t) B * 24;
-	static const char *no_fast = getenv("MDNS_CHUNK_PATH");           // "old": experiments only
-	if (chunk_fits(j->s, M, B) && !(no_fast && !strcmp(no_fast, "old"))) {
+	static const char *chunk_path = getenv("MDNS_CHUNK_PATH");        // "classic": the five-command chunk (experiments)
+	if (chunk_fits(j->s, M, B) && !(chunk_path && !strcmp(chunk_path, "classic"))) {
 		// two launches: the kernels read candidates and (first chunk of the draw) the selection
 		// from the mapped block; nothing is copied, nothing is cleared
 		memcpy(j->h_in, params, pbytes);
@@ -827,13 +830,26 @@ extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B,
 			else { rows_in = (const int *) (j->h_in_dev + kInParams); rows_out = j->d_sel_rows; }
 		}
 		const double scale = -0.5 / (j->noise_level * j->noise_level);
-		if (!launch_chunk_accept(j->s, (const double *) j->h_in_dev, B, scale, rows_in, rows_out, M, j->st.higher,
-		                         j->d_flags, trail.stamp, trail)) return 1;
-		if (j->sel_rows) j->sel_on_device = true;
+		if (j->chunk_seq == 0x7fffffff) {
+			if (!MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kFlagInts * sizeof(int), c->stream))) return 1;
+			j->chunk_seq = 1;
+		}
+		const int flag = ++j->chunk_seq;
 		char *base = j->d_result;
 		unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
-		if (!launch_chunk_commit(j->sel_rows ? j->d_sel_rows : nullptr, M, B, j->d_flags, trail.stamp, trail, j->st, base, bits,
-		                         j->h_box_dev, ++j->box_seq)) return 1;
+		if (!launch_chunk_accept(j->s, (const double *) j->h_in_dev, B, scale, rows_in, rows_out, M, j->st.higher,
+		                         j->d_flags, flag, trail, base)) return 1;
+		if (j->sel_rows) j->sel_on_device = true;
+		const int *thr_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+		if (M <= 128) {
+			// a tile or two: shelf appends, thresholds and the mailbox in ONE workgroup
+			if (!launch_chunk_commit(thr_rows, M, B, j->d_flags, flag, trail, j->st, base, bits, j->h_box_dev, ++j->box_seq)) return 1;
+		} else {
+			if (!launch_joint_commit_trail(thr_rows, M, B, j->d_flags, trail, j->st, base, bits, flag)) return 1;
+			hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
+			                   j->h_box_dev, ++j->box_seq);
+			if (!MDNS_HIP(hipGetLastError())) return 1;
+		}
 		j->box_pending = true;
 		j->trail_valid = false;
 		j->last_B = 0;

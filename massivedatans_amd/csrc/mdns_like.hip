@@ -574,14 +574,14 @@ __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_accept(
 // positions of the selection, one lane per data set.  Same shelf / threshold update as
 // k_gauss_cols_commit (multi_nested_sampler.py:482-485, :438-447).
 __global__ __launch_bounds__(kBlock) void k_joint_commit_trail(
-    const int *__restrict__ thr_rows, int M, int B, int ntiles, const int *__restrict__ flags, JointTrail trail,
+    const int *__restrict__ thr_rows, int M, int B, int ntiles, const int *__restrict__ flags, int flag_value, JointTrail trail,
     JointArrays st, JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits)
 {
 	__shared__ int s_first;
 	if (threadIdx.x == 0) s_first = 0x7fffffff;
 	__syncthreads();
 	for (int b = threadIdx.x; b < B; b += kBlock)
-		if (flags[b]) { atomicMin(&s_first, b); break; }      // ascending per thread: its first is its lowest
+		if (flags[b] == flag_value) { atomicMin(&s_first, b); break; }      // ascending per thread: its first is its lowest
 	__syncthreads();
 	const int bstar = s_first;
 	if (blockIdx.x == 0 && threadIdx.x == 0) header->accepted = bstar < B ? bstar : -1;
@@ -607,12 +607,12 @@ __global__ __launch_bounds__(kBlock) void k_joint_commit_trail(
 			int at_most = 0;
 			double next = INFINITY;
 			int p = 0;
-			for (; p + 8 <= st.nlive; p += 8) {                      // eight loads in flight
-				double v[8];
+			for (; p + 25 <= st.nlive; p += 25) {                    // 25 loads in flight (the latency of a round trip, not the count, is what this pass costs)
+				double v[25];
 #pragma unroll
-				for (int u = 0; u < 8; u++) v[u] = st.live[(size_t) (p + u) * st.ndata + d];
+				for (int u = 0; u < 25; u++) v[u] = st.live[(size_t) (p + u) * st.ndata + d];
 #pragma unroll
-				for (int u = 0; u < 8; u++) { if (v[u] <= thr) at_most++; else next = fmin(next, v[u]); }
+				for (int u = 0; u < 25; u++) { if (v[u] <= thr) at_most++; else next = fmin(next, v[u]); }
 			}
 			for (; p < st.nlive; p++) {
 				const double v = st.live[(size_t) p * st.ndata + d];
@@ -1098,12 +1098,12 @@ bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const d
 }
 
 bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,
-                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits)
+                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits, int flag_value)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
 	hipLaunchKernelGGL(k_joint_commit_trail, dim3((ntiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-	                   d_thr_rows, M, B, ntiles, d_flags, trail, st, (JointHeader *) d_header, d_fillbits);
+	                   d_thr_rows, M, B, ntiles, d_flags, flag_value, trail, st, (JointHeader *) d_header, d_fillbits);
 	return launched("k_joint_commit_trail");
 }
 

@@ -7,8 +7,8 @@ order and ``draw_constrained(Lmins, priortransform, loglikelihood, live_pointsu,
 
 * Candidates are handed out from an explicit buffer instead of a nested Python generator, so
   that the candidates ALREADY proposed (and only those -- no RNG is consumed early) can be
-  scored on the GPU in one batch (``loglikelihood_batch`` keyword).  Likelihood values of
-  look-ahead candidates are cached until the candidates are consumed.
+  handed to a joint state in chunks (``draw_batch`` keyword, ``_draw_chunks``): the chunked loop
+  is the Python statement of what ``csrc/host_constrainer.cpp`` does in one native call.
 * ``float > None`` (hiermetriclearn.py:53 on the first build) follows Python 2, where the
   reference was written: the comparison is true, so the first build computes the radius twice
   (SURVEY.md appendix A#1).
@@ -28,9 +28,6 @@ class MetricLearningFriendsConstrainer(object):
     REGION_BATCH = 10000
     #: probability of an extra unit-cube proposal round after each region refill (:126)
     CUBE_PROBABILITY = 0.1
-    #: most candidates scored ahead of need in one likelihood launch (the batch size bench.py
-    #: times; the depth only reaches it in long unsuccessful streaks, doubling with the tries)
-    MAX_LOOKAHEAD = 256
 
     def __init__(self, metriclearner, rebuild_every=50, metric_rebuild_every=50, verbose=False,
                  keep_phantom_points=False, optimize_phantom_points=False, force_shrink=False):
@@ -49,7 +46,7 @@ class MetricLearningFriendsConstrainer(object):
         self.clusters = None
         self.generator = None
         self._reset_buffer()
-        #: number of (candidate, data set) likelihood evaluations requested, incl. look-ahead
+        #: number of (candidate, data set) likelihood evaluations requested
         self.nevals_requested = 0
 
     # ---- region construction ------------------------------------------------------------
@@ -143,9 +140,6 @@ class MetricLearningFriendsConstrainer(object):
         self._buf = None          # candidates already proposed, not yet consumed
         self._buf_pos = 0
         self._buf_ntotal = 0
-        self._ahead_L = None      # likelihoods of _buf[_ahead_lo : _ahead_lo + len(_ahead_L)]
-        self._ahead_lo = 0
-        self._ahead_key = None
 
     def _next_candidate(self):
         """Next candidate and the proposal count the reference's generator would report with it
@@ -153,32 +147,10 @@ class MetricLearningFriendsConstrainer(object):
         if self._buf is None or self._buf_pos >= len(self._buf):
             self._buf, self._buf_ntotal = next(self.generator)      # consumes RNG, exactly on demand
             self._buf_pos = 0
-            self._ahead_L = None
         u = self._buf[self._buf_pos]
         ntotal = self._buf_ntotal if self._buf_pos == 0 else 0
         self._buf_pos += 1
         return u, ntotal
-
-    def _score(self, u, priortransform, loglikelihood, loglikelihood_batch, mask_key, lookahead):
-        """Likelihood vector of candidate ``u`` (= ``_buf[_buf_pos - 1]``), scoring up to
-        ``lookahead`` further buffered candidates in the same launch when a batch scorer is
-        available."""
-        pos = self._buf_pos - 1
-        if self._ahead_L is not None and self._ahead_key == mask_key and \
-                self._ahead_lo <= pos < self._ahead_lo + len(self._ahead_L):
-            return priortransform(u), self._ahead_L[pos - self._ahead_lo]
-        x = priortransform(u)
-        if loglikelihood_batch is None or lookahead <= 1 or pos + 1 >= len(self._buf):
-            self._ahead_L = None
-            L = loglikelihood(x)
-            self.nevals_requested += len(L)
-            return x, L
-        stop = min(len(self._buf), pos + lookahead)
-        xs = numpy.array([priortransform(v) for v in self._buf[pos:stop]])
-        Ls = loglikelihood_batch(xs)
-        self.nevals_requested += Ls.size
-        self._ahead_L, self._ahead_lo, self._ahead_key = Ls, pos, mask_key
-        return x, Ls[0]
 
     def _draw_chunks(self, draw_batch, live_pointsu, ndim, region_rebuilt, metric_rebuilt):
         """The accept loop of hiermetriclearn.py:181-211 with the candidates handed over in
@@ -192,7 +164,6 @@ class MetricLearningFriendsConstrainer(object):
             if self._buf is None or self._buf_pos >= len(self._buf):
                 self._buf, self._buf_ntotal = next(self.generator)      # consumes RNG, exactly on demand
                 self._buf_pos = 0
-                self._ahead_L = None
                 if self._buf_ntotal > 100000:
                     self.direct_draws_efficient = False
             room = len(self._buf) - self._buf_pos
@@ -243,19 +214,18 @@ class MetricLearningFriendsConstrainer(object):
     def draw_constrained(self, Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs):
         """Propose until a candidate beats the threshold of at least one data set
         (hiermetriclearn.py:173-211).  Returns ``(u, x, L, n_likelihood_calls)``."""
-        loglikelihood_batch = kwargs.get('loglikelihood_batch')
-        mask_key = kwargs.get('mask_key')
         self.iter_since_metric_rebuild += 1
         region_rebuilt, metric_rebuilt = self._draw_constrained_prepare(
             Lmins, priortransform, loglikelihood, live_pointsu, ndim, **kwargs)
         if kwargs.get('draw_batch') is not None:
             return self._draw_chunks(kwargs['draw_batch'], live_pointsu, ndim, region_rebuilt, metric_rebuilt)
-        lookahead = min(self.MAX_LOOKAHEAD, max(1, getattr(self, '_last_ntoaccept', 1)))
         tries = 0
         while True:
             u, nproposed = self._next_candidate()
             assert (u >= 0).all() and (u <= 1).all(), u
-            x, L = self._score(u, priortransform, loglikelihood, loglikelihood_batch, mask_key, lookahead)
+            x = priortransform(u)
+            L = loglikelihood(x)
+            self.nevals_requested += len(L)
             tries += 1
             self.ndraws_since_rebuild += 1
             if nproposed > 100000:
@@ -263,7 +233,6 @@ class MetricLearningFriendsConstrainer(object):
             if numpy.any(L > Lmins):
                 self._last_ntoaccept = tries
                 return u, x, L, tries
-            lookahead = min(self.MAX_LOOKAHEAD, max(lookahead, 2 * tries))
             # a long unsuccessful streak tightens the region -- each kind at most once per draw
             # (hiermetriclearn.py:198-211); the candidate stream restarts from the new region
             if not region_rebuilt and self.ndraws_since_rebuild > self.rebuild_every:

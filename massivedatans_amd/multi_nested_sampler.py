@@ -17,8 +17,8 @@ State (names as in the reference):
   superpoints                            ids still shared by ALL data sets
 
 What differs from the reference is mechanical: no printing (``logging`` at DEBUG), the initial
-``nlive`` likelihood vectors come from one batched launch, the constrainers get an optional
-batch scorer (``loglikelihood_batch``) so that they can look ahead on the GPU, and the
+``nlive`` likelihood vectors come from one batched launch, the constrainers can hand whole
+chunks of proposed candidates to a joint state (``draw_batch``) or be native objects, and the
 per-data-set Python loops of the reference (shelf lists, ``numpy.unique`` over the whole id
 matrix every iteration) are array operations: at 10 000 data sets they, not the likelihood,
 set the wall-clock.  None of this changes a single value (tests/test_orchestration.py).
@@ -703,10 +703,6 @@ class MultiNestedSampler(object):
                         rows = real_rows if real_rows is not None else real_indices[joint_indices]
                     last = {}
                     extra['draw_batch'] = lambda us, hint, rows=rows, last=last: self._draw_batch(us, rows, last, hint)
-                elif self.multi_loglikelihood_batch is not None:
-                    extra['loglikelihood_batch'] = \
-                        lambda ps, m=joint_data_mask: self.multi_loglikelihood_batch(ps, m)
-                    extra['mask_key'] = (self.ndata, joint_data_mask.tobytes())
                 t_draw = time.perf_counter()
                 uj, xj, Lj, n = draw(
                     Lmins=Lmins_higher, priortransform=self.priortransform,

@@ -46,7 +46,7 @@ def run_case(g, oracle, batched, fused=False, native=False):
 # "native": the same with every constrainer a constrainer.NativeConstrainer -- region, proposals
 # (numpy's own Mersenne Twister stepped in C), prior transform and accept loop of a draw in ONE call
 # of csrc/host_constrainer.cpp, the oracle behind its backend table
-@pytest.mark.parametrize("mode", ["single", "batched", "fused", "native"])
+@pytest.mark.parametrize("mode", ["single", "fused", "native"])
 def test_trace_bit_exact(case, mode, oracle, monkeypatch):
     g = load_trace(case)
     batched = mode != "single"
@@ -55,9 +55,9 @@ def test_trace_bit_exact(case, mode, oracle, monkeypatch):
         if not constrainer.available():
             pytest.skip("libmdns_host.so not built")
     if case == "horns6" and mode not in ("single", "native"):
-        pytest.skip("242k draws: run once, unbatched")
+        pytest.skip("242k draws: run one candidate at a time and native")
     if case.startswith("horns100") and mode == "single":
-        pytest.skip("44k draws: run batched and fused")
+        pytest.skip("44k draws: run fused and native")
     patch_neighbors(monkeypatch, oracle)
     with np.errstate(all="ignore"):
         results, sampler, rec, rng_probe = run_case(g, oracle, batched, fused=(mode in ("fused", "native")),
