@@ -164,6 +164,10 @@ double mdns_region_radius(mdns_region *r);
  * counts int32[M] overwritten.  Host pointers (synchronous) / device pointers (asynchronous). */
 int mdns_region_count(mdns_region *r, const double *points, int M, int *counts);
 int mdns_region_count_dev(mdns_region *r, const double *d_points, int M, int *d_counts);
+/* mdns_region_count with the shortest round trip (what a native constrainer calls once per 1000
+ * proposals): points through a pinned block, counts exported by a kernel into host memory mapped
+ * into the device, polled -- no pageable copies, no stream synchronisation. */
+int mdns_region_count_polled(mdns_region *r, const double *points, int M, int *counts);
 
 /* ------------------------------------------------------------------------------------ */
 /* Part 2b: the constrained draw decided on the device (extension) */
@@ -466,9 +470,12 @@ int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, cons
 /* counters since creation, out int64[MDNS_CONSTRAINER_COUNTERS]: [0] draws, [1] chunks, [2] candidates
  * scored, [3] (candidate, data set) pairs scored, [4] regions built, [5] radius computations (K6),
  * [6] membership calls (K3), [7] raw proposals, [8] proposals the region kept, [9] tries (the
- * reference's likelihood calls).  mdns_constrainer_share_stats: every increment is also added to
- * totals int64[MDNS_CONSTRAINER_COUNTERS] (the caller's: the sum over a sampler's constrainers). */
-#define MDNS_CONSTRAINER_COUNTERS 10
+ * reference's likelihood calls); nanoseconds spent in [10] the bootstrap choices, [11] region_create
+ * (K6 + upload), [12] region_count (K3), [13] proposal random numbers + arithmetic, [14] the prior
+ * transform, [15] draw_chunk, [16] mdns_constrainer_draw as a whole.  mdns_constrainer_share_stats:
+ * every increment is also added to totals int64[MDNS_CONSTRAINER_COUNTERS] (the caller's: the sum
+ * over a sampler's constrainers). */
+#define MDNS_CONSTRAINER_COUNTERS 17
 void mdns_constrainer_stats(const mdns_constrainer *c, long long *out);
 void mdns_constrainer_share_stats(mdns_constrainer *c, long long *totals);
 const char *mdns_host_last_error(void);

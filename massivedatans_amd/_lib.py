@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "mdns_region_create", "mdns_region_create_bootstrapped", "mdns_region_wrap_dev", "mdns_region_destroy",
     "mdns_region_bootstrap_radius", "mdns_region_bootstrap_radius_dev", "mdns_region_bootstrap_radius_packed",
     "mdns_region_bootstrap_radius_async", "mdns_region_set_radius",
-    "mdns_region_radius", "mdns_region_count", "mdns_region_count_dev",
+    "mdns_region_radius", "mdns_region_count", "mdns_region_count_dev", "mdns_region_count_polled",
     "mdns_dev_alloc", "mdns_dev_free", "mdns_h2d", "mdns_d2h", "mdns_d2d", "mdns_sync", "mdns_set_stream",
     "mdns_event_create", "mdns_event_destroy", "mdns_event_record", "mdns_event_elapsed_ms",
     "mdns_profile", "mdns_profile_every", "mdns_profile_read", "mdns_profile_kernel",
@@ -96,6 +96,7 @@ def _declare(lib):
         "mdns_region_radius": (d, [vp]),
         "mdns_region_count": (i, [vp, vp, i, vp]),
         "mdns_region_count_dev": (i, [vp, vp, i, vp]),
+        "mdns_region_count_polled": (i, [vp, vp, i, vp]),
         "mdns_dev_alloc": (vp, [sz]),
         "mdns_dev_free": (None, [vp]),
         "mdns_h2d": (i, [vp, vp, sz]),

@@ -56,7 +56,8 @@ class NumpyOps(C.Structure):               # mdns_numpy_ops
 
 METRICS = {'none': 0, 'simplescaling': 1, 'truncatedscaling': 2}
 #: mdns_constrainer_stats (include/mdns.h)
-COUNTERS = ("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals", "inside", "tries")
+COUNTERS = ("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals", "inside", "tries",
+            "ns_bootstrap", "ns_region", "ns_count", "ns_propose", "ns_transform", "ns_chunk", "ns_draw")
 
 _HOST = None
 

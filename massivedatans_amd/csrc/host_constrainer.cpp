@@ -22,11 +22,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <time.h>
 #include <vector>
 
 #include "mdns.h"
 
 extern "C" int mdns_host_bootstrap_masks_mt(void *state, int64_t K, int rounds, uint32_t *masks);
+extern "C" int mdns_host_bootstrap_skip_mt(void *state, int64_t K, int rounds);
 
 namespace {
 
@@ -176,7 +178,17 @@ struct Metric {
 // region (clustering/radfriendsregion.py)
 // ---------------------------------------------------------------------------------------
 // index of a counter in mdns_constrainer_stats' output
-enum { N_DRAWS, N_CHUNKS, N_CANDIDATES, N_PAIRS, N_REGIONS, N_RADII, N_COUNTS, N_PROPOSALS, N_INSIDE, N_TRIES, N_COUNTERS };
+enum { N_DRAWS, N_CHUNKS, N_CANDIDATES, N_PAIRS, N_REGIONS, N_RADII, N_COUNTS, N_PROPOSALS, N_INSIDE, N_TRIES,
+       // nanoseconds spent in: the bootstrap choice, region_create (K6 + upload), region_count (K3),
+       // proposal arithmetic + random numbers, prior transform, draw_chunk, the whole draw call
+       T_BOOTSTRAP, T_REGION, T_COUNT, T_PROPOSE, T_TRANSFORM, T_CHUNK, T_DRAW, N_COUNTERS };
+
+inline long long now_ns()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (long long) ts.tv_sec * 1000000000LL + ts.tv_nsec;
+}
 
 struct Counters {
 	long long v[N_COUNTERS] = {0};
@@ -208,7 +220,9 @@ struct Region {
 	{
 		if (!has_radius) {
 			double r = 0;
+			const long long t0 = now_ns();
 			handle = be->region_create(be->user, members.data(), K, ndim, masks.data(), nbootstraps, &r);
+			if (stat) stat->add(T_REGION, now_ns() - t0);
 			if (!handle) { set_error("region_create (K6) failed for %d points", K); return false; }
 			radius = r;
 			has_radius = true;
@@ -223,7 +237,9 @@ struct Region {
 		double r;
 		if (!maxdistance(&r)) return false;
 		if (!handle) {
+			const long long t0 = now_ns();
 			handle = be->region_create(be->user, members.data(), K, ndim, nullptr, 0, &r);
+			if (stat) stat->add(T_REGION, now_ns() - t0);
 			if (!handle) { set_error("region_create failed for %d points", K); return false; }
 		}
 		return true;
@@ -232,7 +248,10 @@ struct Region {
 	{
 		if (!member_set()) return false;
 		if (stat) stat->add(N_COUNTS, 1);
-		if (be->region_count(be->user, handle, points, n, counts) != 0) { set_error("region_count failed"); return false; }
+		const long long t0 = now_ns();
+		const int rc = be->region_count(be->user, handle, points, n, counts);
+		if (stat) stat->add(T_COUNT, now_ns() - t0);
+		if (rc != 0) { set_error("region_count failed"); return false; }
 		return true;
 	}
 	// lo = min(members) - maxdistance, hi = max(members) + maxdistance (radfriendsregion.py:69-70)
@@ -313,7 +332,10 @@ struct Env {
 };
 
 // RadFriendsRegion(members, maxdistance=None | value) (radfriendsregion.py:59-70)
-RegionRef new_region(Env &e, const double *members, int K, bool given, double maxdistance)
+// `discarded`: the caller replaces this region before anybody can ask it for anything -- its
+// bootstrap choice is drawn from the stream (the position of the draws is part of the results) but
+// not kept
+RegionRef new_region(Env &e, const double *members, int K, bool given, double maxdistance, bool discarded = false)
 {
 	RegionRef r = std::make_shared<Region>();
 	r->members.assign(members, members + (size_t) K * e.c->ndim);
@@ -329,8 +351,12 @@ RegionRef new_region(Env &e, const double *members, int K, bool given, double ma
 		// nbootstraps x numpy.random.choice(arange(K), size=K) NOW (neighbors.py:173-174): the
 		// position of these draws in the stream is part of the results; K6 itself, which draws
 		// nothing, waits until somebody asks for the radius
-		r->masks.assign(K, 0u);
-		if (mdns_host_bootstrap_masks_mt(e.mt, K, r->nbootstraps, r->masks.data()) != 0) {
+		if (!discarded) r->masks.assign(K, 0u);
+		const long long t0 = now_ns();
+		const int rc = discarded ? mdns_host_bootstrap_skip_mt(e.mt, K, r->nbootstraps)
+		                         : mdns_host_bootstrap_masks_mt(e.mt, K, r->nbootstraps, r->masks.data());
+		e.c->stat.add(T_BOOTSTRAP, now_ns() - t0);
+		if (rc != 0) {
 			set_error("bootstrap choice for %d points failed", K);
 			return RegionRef();
 		}
@@ -363,7 +389,8 @@ bool cluster(Env &e, const double *u, int K, bool keepMetric)
 	c->metric.transform(u, K, ndim, w_old.data());
 	RegionRef region;
 	if (keepMetric) {
-		region = new_region(e, w_old.data(), K, false, 0);
+		// (with force_shrink and no previous radius never_grow replaces it at once, hiermetriclearn.py:53-54)
+		region = new_region(e, w_old.data(), K, false, 0, c->force_shrink && !c->has_prev);
 		if (!region) return false;
 		region = never_grow(e, region, w_old.data(), K);
 		if (!region) return false;
@@ -462,7 +489,18 @@ bool deliver(Env &e, const double *ws, int n, long long nspent)
 
 // next(self.generator): fills the buffer with the next batch of candidates (consumes RNG, exactly
 // on demand)
+bool next_batch_inner(Env &e);
+
+// (time spent here minus the membership kernels = random numbers + proposal arithmetic)
 bool next_batch(Env &e)
+{
+	const long long t0 = now_ns(), k0 = e.c->stat.v[T_COUNT] + e.c->stat.v[T_REGION];
+	const bool ok = next_batch_inner(e);
+	e.c->stat.add(T_PROPOSE, now_ns() - t0 - (e.c->stat.v[T_COUNT] + e.c->stat.v[T_REGION] - k0));
+	return ok;
+}
+
+bool next_batch_inner(Env &e)
 {
 	mdns_constrainer *c = e.c;
 	const int ndim = c->ndim, N = BATCH;
@@ -702,11 +740,29 @@ extern "C" void mdns_constrainer_share_stats(mdns_constrainer *c, long long *tot
 	if (c) c->stat.totals = totals;
 }
 
+static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, const mdns_prior *prior,
+                            const mdns_numpy_ops *np, void *mt19937_state,
+                            const double *pile_u, const void *ids, int ids_itemsize, int K,
+                            const int *rows, int M,
+                            double *u_out, double *x_out, long long *ntries, unsigned long long *fillbits);
+
 extern "C" int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, const mdns_prior *prior,
                                      const mdns_numpy_ops *np, void *mt19937_state,
                                      const double *pile_u, const void *ids, int ids_itemsize, int K,
                                      const int *rows, int M,
                                      double *u_out, double *x_out, long long *ntries, unsigned long long *fillbits)
+{
+	const long long t0 = now_ns();
+	const int rc = constrainer_draw(c, be, prior, np, mt19937_state, pile_u, ids, ids_itemsize, K, rows, M, u_out, x_out, ntries, fillbits);
+	if (c) c->stat.add(T_DRAW, now_ns() - t0);
+	return rc;
+}
+
+static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, const mdns_prior *prior,
+                            const mdns_numpy_ops *np, void *mt19937_state,
+                            const double *pile_u, const void *ids, int ids_itemsize, int K,
+                            const int *rows, int M,
+                            double *u_out, double *x_out, long long *ntries, unsigned long long *fillbits)
 {
 	if (!c || !be || !prior || !mt19937_state || !pile_u || !ids || K <= 0 || M <= 0 || !u_out || !x_out || !ntries || !fillbits) {
 		set_error("mdns_constrainer_draw: bad arguments (K=%d M=%d)", K, M);
@@ -770,9 +826,14 @@ extern "C" int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backen
 		const double *chunk = &c->buf[(size_t) c->buf_pos * ndim];
 		c->xs.resize((size_t) B * ndim);
 		c->params.resize((size_t) B * prior->nparams);
+		const long long t0 = now_ns();
 		transform(prior, chunk, B, c->xs.data(), c->params.data());
+		const long long t1 = now_ns();
 		int accepted = -1, nscored = B;
-		if (be->draw_chunk(be->user, c->params.data(), B, &accepted, fillbits, &nscored) != 0) { set_error("draw_chunk failed"); return 1; }
+		const int rc_chunk = be->draw_chunk(be->user, c->params.data(), B, &accepted, fillbits, &nscored);
+		c->stat.add(T_TRANSFORM, t1 - t0);
+		c->stat.add(T_CHUNK, now_ns() - t1);
+		if (rc_chunk != 0) { set_error("draw_chunk failed"); return 1; }
 		c->stat.add(N_CHUNKS, 1);
 		c->stat.add(N_CANDIDATES, nscored);
 		c->stat.add(N_PAIRS, (long long) nscored * M);

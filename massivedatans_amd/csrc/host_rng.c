@@ -58,7 +58,9 @@ int mdns_host_bootstrap_masks(const mdns_bitgen *bg, int64_t K, int rounds, uint
  * of the state before it trusts it (massivedatans_amd/_host.py). */
 typedef struct { uint32_t key[624]; int pos; } mdns_mt19937;
 
-static void mt_refill(mdns_mt19937 *s)
+/* (inlined into its callers so that their AVX2 clones get an AVX2 twist as well: the three loops
+ * have no dependency shorter than 227 elements) */
+static inline __attribute__((always_inline)) void mt_refill(mdns_mt19937 *s)
 {
 	const uint32_t UP = 0x80000000u, LO = 0x7fffffffu, A = 0x9908b0dfu;
 	uint32_t y;
@@ -79,6 +81,51 @@ static void mt_refill(mdns_mt19937 *s)
 /* The inner loops are free of unpredictable branches (at K = 4600 almost every second draw is
  * rejected: 9 ns per draw with a branch, 3 with one branch-free loop, under 2 split in three).  A run of draws is never longer than the number of points still to be drawn, so
  * the generator stops exactly where numpy's one-at-a-time loop stops. */
+#if defined(__x86_64__) && defined(__GNUC__)
+#define MDNS_CLONES __attribute__((target_clones("avx2", "default")))      /* wider tempering loops where the CPU has them */
+#else
+#define MDNS_CLONES
+#endif
+
+/* The same draws WITHOUT the choice: the stream is left where mdns_host_bootstrap_masks_mt would
+ * leave it.  For regions whose bootstrap choice is drawn -- the reference draws it in the
+ * constructor, clustering/radfriendsregion.py:62-64 -- and never used: the first region of a new
+ * constrainer is replaced at once (hiermetriclearn.py:53-54), half of all regions of a run. */
+MDNS_CLONES
+int mdns_host_bootstrap_skip_mt(void *state, int64_t K, int rounds)
+{
+	mdns_mt19937 *s = (mdns_mt19937 *) state;
+	if (!s || K <= 0 || rounds < 0 || rounds > 32 || s->pos < 0 || s->pos > 624) return 1;
+	const uint64_t top64 = (uint64_t) K - 1;
+	if (top64 > 0xFFFFFFFEull) return 1;
+	if (top64 == 0) return 0;
+	const uint32_t top = (uint32_t) top64;
+	uint32_t cover = top;
+	cover |= cover >> 1; cover |= cover >> 2; cover |= cover >> 4; cover |= cover >> 8; cover |= cover >> 16;
+	for (int b = 0; b < rounds; b++) {
+		int64_t need = K;
+		while (need > 0) {
+			if (s->pos == 624) mt_refill(s);
+			int64_t n = 624 - s->pos;
+			if (n > need) n = need;
+			const uint32_t *key = s->key + s->pos;
+			int64_t got = 0;
+			for (int64_t i = 0; i < n; i++) {
+				uint32_t y = key[i];
+				y ^= (y >> 11);
+				y ^= (y << 7) & 0x9d2c5680u;
+				y ^= (y << 15) & 0xefc60000u;
+				y ^= (y >> 18);
+				got += (y & cover) <= top;
+			}
+			s->pos += (int) n;
+			need -= got;
+		}
+	}
+	return 0;
+}
+
+MDNS_CLONES
 int mdns_host_bootstrap_masks_mt(void *state, int64_t K, int rounds, uint32_t *masks)
 {
 	mdns_mt19937 *s = (mdns_mt19937 *) state;

@@ -760,7 +760,7 @@ extern "C" void mdns_backend_region_destroy(void *joint, void *region)
 extern "C" int mdns_backend_region_count(void *joint, void *region, const double *points, int n, int *counts)
 {
 	(void) joint;
-	return mdns_region_count((mdns_region *) region, points, n, counts);
+	return mdns_region_count_polled((mdns_region *) region, points, n, counts);
 }
 
 static constexpr size_t kInParams = (size_t) MDNS_JOINT_MAX_BATCH * 24;      // bytes of the candidates' slot in h_in

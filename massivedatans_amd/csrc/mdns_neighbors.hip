@@ -13,6 +13,8 @@
 // radii (cneighbors.c:64-71,160-174) the root is taken once after the max of the min squared
 // distances -- the same number because sqrt is monotone.
 #include "mdns_internal.h"
+#include <cstdlib>
+#include <cstring>
 
 #pragma clang fp contract(off)
 
@@ -379,6 +381,134 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// K6 again, for packed choices (the shape every region of a run has): the member a wave looks at
+// is the same for all of its lanes.  A workgroup owns 64 points (lane = point) and a chunk of the
+// members (grid.y); its four waves walk that chunk interleaved.  Because the member is
+// wave-uniform its choice bits are a SCALAR: per round  v_max_f64 t, d, S  with S = -inf where the
+// member is chosen (t = d) and +inf where it is not (t = +inf), then  v_min_f64 nearest, t  --
+// two vector instructions per round and pair instead of the four of the masked-NaN form above
+// (sign-extracting the bit, and-ing, or-ing into the exponent, min), with the distance still
+// computed once per pair; the scalar unit prepares S (s_bitcmp1 + s_cselect) in the shadow of
+// another wave's vector work.  Same minima, bit for bit (min and max select, they do not round).
+// Per-point minima of a chunk go to part[y][K][RT] with plain stores; k_nearest_finish takes the
+// min over the chunks and the max over the left-out points (cneighbors.c:160-168).
+template <int D, int RT>
+__global__ __launch_bounds__(kBlock) void k_nearest_uniform(
+    const double *__restrict__ members, int K, const unsigned *__restrict__ mask, int kchunk, int tile_n,
+    double *__restrict__ part)
+{
+	extern __shared__ double smem[];
+	double *tile = smem;                                                   // [tile_n][D]
+	double *meet = smem + (size_t) tile_n * D;                             // [4][RT][64]
+	unsigned *tmask = reinterpret_cast<unsigned *>(meet + 4 * RT * 64);    // [tile_n]
+	const int lane = threadIdx.x & 63;
+	const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int i = blockIdx.x * 64 + lane;
+	const int ii = i < K ? i : K - 1;
+	double c[D];
+#pragma unroll
+	for (int k = 0; k < D; k++) c[k] = members[(size_t) ii * D + k];
+	double nearest[RT];
+#pragma unroll
+	for (int b = 0; b < RT; b++) nearest[b] = 1e300;                      // cneighbors.c:148
+	const int kbeg = blockIdx.y * kchunk, kend = min(K, kbeg + kchunk);
+	const double PINF = __longlong_as_double(0x7ff0000000000000LL), NINF = __longlong_as_double((long long) 0xfff0000000000000ULL);
+	for (int t0 = kbeg; t0 < kend; t0 += tile_n) {
+		const int n = min(tile_n, kend - t0);
+		__syncthreads();
+		stage_to_lds(tile, members + (size_t) t0 * D, n * D);
+		stage_to_lds(tmask, mask + t0, n);
+		__syncthreads();
+		auto offer = [&](int jn) {
+			const double d = sq_distance_fixed<D>(tile + jn * D, c);
+			const unsigned m = (unsigned) __builtin_amdgcn_readfirstlane((int) tmask[jn]);
+#pragma unroll
+			for (int b = 0; b < RT; b++) {
+				const double S = (m >> b & 1u) ? NINF : PINF;             // scalar: s_bitcmp1 + s_cselect_b64
+				// (written as asm: left to itself the compiler turns max(d, +-inf) into two
+				// v_cndmask_b32 per round -- three vector instructions instead of two)
+				double t;
+				asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(d), "s"(S));
+				nearest[b] = min_or_skip(nearest[b], t);
+			}
+		};
+		int jn = wv;
+		for (; jn + 4 < n; jn += 8) { offer(jn); offer(jn + 4); }
+		if (jn < n) offer(jn);
+	}
+#pragma unroll
+	for (int b = 0; b < RT; b++) meet[(wv * RT + b) * 64 + lane] = nearest[b];
+	__syncthreads();
+	// [RT][64] minima over the four waves, written as rows of part[y][i][RT]
+	for (int e = threadIdx.x; e < RT * 64; e += kBlock) {
+		const int b = e / 64, l = e % 64;
+		const double v = fmin(fmin(meet[(0 * RT + b) * 64 + l], meet[(1 * RT + b) * 64 + l]),
+		                      fmin(meet[(2 * RT + b) * 64 + l], meet[(3 * RT + b) * 64 + l]));
+		const int p = blockIdx.x * 64 + l;
+		if (p < K) part[((size_t) blockIdx.y * K + p) * RT + b] = v;
+	}
+}
+
+// min over the member chunks, then per round the max over the left-out points with index >= 1
+// (cneighbors.c:160-168; the reference's loop starts at 1), and -- last workgroup -- radius and
+// threshold for the membership kernel and the host (see k_nearest_chosen)
+template <int RT>
+__global__ __launch_bounds__(kBlock) void k_nearest_finish(
+    const double *__restrict__ part, int K, int ny, const unsigned *__restrict__ mask, int nb,
+    double *__restrict__ round_sq, BootstrapFinish fin, int nround_all)
+{
+	__shared__ double wmax[4][RT];
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	const int i = blockIdx.x * kBlock + threadIdx.x;
+	double v[RT];
+#pragma unroll
+	for (int b = 0; b < RT; b++) v[b] = 0.0;
+	if (i < K && i >= 1) {
+		const unsigned m = mask[i];
+#pragma unroll
+		for (int b = 0; b < RT; b++) v[b] = 1e300;
+		for (int y = 0; y < ny; y++) {
+			const double *row = part + ((size_t) y * K + i) * RT;
+#pragma unroll
+			for (int b = 0; b < RT; b++) v[b] = fmin(v[b], row[b]);
+		}
+#pragma unroll
+		for (int b = 0; b < RT; b++) if (b >= nb || (m >> b & 1u)) v[b] = 0.0;     // chosen points do not contribute
+	}
+#pragma unroll
+	for (int b = 0; b < RT; b++) {
+		const double w = wave_max(v[b]);
+		if (lane == 0) wmax[wv][b] = w;
+	}
+	__syncthreads();
+	if (threadIdx.x < RT && threadIdx.x < nb) {
+		const double w = fmax(fmax(wmax[0][threadIdx.x], wmax[1][threadIdx.x]), fmax(wmax[2][threadIdx.x], wmax[3][threadIdx.x]));
+		if (w > 0.0) atomic_max_nonneg(round_sq + threadIdx.x, w);
+	}
+	if (!fin.counter) return;
+	__threadfence();
+	__syncthreads();
+	if (wv != 0) return;
+	unsigned ticket = 0;
+	if (lane == 0) ticket = atomicAdd(fin.counter, 1u);
+	if (__shfl(ticket, 0, 64) != gridDim.x - 1) return;
+	__threadfence();
+	double best = 0.0;
+	for (int b = lane; b < nround_all; b += 64)
+		best = fmax(best, __hip_atomic_load(round_sq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	best = wave_max(best);
+	for (int b = lane; b < nround_all; b += 64) round_sq[b] = 0.0;      // the slots go back to zero
+	if (lane != 0) return;
+	double radius, thresh;
+	radius_and_threshold(best, radius, thresh);
+	fin.d_res->radius = radius;
+	fin.d_res->thresh = thresh;
+	*fin.counter = 0;
+	fin.h_res->radius = radius;
+	fin.h_res->thresh = thresh;
+	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
@@ -496,10 +626,65 @@ bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_
 	return launch_nearest<false>(d_members, K, ndim, d_chosen, nbootstraps, d_round_sq, finish);
 }
 
+// grid.y of k_nearest_uniform: member chunks, so that the workgroups fill the CUs evenly about
+// three deep (more waves per SIMD than that buys nothing: the loop is issue-bound)
+static int uniform_chunks(int K, int num_cus)
+{
+	const int groups = (K + 63) / 64;
+	int most = K / 128;                              // a chunk of fewer than 128 members is all prologue
+	if (most < 1) most = 1;
+	if (most > 64) most = 64;
+	int best = 1;
+	double best_cost = 1e300;
+	for (int gy = 1; gy <= most; gy++) {
+		const long long wgs = (long long) groups * gy;
+		const long long rounds = (wgs + num_cus - 1) / num_cus;          // workgroups the busiest CU gets
+		if (rounds > 4 && gy > 1) break;
+		// time ~ (workgroups of the busiest CU) x (members per chunk + a fixed cost per workgroup);
+		// a wave alone on its SIMD also pays for its scalar instructions (nothing to overlap with)
+		const double alone = rounds == 1 ? 1.6 : (rounds == 2 ? 1.15 : 1.0);
+		const double cost = alone * (double) rounds * ((double) K / gy + 96.0);
+		if (cost < best_cost) { best_cost = cost; best = gy; }
+	}
+	static const char *forced = getenv("MDNS_K6_GY");                    // experiments only
+	if (forced && atoi(forced) > 0) best = atoi(forced) < most ? atoi(forced) : most;
+	return best;
+}
+
 bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const unsigned *d_packed,
                              int nbootstraps, double *d_round_sq, const BootstrapFinish *finish)
 {
 	if (nbootstraps > kRounds || !finish) { set_error("packed bootstrap: at most %d rounds, finishing only", kRounds); return false; }
+	Context *c = ctx();
+	static const char *forced = getenv("MDNS_K6_PATH");                   // "classic": the masked-NaN kernel (experiments)
+	const bool classic = forced && !strcmp(forced, "classic");
+	if (ndim >= 1 && ndim <= 5 && K >= 64 && !classic) {
+		const int rt = nbootstraps <= 10 ? 10 : kRounds;
+		const int gy = uniform_chunks(K, c->num_cus);
+		int kchunk = (K + gy - 1) / gy;
+		kchunk = (kchunk + 3) & ~3;
+		const int ny = (K + kchunk - 1) / kchunk;
+		const size_t fixed = (size_t) 4 * rt * 64 * sizeof(double);
+		int tile_n = pick_tile(ndim, sizeof(unsigned), fixed);
+		if (tile_n <= 0) { set_error("ndim=%d too large for the member tile", ndim); return false; }
+		if (tile_n > kchunk) tile_n = (kchunk + 15) & ~15;
+		const size_t lds = (size_t) tile_n * ndim * sizeof(double) + fixed + (size_t) tile_n * sizeof(unsigned);
+		double *d_part = (double *) device_scratch((size_t) ny * K * rt * sizeof(double));
+		if (!d_part) return false;
+		dim3 grid((K + 63) / 64, ny);
+		ProfileScope prof(3);
+		note_kernel(3, "k_nearest_uniform<%d, %d>", ndim, rt);
+#define UNI_LAUNCH(D) do { if (rt == 10) hipLaunchKernelGGL((k_nearest_uniform<D, 10>), grid, dim3(kBlock), lds, c->stream, d_members, K, d_packed, kchunk, tile_n, d_part); \
+		else hipLaunchKernelGGL((k_nearest_uniform<D, kRounds>), grid, dim3(kBlock), lds, c->stream, d_members, K, d_packed, kchunk, tile_n, d_part); } while (0)
+		switch (ndim) { case 1: UNI_LAUNCH(1); break; case 2: UNI_LAUNCH(2); break; case 3: UNI_LAUNCH(3); break;
+		                case 4: UNI_LAUNCH(4); break; default: UNI_LAUNCH(5); break; }
+#undef UNI_LAUNCH
+		if (!launched("k_nearest_uniform")) return false;
+		const dim3 fgrid((K + kBlock - 1) / kBlock);
+		if (rt == 10) hipLaunchKernelGGL((k_nearest_finish<10>), fgrid, dim3(kBlock), 0, c->stream, (const double *) d_part, K, ny, d_packed, nbootstraps, d_round_sq, *finish, nbootstraps);
+		else hipLaunchKernelGGL((k_nearest_finish<kRounds>), fgrid, dim3(kBlock), 0, c->stream, (const double *) d_part, K, ny, d_packed, nbootstraps, d_round_sq, *finish, nbootstraps);
+		return launched("k_nearest_finish");
+	}
 	return launch_nearest<false>(d_members, K, ndim, nullptr, nbootstraps, d_round_sq, finish, d_packed);
 }
 
