@@ -192,6 +192,12 @@ void mdns_joint_destroy(mdns_joint *j);
  * against ALL spectra and keeps the result as the live likelihood matrix; nothing is returned
  * (mdns_joint_get_live reads it back).  All data sets are running, all shelves empty. */
 int mdns_joint_init_gauss(mdns_joint *j, const double *params, double noise_level);
+/* The same for spectra with variances: params f64[nlive, 5] of the three-line template
+ * (mdns_muse3_loglike_batch) scored with the scale-marginalised likelihood (cmuselike.c:45-64);
+ * jitter f64[nlive, ndata] or NULL is added (musefuse.py:535: the tie-breaking noise the reference
+ * adds to every likelihood evaluation).  A joint state over such spectra is driven through the
+ * mdns_backend_* entry points (Part 5). */
+int mdns_joint_init_muse3(mdns_joint *j, const double *params, const double *jitter);
 /* The same from a host matrix liveL f64[nlive, ndata] (row p = live slot p). */
 int mdns_joint_set_live(mdns_joint *j, const double *liveL);
 /* liveL f64[nlive, ndata] <- the device matrix (the integrator's remainder, :536-563). */
@@ -411,8 +417,9 @@ typedef struct mdns_draw_backend {
 	 * first that beats the threshold of some selected data set (hiermetriclearn.py:193), or -1;
 	 * fillbits uint64[ceil(M/64)]: bit k set when it beats the k-th selected data set's
 	 * (multi_nested_sampler.py:482-485); those data sets take the point in.  *nscored = candidates
-	 * looked at (B, or fewer when the scorer stops at the accepted one). */
-	int (*draw_chunk)(void *user, const double *params, int B, int *accepted,
+	 * looked at (B, or fewer when the scorer stops at the accepted one).  jitter (NULL, or f64[B, M]):
+	 * added to the likelihoods before they are compared and kept (musefuse.py:535). */
+	int (*draw_chunk)(void *user, const double *params, int B, const double *jitter, int *accepted,
 	                  unsigned long long *fillbits, int *nscored);
 	/* How many of `offered` candidates one chunk should hold for M selected data sets when the last
 	 * draw of this constrainer needed `hint` tries (a speed choice: results do not depend on it). */
@@ -430,6 +437,12 @@ typedef struct mdns_prior {
 	int pow10[MDNS_MAX_DIM], kernel_pow10[MDNS_MAX_DIM];
 	void (*custom)(void *user, const double *u, int B, double *x, double *params);
 	void *user;
+	/* > 0: every likelihood evaluation adds N(0, jitter_sigma) noise per selected data set, drawn from
+	 * the global stream in evaluation order -- `Lout[data_mask] + numpy.random.normal(0, 1e-5,
+	 * size=data_mask.sum())`, musefuse.py:535.  The constrainer draws the deviates of a chunk's
+	 * candidates one candidate after the other and, when one is accepted, puts the stream back to where
+	 * it stood after THAT candidate's deviates (the reference never evaluates the ones behind it). */
+	double jitter_sigma;
 } mdns_prior;
 
 /* numpy operations the constrainer leaves to numpy itself so that its numbers ARE numpy's (numpy
@@ -472,10 +485,11 @@ int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, cons
  * [6] membership calls (K3), [7] raw proposals, [8] proposals the region kept, [9] tries (the
  * reference's likelihood calls); nanoseconds spent in [10] the bootstrap choices, [11] region_create
  * (K6 + upload), [12] region_count (K3), [13] proposal random numbers + arithmetic, [14] the prior
- * transform, [15] draw_chunk, [16] mdns_constrainer_draw as a whole.  mdns_constrainer_share_stats:
+ * transform, [15] draw_chunk, [16] mdns_constrainer_draw as a whole, [17] the likelihood jitter.
+ * mdns_constrainer_share_stats:
  * every increment is also added to totals int64[MDNS_CONSTRAINER_COUNTERS] (the caller's: the sum
  * over a sampler's constrainers). */
-#define MDNS_CONSTRAINER_COUNTERS 17
+#define MDNS_CONSTRAINER_COUNTERS 18
 void mdns_constrainer_stats(const mdns_constrainer *c, long long *out);
 void mdns_constrainer_share_stats(mdns_constrainer *c, long long *totals);
 const char *mdns_host_last_error(void);
@@ -494,7 +508,7 @@ void *mdns_backend_region_create(void *joint, const double *members, int K, int 
 void mdns_backend_region_destroy(void *joint, void *region);
 int mdns_backend_region_count(void *joint, void *region, const double *points, int n, int *counts);
 int mdns_backend_draw_begin(void *joint, const int *rows, int M);
-int mdns_backend_draw_chunk(void *joint, const double *params, int B, int *accepted,
+int mdns_backend_draw_chunk(void *joint, const double *params, int B, const double *jitter, int *accepted,
                             unsigned long long *fillbits, int *nscored);
 int mdns_backend_chunk_size(void *joint, int offered, int M, int hint);
 

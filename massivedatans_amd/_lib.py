@@ -30,7 +30,7 @@ ABI_SYMBOLS = (
     "mdns_profile", "mdns_profile_every", "mdns_profile_read", "mdns_profile_kernel",
     "mdns_gauss_loglike_batch_dev", "mdns_muse_loglike_batch_dev", "mdns_muse3_loglike_batch_dev",
     "mdns_count_within_dev", "mdns_bootstrap_round_maxsq_dev",
-    "mdns_joint_create", "mdns_joint_destroy", "mdns_joint_init_gauss", "mdns_joint_set_live",
+    "mdns_joint_create", "mdns_joint_destroy", "mdns_joint_init_gauss", "mdns_joint_init_muse3", "mdns_joint_set_live",
     "mdns_joint_get_live", "mdns_joint_set_running", "mdns_joint_prepare", "mdns_joint_keep_words",
     "mdns_joint_advance", "mdns_joint_reserve", "mdns_joint_shelf_cap", "mdns_joint_draw_gauss", "mdns_joint_score", "mdns_joint_commit",
     "mdns_joint_get_thresholds", "mdns_joint_score_dev", "mdns_joint_flags_dev", "mdns_joint_commit_dev", "mdns_joint_commit_bits_dev",
@@ -120,6 +120,7 @@ def _declare(lib):
         "mdns_joint_create": (vp, [vp, i, i]),
         "mdns_joint_destroy": (None, [vp]),
         "mdns_joint_init_gauss": (i, [vp, vp, d]),
+        "mdns_joint_init_muse3": (i, [vp, vp, vp]),
         "mdns_joint_set_live": (i, [vp, vp]),
         "mdns_joint_get_live": (i, [vp, vp]),
         "mdns_joint_set_running": (i, [vp, vp, i]),
@@ -156,7 +157,7 @@ def _declare(lib):
         "mdns_backend_region_destroy": (None, [vp, vp]),
         "mdns_backend_region_count": (i, [vp, vp, vp, i, vp]),
         "mdns_backend_draw_begin": (i, [vp, vp, i]),
-        "mdns_backend_draw_chunk": (i, [vp, vp, i, vp, vp, vp]),
+        "mdns_backend_draw_chunk": (i, [vp, vp, i, vp, vp, vp, vp]),
         "mdns_backend_chunk_size": (i, [vp, i, i, i]),
     }
     for name, (res, args) in sig.items():

@@ -29,7 +29,7 @@ _REGION_CREATE = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_
 _REGION_DESTROY = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
 _REGION_COUNT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int))
 _DRAW_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int)
-_DRAW_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int),
+_DRAW_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
                           C.POINTER(C.c_ulonglong), C.POINTER(C.c_int))
 _CHUNK_SIZE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 _CUSTOM_PRIOR = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
@@ -47,7 +47,7 @@ class DrawBackend(C.Structure):            # mdns_draw_backend
 class Prior(C.Structure):                  # mdns_prior
     _fields_ = [("ndim", C.c_int), ("nparams", C.c_int), ("a", C.c_double * MAX_DIM), ("b", C.c_double * MAX_DIM),
                 ("pow10", C.c_int * MAX_DIM), ("kernel_pow10", C.c_int * MAX_DIM), ("custom", _CUSTOM_PRIOR),
-                ("user", C.c_void_p)]
+                ("user", C.c_void_p), ("jitter_sigma", C.c_double)]
 
 
 class NumpyOps(C.Structure):               # mdns_numpy_ops
@@ -57,7 +57,7 @@ class NumpyOps(C.Structure):               # mdns_numpy_ops
 METRICS = {'none': 0, 'simplescaling': 1, 'truncatedscaling': 2}
 #: mdns_constrainer_stats (include/mdns.h)
 COUNTERS = ("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals", "inside", "tries",
-            "ns_bootstrap", "ns_region", "ns_count", "ns_propose", "ns_transform", "ns_chunk", "ns_draw")
+            "ns_bootstrap", "ns_region", "ns_count", "ns_propose", "ns_transform", "ns_chunk", "ns_draw", "ns_jitter")
 
 _HOST = None
 
@@ -218,11 +218,15 @@ def python_backend(joint, member_set_factory=None):
         state["M"] = M
         return 0
 
-    def draw_chunk(_user, params_ptr, B, accepted_ptr, bits_ptr, nscored_ptr):
+    def draw_chunk(_user, params_ptr, B, jitter_ptr, accepted_ptr, bits_ptr, nscored_ptr):
         try:
             nparams = joint_nparams(joint)
             params = numpy.ctypeslib.as_array(params_ptr, (B, nparams)).copy()
-            idx, _, beats, nscored = joint.draw_params(params, state["rows"])
+            if jitter_ptr:
+                jitter = numpy.ctypeslib.as_array(jitter_ptr, (B, state["M"])).copy()
+                idx, _, beats, nscored = joint.draw_params(params, state["rows"], jitter=jitter)
+            else:
+                idx, _, beats, nscored = joint.draw_params(params, state["rows"])
             accepted_ptr[0] = idx
             nscored_ptr[0] = nscored
             if idx >= 0:

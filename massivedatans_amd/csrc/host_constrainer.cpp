@@ -181,7 +181,7 @@ struct Metric {
 enum { N_DRAWS, N_CHUNKS, N_CANDIDATES, N_PAIRS, N_REGIONS, N_RADII, N_COUNTS, N_PROPOSALS, N_INSIDE, N_TRIES,
        // nanoseconds spent in: the bootstrap choice, region_create (K6 + upload), region_count (K3),
        // proposal arithmetic + random numbers, prior transform, draw_chunk, the whole draw call
-       T_BOOTSTRAP, T_REGION, T_COUNT, T_PROPOSE, T_TRANSFORM, T_CHUNK, T_DRAW, N_COUNTERS };
+       T_BOOTSTRAP, T_REGION, T_COUNT, T_PROPOSE, T_TRANSFORM, T_CHUNK, T_DRAW, T_JITTER, N_COUNTERS };
 
 inline long long now_ns()
 {
@@ -315,6 +315,10 @@ struct mdns_constrainer {
 	std::vector<double> us, ws, dir, rad, coin, xs, params, wtmp;
 	std::vector<int32_t> idx;
 	std::vector<int> counts;
+	// likelihood jitter of a chunk and the stream's state after each candidate's share of it
+	struct Snapshot { MT mt; int has_gauss; double gauss; };
+	std::vector<double> jitter;
+	std::vector<Snapshot> snap;
 };
 
 namespace {
@@ -829,10 +833,39 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 		const long long t0 = now_ns();
 		transform(prior, chunk, B, c->xs.data(), c->params.data());
 		const long long t1 = now_ns();
+		// the tie-breaking noise of musefuse.py:535, candidate by candidate, with the state of the
+		// stream remembered after each of them
+		const double *jitter = nullptr;
+		if (prior->jitter_sigma > 0) {
+			c->jitter.resize((size_t) B * M);
+			c->snap.resize(B);
+			for (int b = 0; b < B; b++) {
+				double *row = &c->jitter[(size_t) b * M];
+				for (int k = 0; k < M; k++) {
+					const double g = prior->jitter_sigma * legacy_gauss(mt);
+					row[k] = 0.0 + g;
+				}
+				c->snap[b].mt = *mt;
+				c->snap[b].has_gauss = g_has_gauss;
+				c->snap[b].gauss = g_gauss;
+			}
+			jitter = c->jitter.data();
+			c->stat.add(T_JITTER, now_ns() - t1);
+		}
+		const long long t2 = now_ns();
 		int accepted = -1, nscored = B;
-		const int rc_chunk = be->draw_chunk(be->user, c->params.data(), B, &accepted, fillbits, &nscored);
+		const int rc_chunk = be->draw_chunk(be->user, c->params.data(), B, jitter, &accepted, fillbits, &nscored);
+		if (jitter && rc_chunk == 0) {
+			// the reference evaluated exactly the candidates up to the accepted one (or all `nscored`)
+			const int last = accepted >= 0 ? accepted : nscored - 1;
+			if (last >= 0 && last < B - 1) {
+				*mt = c->snap[last].mt;
+				g_has_gauss = c->snap[last].has_gauss;
+				g_gauss = c->snap[last].gauss;
+			}
+		}
 		c->stat.add(T_TRANSFORM, t1 - t0);
-		c->stat.add(T_CHUNK, now_ns() - t1);
+		c->stat.add(T_CHUNK, now_ns() - t2);
 		if (rc_chunk != 0) { set_error("draw_chunk failed"); return 1; }
 		c->stat.add(N_CHUNKS, 1);
 		c->stat.add(N_CANDIDATES, nscored);

@@ -168,6 +168,78 @@ __global__ __launch_bounds__(kBlock) void k_joint_publish(const JointHeader *__r
 	__hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---- the draw for scorers that leave a dense L[B, M] (the scale-marginalised likelihood, K2) ----
+// L += jitter (musefuse.py:535), then the accept test `any(L > Lmins)` (hiermetriclearn.py:193): one
+// thread per (candidate, selected data set); an accepted candidate gets flags[b] = flag (every
+// writer stores the same value)
+__global__ __launch_bounds__(kBlock) void k_joint_accept_dense(double *__restrict__ L, const double *__restrict__ jitter, int B, int M,
+                                                               const int *__restrict__ thr_rows, const double *__restrict__ higher,
+                                                               int *__restrict__ flags, int flag, JointHeader *__restrict__ header)
+{
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) header->status = 0;
+	const int k = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+	if (k >= M) return;
+	const size_t at = (size_t) b * M + k;
+	double v = L[at];
+	if (jitter) { v = v + jitter[at]; L[at] = v; }
+	const int d = thr_rows ? thr_rows[k] : k;
+	if (v > higher[d]) flags[b] = flag;
+}
+
+// first flagged candidate -> shelf appends, next thresholds, fill bits (k_joint_commit_trail with the
+// likelihoods read from the dense block)
+__global__ __launch_bounds__(kBlock) void k_joint_commit_dense(
+    const double *__restrict__ L, const int *__restrict__ thr_rows, int M, int B, int ntiles, const int *__restrict__ flags, int flag,
+    JointArrays st, JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits)
+{
+	__shared__ int s_first;
+	if (threadIdx.x == 0) s_first = 0x7fffffff;
+	__syncthreads();
+	for (int b = threadIdx.x; b < B; b += kBlock)
+		if (flags[b] == flag) { atomicMin(&s_first, b); break; }
+	__syncthreads();
+	const int bstar = s_first;
+	if (blockIdx.x == 0 && threadIdx.x == 0) header->accepted = bstar < B ? bstar : -1;
+	if (bstar >= B) return;
+	const int lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (tile >= ntiles) return;
+	const int k = tile * 64 + lane;
+	bool beats = false;
+	if (k < M) {
+		const int d = thr_rows ? thr_rows[k] : k;
+		const double v = L[(size_t) bstar * M + k];
+		const double thr = st.higher[d];
+		beats = v > thr;
+		if (beats) {
+			const int n = st.shelfn[d];
+			if (n >= st.cap) atomicOr(&header->status, 1);
+			else {
+				int at_most = 0;
+				double next = INFINITY;
+				for (int p = 0; p < st.nlive; p++) {
+					const double w = st.live[(size_t) p * st.ndata + d];
+					if (w <= thr) at_most++; else next = fmin(next, w);
+				}
+				for (int e = 0; e < n; e++) {
+					const double w = st.shelfL[(size_t) e * st.ndata + d];
+					if (w <= thr) at_most++; else next = fmin(next, w);
+				}
+				st.shelfL[(size_t) n * st.ndata + d] = v;
+				st.shelfn[d] = n + 1;
+				st.higher[d] = at_most >= n + 2 ? thr : fmin(v, next);
+			}
+		}
+	}
+	const unsigned long long word = __ballot(beats);
+	if (lane == 0) fillbits[tile] = word;
+}
+
+__global__ void k_joint_add(double *__restrict__ p, const double *__restrict__ q, size_t n)
+{
+	for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t) gridDim.x * blockDim.x) p[e] = p[e] + q[e];
+}
+
 __global__ void k_joint_fill(double *__restrict__ p, size_t n, double value)
 {
 	for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t) gridDim.x * blockDim.x) p[e] = value;
@@ -216,6 +288,12 @@ struct mdns_joint {
 	int staged_M = 0;
 	size_t staged_in_bytes = 0;
 	double noise_level = 0;            // of mdns_joint_init_gauss (the backend entry points score with it)
+	// which likelihood: 0 = the Gaussian line (clike.c; lane kernels, trail), 1 = the three-line
+	// template scored with the scale-marginalised chi^2 (cmuselike.c; dense L[B, M] block)
+	int kind = 0;
+	int nparams = 3;
+	double *d_dense = nullptr;  size_t dense_cap = 0;       // L[B, M] of a chunk (kind 1)
+	double *d_jitter = nullptr;  size_t jitter_cap = 0;
 	// the draw in progress through the mdns_backend_* entry points: its selection, uploaded once
 	int *d_sel_rows = nullptr;  size_t sel_rows_cap = 0;
 	bool sel_rows = false;
@@ -248,6 +326,8 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	                j->d_argmin, j->d_keep, j->d_status, j->d_flags, j->d_params};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	if (j->d_sel_rows) (void) hipFree(j->d_sel_rows);
+	if (j->d_dense) (void) hipFree(j->d_dense);
+	if (j->d_jitter) (void) hipFree(j->d_jitter);
 	if (j->h_in) (void) hipHostFree(j->h_in);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
 	for (void *b : trail) if (b) (void) hipFree(b);
@@ -261,10 +341,13 @@ extern "C" mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_c
 	Context *c = ctx();
 	if (!c) return nullptr;
 	if (!s || nlive <= 0 || s->ndata <= 0) { set_error("mdns_joint_create: bad arguments (nlive=%d)", nlive); return nullptr; }
-	if (!s->d_yT || !s->d_x) { set_error("mdns_joint_create: the spectra need a wavelength grid and no variances (Gaussian-line problem)"); return nullptr; }
+	if (!s->d_x || (!s->d_yT && !s->d_w)) { set_error("mdns_joint_create: the spectra need a wavelength grid"); return nullptr; }
 	if (shelf_cap < 4) shelf_cap = 4;
 	mdns_joint *j = new mdns_joint();
 	j->s = s; j->nlive = nlive; j->cap = shelf_cap; j->ndata = s->ndata;
+	// spectra with variances: the scale-marginalised likelihood against the three-line template
+	j->kind = s->d_w ? 1 : 0;
+	j->nparams = j->kind == 1 ? 5 : 3;
 	const size_t nd = (size_t) s->ndata;
 	const size_t res = (size_t) kFlagInts * sizeof(int) + result_bytes(s->ndata);
 	bool ok =
@@ -279,7 +362,7 @@ extern "C" mdns_joint *mdns_joint_create(mdns_spectra *s, int nlive, int shelf_c
 	    MDNS_HIP(hipMalloc((void **) &j->d_status, sizeof(int))) &&
 	    MDNS_HIP(hipMalloc((void **) &j->d_flags, res)) &&
 	    // candidates [B, 3] followed by the selection's row ids: one staging block
-	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 3 * sizeof(double) + nd * sizeof(int) + 16)) &&
+	    MDNS_HIP(hipMalloc((void **) &j->d_params, (size_t) MDNS_JOINT_MAX_BATCH * 5 * sizeof(double) + nd * sizeof(int) + 16)) &&
 	    MDNS_HIP(hipHostMalloc((void **) &j->h_box, sizeof(JointMailbox) + ((nd + 63) / 64) * 8, hipHostMallocMapped | hipHostMallocCoherent)) &&
 	    MDNS_HIP(hipHostGetDevicePointer((void **) &j->h_box_dev, j->h_box, 0));
 	if (ok) {
@@ -349,6 +432,7 @@ extern "C" int mdns_joint_init_gauss(mdns_joint *j, const double *params, double
 {
 	Context *c = ctx();
 	if (!c || !j || !params) return 1;
+	if (j->kind != 0) { set_error("mdns_joint_init_gauss: these spectra carry variances (mdns_joint_init_muse3)"); return 1; }
 	if (j->nlive > MDNS_JOINT_MAX_BATCH) { set_error("mdns_joint_init_gauss: nlive=%d > %d", j->nlive, MDNS_JOINT_MAX_BATCH); return 1; }
 	char *pin = joint_pin(j, (size_t) j->nlive * 24);
 	if (!pin) return 1;
@@ -357,6 +441,40 @@ extern "C" int mdns_joint_init_gauss(mdns_joint *j, const double *params, double
 	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, (size_t) j->nlive * 24, hipMemcpyHostToDevice, c->stream))) return 1;
 	// always the lane kernel: every likelihood of a run is then the same chain of operations
 	if (gauss_loglike_cols_dev(j->s, j->d_params, j->nlive, noise_level, nullptr, j->ndata, j->st.live) != 0) return 1;
+	if (joint_reset(j) != 0) return 1;
+	return joint_sync(c) ? 0 : 1;
+}
+
+static bool joint_grow(double **p, size_t *cap, size_t need)
+{
+	if (need <= *cap) return true;
+	Context *c = ctx();
+	if (*p) { (void) hipStreamSynchronize(c->stream); (void) hipFree(*p); *p = nullptr; *cap = 0; }
+	const size_t n = need + need / 2 + 1024;
+	if (!MDNS_HIP(hipMalloc((void **) p, n * sizeof(double)))) return false;
+	*cap = n;
+	return true;
+}
+
+extern "C" int mdns_joint_init_muse3(mdns_joint *j, const double *params, const double *jitter)
+{
+	Context *c = ctx();
+	if (!c || !j || !params) return 1;
+	if (j->kind != 1) { set_error("mdns_joint_init_muse3: the spectra carry no variances"); return 1; }
+	if (j->nlive > MDNS_JOINT_MAX_BATCH) { set_error("mdns_joint_init_muse3: nlive=%d > %d", j->nlive, MDNS_JOINT_MAX_BATCH); return 1; }
+	const size_t pbytes = (size_t) j->nlive * 5 * sizeof(double), n = (size_t) j->nlive * j->ndata;
+	char *pin = joint_pin(j, pbytes);
+	if (!pin) return 1;
+	memcpy(pin, params, pbytes);
+	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	if (mdns_muse3_loglike_batch_dev(j->s, j->d_params, j->nlive, nullptr, j->ndata, j->st.live) != 0) return 1;
+	if (jitter) {
+		// (musefuse.py:535 adds its noise to the initial points' likelihoods too)
+		if (!joint_grow(&j->d_jitter, &j->jitter_cap, n)) return 1;
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_jitter, jitter, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
+		hipLaunchKernelGGL(k_joint_add, dim3(1024), dim3(kBlock), 0, c->stream, j->st.live, (const double *) j->d_jitter, n);
+		if (!MDNS_HIP(hipGetLastError())) return 1;
+	}
 	if (joint_reset(j) != 0) return 1;
 	return joint_sync(c) ? 0 : 1;
 }
@@ -540,6 +658,7 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 {
 	Context *c = ctx();
 	if (!c || !check_draw(j, B, M, "mdns_joint_score_dev")) return 1;
+	if (j->kind != 0) { set_error("mdns_joint_score_dev: Gaussian-line states only (use the mdns_backend_* entry points)"); return 1; }
 	mdns_spectra *s = j->s;
 	j->last_B = 0;
 	j->trail_valid = false;
@@ -802,7 +921,49 @@ extern "C" int mdns_backend_draw_begin(void *joint, const int *rows, int M)
 	return 0;
 }
 
-extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B, int *accepted,
+// the chunk for kind 1: templates + K2 into the dense block, jitter, accept flags, commit, mailbox
+static int backend_chunk_muse(mdns_joint *j, const double *params, int B, const double *jitter, int M)
+{
+	Context *c = ctx();
+	const size_t pbytes = (size_t) B * 5 * sizeof(double), n = (size_t) B * M;
+	char *pin = joint_pin(j, pbytes);
+	if (!pin) return 1;
+	memcpy(pin, params, pbytes);
+	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	if (j->sel_rows && !j->sel_on_device) {
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, j->h_in + kInParams, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
+		j->sel_on_device = true;
+	}
+	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+	if (!joint_grow(&j->d_dense, &j->dense_cap, n)) return 1;
+	if (jitter) {
+		if (!joint_grow(&j->d_jitter, &j->jitter_cap, n)) return 1;
+		// (pageable source: the runtime stages it and returns when the caller's buffer is free)
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_jitter, jitter, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
+	}
+	if (mdns_muse3_loglike_batch_dev(j->s, j->d_params, B, d_rows, M, j->d_dense) != 0) return 1;
+	if (j->chunk_seq == 0x7fffffff) {
+		if (!MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kFlagInts * sizeof(int), c->stream))) return 1;
+		j->chunk_seq = 1;
+	}
+	const int flag = ++j->chunk_seq;
+	char *base = j->d_result;
+	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
+	hipLaunchKernelGGL(k_joint_accept_dense, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream,
+	                   j->d_dense, jitter ? (const double *) j->d_jitter : nullptr, B, M, d_rows, (const double *) j->st.higher,
+	                   j->d_flags, flag, (JointHeader *) base);
+	const int ntiles = (M + 63) / 64;
+	hipLaunchKernelGGL(k_joint_commit_dense, dim3((ntiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
+	                   (const double *) j->d_dense, d_rows, M, B, ntiles, (const int *) j->d_flags, flag, j->st, (JointHeader *) base, bits);
+	hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, ntiles, j->h_box_dev, ++j->box_seq);
+	if (!MDNS_HIP(hipGetLastError())) return 1;
+	j->box_pending = true;
+	j->trail_valid = false;
+	j->last_B = 0;
+	return 0;
+}
+
+extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B, const double *jitter, int *accepted,
                                        unsigned long long *fillbits, int *nscored)
 {
 	Context *c = ctx();
@@ -815,6 +976,13 @@ extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B,
 	if (nscored) *nscored = B;
 	if (B == 0 || M == 0) return 0;
 	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
+	if (j->kind == 1) {
+		if (backend_chunk_muse(j, params, B, jitter, M) != 0) return 1;
+		if (mdns_joint_fetch(j, M, accepted, fillbits) != 0) return 1;
+		if (*accepted >= 0) j->shelf_bound++;
+		return 0;
+	}
+	if (jitter) { set_error("mdns_backend_draw_chunk: likelihood jitter is not part of the Gaussian-line problem"); return 1; }
 	const size_t pbytes = (size_t) B * 24;
 	static const char *chunk_path = getenv("MDNS_CHUNK_PATH");        // "classic": the five-command chunk (experiments)
 	if (chunk_fits(j->s, M, B) && !(chunk_path && !strcmp(chunk_path, "classic"))) {
@@ -876,9 +1044,12 @@ extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B,
 // spectrum) pairs (~50 us of GPU time) -- a speed choice only
 extern "C" int mdns_backend_chunk_size(void *joint, int offered, int M, int hint)
 {
-	(void) joint;
-	const long long EVAL_BUDGET = 2560000;
-	const int MIN_CHUNK = 32;
+	const mdns_joint *j = (const mdns_joint *) joint;
+	// (a K2 pair reads 16 bytes x 4096 channels against K1's 8 x 200: a twentieth of the pairs,
+	// and each speculative candidate also costs its jitter deviates on the host)
+	const bool muse = j && j->kind == 1;
+	const long long EVAL_BUDGET = muse ? 400000 : 2560000;
+	const int MIN_CHUNK = muse ? 4 : 32;
 	long long budget = EVAL_BUDGET / (M > 0 ? M : 1);
 	if (budget < MIN_CHUNK) budget = MIN_CHUNK;
 	long long want = 4LL * (hint > 0 ? hint : 1);

@@ -9,6 +9,7 @@ one component, the labels.  No CPU fallback: constructing the object needs the H
 a device.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -32,6 +33,8 @@ class DeviceGroups(object):
         self._rows = None
         self._npoints = 0
         self.ncalls = 0
+        #: MDNS_GROUPS_LOG=1: (selected data sets, components, distinct ids) of every call (tools/e2e_run.py prints a summary)
+        self.size_log = [] if os.environ.get("MDNS_GROUPS_LOG") == "1" else None
 
     def close(self):
         if self._h:
@@ -80,6 +83,8 @@ class DeviceGroups(object):
                                                     len(self._distinct), None), "mdns_groups_components")
         self._rows, self._npoints = rows, npoints
         self.ncalls += 1
+        if self.size_log is not None:
+            self.size_log.append((M, int(ncomp.value), int(ndistinct.value)))
         return int(ncomp.value), self._distinct[:ndistinct.value].astype(np.int64)
 
     def touched(self, npoints):

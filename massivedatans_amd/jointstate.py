@@ -42,10 +42,11 @@ class HostJointState(object):
     #: candidates scored at once grow 1, 2, 4 ... up to this (a CPU scorer pays per candidate)
     MAX_CHUNK = 64
 
-    def __init__(self, scorer, nlive, ndata, to_kernel_params):
+    def __init__(self, scorer, nlive, ndata, to_kernel_params, nparams=3):
         self.scorer = scorer
         self.nlive, self.ndata = int(nlive), int(ndata)
         self.to_kernel_params = to_kernel_params
+        self.nparams = int(nparams)
         self.live = None                                  # [nlive, ndata], all data sets ever
         self.shelfL = [[] for _ in range(self.ndata)]
         self.higher = numpy.full(self.ndata, numpy.nan)
@@ -54,8 +55,11 @@ class HostJointState(object):
         self.nevals_scored = 0
         self.ncalls = 0
 
-    def init(self, xs):
+    def init(self, xs, jitter=None):
+        """``jitter`` [nlive, ndata]: noise added to the likelihoods (musefuse.py:535)."""
         self.live = numpy.array(self.scorer.loglike_batch(self.to_kernel_params(xs), numpy.ones(self.ndata, dtype=bool)))
+        if jitter is not None:
+            self.live = self.live + jitter
         self.nevals_scored += self.live.size
         self.ncalls += 1
         assert self.live.shape == (self.nlive, self.ndata)
@@ -94,8 +98,9 @@ class HostJointState(object):
     def draw(self, xs, rows):
         return self.draw_params(self.to_kernel_params(xs), rows)
 
-    def draw_params(self, params, rows):
-        """``draw`` for candidates given as kernel parameter rows."""
+    def draw_params(self, params, rows, jitter=None):
+        """``draw`` for candidates given as kernel parameter rows; ``jitter`` [B, M] is added to
+        their likelihoods before anything is compared or kept."""
         rows = numpy.arange(self.ndata) if rows is None else numpy.asarray(rows, dtype=int)
         mask = numpy.zeros(self.ndata, dtype=bool)
         mask[rows] = True
@@ -103,6 +108,8 @@ class HostJointState(object):
         pos, chunk = 0, 1
         while pos < len(params):
             Ls = self.scorer.loglike_batch(params[pos:pos + chunk], mask)
+            if jitter is not None:
+                Ls = Ls + jitter[pos:pos + len(Ls)]
             self.nevals_scored += Ls.size
             self.ncalls += 1
             ok = (Ls > thr).any(axis=1)
@@ -175,7 +182,7 @@ class GaussJointState(object):
         self._lib = _lib.require_device()
         self.spectra = spectra                             # keeps the spectra handle alive
         self.nlive, self.ndata = int(nlive), int(spectra.ndata)
-        self.noise_level = float(spectra.noise_level)
+        self.noise_level = float(getattr(spectra, "noise_level", 0.0))
         self.to_kernel_params = to_kernel_params
         self._h = self._lib.mdns_joint_create(spectra.handle, self.nlive, int(shelf_cap))
         if not self._h:
@@ -261,9 +268,13 @@ class GaussJointState(object):
         B = min(len(xs), _lib.JOINT_MAX_BATCH)
         return self.draw_params(self.to_kernel_params(xs[:B]), rows)
 
-    def draw_params(self, params, rows):
+    def draw_params(self, params, rows, jitter=None):
         """``draw`` for candidates given as kernel parameter rows (A, mu, sig)."""
         M = self.ndata if rows is None else len(rows)
+        if jitter is not None:
+            if not self.via_backend:
+                raise ValueError("likelihood jitter goes through the backend entry points")
+            jitter = _lib.as_f64(jitter)
         B = min(len(params), _lib.JOINT_MAX_BATCH)
         params = _lib.as_f64(params[:B])
         if rows is not None:
@@ -273,8 +284,9 @@ class GaussJointState(object):
                 return -1, None, None, B
             self._check(self._lib.mdns_backend_draw_begin(self._h, _lib.ptr(rows) if rows is not None else None, M),
                         "mdns_backend_draw_begin")
-            self._check(self._lib.mdns_backend_draw_chunk(self._h, _lib.ptr(params), B, C.addressof(self._accepted),
-                                                          _lib.ptr(self._bits), C.addressof(self._nscored)),
+            self._check(self._lib.mdns_backend_draw_chunk(self._h, _lib.ptr(params), B,
+                                                          _lib.ptr(jitter) if jitter is not None else None,
+                                                          C.addressof(self._accepted), _lib.ptr(self._bits), C.addressof(self._nscored)),
                         "mdns_backend_draw_chunk")
             self.ncalls += 1
             self.nevals_scored += B * M
@@ -383,6 +395,35 @@ class GaussJointState(object):
         return higher, n.astype(int)
 
 
+class MuseJointState(GaussJointState):
+    """The joint state of the MUSE-style problem on the GPU: spectra with per-pixel variances
+    (:class:`massivedatans_amd.like.MuseSpectra`), the three-line template evaluated on the device
+    from 5 parameters, the scale-marginalised likelihood of cmuselike.c:45-64.  Draw chunks go
+    through the entry points a native constrainer calls (``mdns_backend_draw_*``)."""
+
+    nparams = 5
+
+    def __init__(self, spectra, nlive, shelf_cap=64):
+        super(MuseJointState, self).__init__(spectra, nlive, lambda xs: xs, shelf_cap=shelf_cap, fetch_rows=False, via_backend=True)
+
+    def init(self, xs, jitter=None):
+        params = _lib.as_f64(xs)
+        if params.shape != (self.nlive, 5):
+            raise ValueError("initial points must be [nlive, 5]")
+        if jitter is not None:
+            jitter = _lib.as_f64(jitter)
+            if jitter.shape != (self.nlive, self.ndata):
+                raise ValueError("jitter must be [nlive, ndata]")
+        self._check(self._lib.mdns_joint_init_muse3(self._h, _lib.ptr(params), _lib.ptr(jitter) if jitter is not None else None),
+                    "mdns_joint_init_muse3")
+        self.shelf_n[:] = 0
+        self.nevals_scored += self.nlive * self.ndata
+        self.ncalls += 1
+
+    def chunk_size(self, offered, M, hint=None):
+        return int(self._lib.mdns_backend_chunk_size(self._h, int(offered), int(M), int(hint or 1)))
+
+
 _POP8 = numpy.array([bin(i).count("1") for i in range(256)], dtype=numpy.int64)
 
 
@@ -391,4 +432,4 @@ def _popcount(words):
     return _POP8[numpy.ascontiguousarray(words).view(numpy.uint8).reshape(len(words), 8)].sum(axis=1)
 
 
-__all__ = ['HostJointState', 'GaussJointState']
+__all__ = ['HostJointState', 'GaussJointState', 'MuseJointState']

@@ -164,9 +164,32 @@ class MultiNestedSampler(object):
         # nlive prior draws, every data set starts from the same points: all are superpoints
         # (multi_nested_sampler.py:88-103).  RNG: nlive x uniform(0, 1, ndim).
         all_mask = numpy.ones(ndata) == 1
-        us = [self.draw_global_uniform() for _ in range(nlive_points)]
-        xs = [priortransform(u) for u in us]
-        if self.joint is not None:
+        jitter_sigma = getattr(self.joint, 'jitter_sigma', 0.0) if self.joint is not None else 0.0
+        if jitter_sigma > 0:
+            # a likelihood that draws noise with every evaluation (musefuse.py:535): the reference
+            # alternates  u = uniform(ndim)  and  L = loglikelihood(x)  per initial point (:90-94),
+            # so the noise of point i sits between the coordinates of points i and i + 1 in the stream
+            us, noise = [], []
+            for _ in range(nlive_points):
+                us.append(self.draw_global_uniform())
+                noise.append(numpy.random.normal(0, jitter_sigma, size=ndata))
+            xs = [priortransform(u) for u in us]
+            self.joint.init(numpy.array(xs), jitter=numpy.array(noise))
+            Ls = None
+        elif multi_loglikelihood_batch is None and self.joint is None:
+            # one point at a time, like the reference (:90-94): a likelihood that consumes random
+            # numbers itself must see them in that order
+            us, xs, Ls = [], [], []
+            for _ in range(nlive_points):
+                us.append(self.draw_global_uniform())
+                xs.append(priortransform(us[-1]))
+                Ls.append(multi_loglikelihood(xs[-1], data_mask=all_mask))
+        else:
+            us = [self.draw_global_uniform() for _ in range(nlive_points)]
+            xs = [priortransform(u) for u in us]
+        if jitter_sigma > 0 or (multi_loglikelihood_batch is None and self.joint is None):
+            pass
+        elif self.joint is not None:
             self.joint.init(numpy.array(xs))            # the matrix is computed where it stays
             Ls = None
         elif multi_loglikelihood_batch is not None:
@@ -196,6 +219,10 @@ class MultiNestedSampler(object):
         self._walk = None                   # native incremental grouping walk (csrc/host_groups.c)
         self._low = None                    # smallest live likelihoods per data set (_refresh_thresholds)
         self._low_cap = -1
+        if self.native is not None:
+            # numpy's normal() may have left half a pair of Gaussian deviates cached: it travels
+            # with the stream the native constrainers continue
+            self.native.sync_gauss_from_numpy()
 
     def __del__(self):
         try:

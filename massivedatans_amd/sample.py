@@ -151,7 +151,12 @@ def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False
     context = None
     if native:
         from . import constrainer
-        context = native_context(joint, constrainer.sample_py_prior(), problem.ndata)
+        prior = problem.native_prior() if hasattr(problem, 'native_prior') else constrainer.sample_py_prior()
+        context = native_context(joint, prior, problem.ndata)
+    # (the problem definition: sample.py's by default, the problem object's own when it has one)
+    prior_fn = getattr(problem, 'priortransform', priortransform)
+    prior_batch = getattr(problem, 'priortransform_batch', priortransform_batch)
+    ndim = getattr(problem, 'nparams', nparams)
     if context is not None:
         # every constrainer of this sampler: MLFriends with the reference driver's settings
         # (sample.py:133-137), in the library
@@ -167,13 +172,13 @@ def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False
     on_device = isinstance(joint, GaussJointState) or isinstance(getattr(joint, 'local', None), GaussJointState)
     device_groups = use_graph and on_device and os.environ.get('MDNS_DEVICE_GROUPS', '1') != '0'
     sampler = MultiNestedSampler(
-        nlive_points=nlive_points, priortransform=priortransform,
-        multi_loglikelihood=problem.multi_loglikelihood, ndim=nparams, ndata=problem.ndata,
+        nlive_points=nlive_points, priortransform=prior_fn,
+        multi_loglikelihood=problem.multi_loglikelihood, ndim=ndim, ndata=problem.ndata,
         superset_draw_constrained=superset_constrainer.draw_constrained,
         individual_draw_constrained=individual_draw_constrained,
         draw_constrained=cc.get, nsuperset_draws=nsuperset_draws, use_graph=use_graph,
-        multi_loglikelihood_batch=problem.multi_loglikelihood_batch if batched else None,
-        joint_state=joint, priortransform_batch=priortransform_batch if fused else None,
+        multi_loglikelihood_batch=getattr(problem, 'multi_loglikelihood_batch', None) if batched else None,
+        joint_state=joint, priortransform_batch=prior_batch if fused else None,
         device_groups=device_groups, native=context)
     superset_constrainer.sampler = sampler
     cc.sampler = sampler

@@ -186,7 +186,7 @@ class Recorder(object):
         return self._s.cut_down(surviving)
 
 
-def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horns", use_graph=False):
+def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horns", use_graph=False, nx=1024):
     import cachedconstrainer
     import hiermetriclearn
     from clustering.radfriendsregion import RadFriendsRegion
@@ -213,24 +213,44 @@ def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horn
         return Py2Constrainer(metriclearner='truncatedscaling', force_shrink=True, rebuild_every=1000,
                               metric_rebuild_every=20, verbose=False)
 
-    data = (gen.horns if generator == "horns" else gen.nothing)(ndata)
-    x, y = data["x"], data["y"]
     ref = Oracle("reference")
     noise_level = 0.01
+    if generator == "muse":
+        # BASELINE.json configs[4]: the likelihood of musefuse.py:520-535 -- host template, the
+        # reference's cmuselike.so, N(0, 1e-5) noise from the global stream on EVERY evaluation --
+        # on the synthetic cube and three-line template SURVEY 8(d) defines (the reference's own
+        # model needs external grids, musefuse.py:171-284); prior ranges of massivedatans_amd.musefuse
+        from massivedatans_amd import musefuse as problem_definition
+        data = gen.muse_like(ndata, nx)
+        x, y, v = data["x"], numpy.ascontiguousarray(data["y"]), numpy.ascontiguousarray(data["v"])
+        Lout = numpy.zeros(ndata)
+        ndim = problem_definition.nparams
+        priortransform = problem_definition.priortransform
 
-    def priortransform(cube):                          # sample.py:52-58
-        cube = cube.copy()
-        cube[0] = 10 ** (cube[0] * 2 - 2)
-        cube[1] = cube[1] * 400 + 400
-        cube[2] = cube[2] * 2
-        return cube
+        def multi_loglikelihood(params, data_mask):    # musefuse.py:520-535
+            ypred = gen.muse_template(x, params)
+            if not numpy.any(ypred):
+                return numpy.ones(data_mask.sum()) * -1e100
+            ref.muse_like(y, v, ypred, data_mask, Lout=Lout)
+            return Lout[data_mask] + numpy.random.normal(0, 1e-5, size=data_mask.sum())
+    else:
+        data = (gen.horns if generator == "horns" else gen.nothing)(ndata)
+        x, y = data["x"], data["y"]
+        ndim = 3
 
-    def multi_loglikelihood(params, data_mask):        # sample.py:101-108
-        A, mu, log_sig_kms = params
-        sig = 10 ** log_sig_kms
-        Lout = numpy.zeros(data_mask.sum())
-        ref.gauss_like(x, y, A, mu, sig, noise_level, data_mask, Lout=Lout)
-        return -0.5 * Lout
+        def priortransform(cube):                          # sample.py:52-58
+            cube = cube.copy()
+            cube[0] = 10 ** (cube[0] * 2 - 2)
+            cube[1] = cube[1] * 400 + 400
+            cube[2] = cube[2] * 2
+            return cube
+
+        def multi_loglikelihood(params, data_mask):        # sample.py:101-108
+            A, mu, log_sig_kms = params
+            sig = 10 ** log_sig_kms
+            Lout = numpy.zeros(data_mask.sum())
+            ref.gauss_like(x, y, A, mu, sig, noise_level, data_mask, Lout=Lout)
+            return -0.5 * Lout
 
     cachedconstrainer.generate_fresh_constrainer = fresh            # sample.py:157
     superset_constrainer = fresh()
@@ -239,7 +259,7 @@ def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horn
     numpy.random.seed(1)                                            # sample.py:162
     sampler = MultiNestedSampler(
         nlive_points=nlive, priortransform=priortransform, multi_loglikelihood=multi_loglikelihood,
-        ndim=3, ndata=ndata, superset_draw_constrained=superset_constrainer.draw_constrained,
+        ndim=ndim, ndata=ndata, superset_draw_constrained=superset_constrainer.draw_constrained,
         individual_draw_constrained=individual_draw_constrained, draw_constrained=cc.get,
         nsuperset_draws=nsuperset_draws, use_graph=use_graph)
     superset_constrainer.sampler = sampler
@@ -249,7 +269,7 @@ def run_reference(ndata, nlive, max_samples, nsuperset_draws=10, generator="horn
     rng_probe = numpy.random.uniform()
     return dict(
         ndata=ndata, nlive=nlive, max_samples=max_samples, nsuperset_draws=nsuperset_draws,
-        use_graph=int(use_graph),
+        use_graph=int(use_graph), nx=nx,
         logZ=results["logZ"], logZerr=results["logZerr"], information=results["information"],
         ndraws=sampler.ndraws, nweights=len(results["weights"]),
         iter_nrunning=numpy.array([len(L) for L in rec.Ls]),
@@ -275,6 +295,9 @@ CASES = {
     "horns12_graph": (12, 24, 260, 10, "horns", True),
     "nothing4_graph": (4, 40, 1500, 3, "nothing", True),
     "horns100_graph": (100, 50, 300, 10, "horns", True),
+    # the MUSE-style problem (cmuselike.c likelihood + per-evaluation noise), 1024 channels
+    "muse6": (6, 20, 120, 10, "muse", False),
+    "muse10_graph": (10, 25, 200, 10, "muse", True),
 }
 LIGHT = {"horns100", "horns100_graph"}          # cases kept small: no iter_L / iter_u
 

@@ -75,3 +75,31 @@ def patch_neighbors(monkeypatch, oracle):
     monkeypatch.setattr(neighbors, "is_within_distance_of", within)
     monkeypatch.setattr(neighbors, "bootstrapped_maxdistance_chosen", boot)
     monkeypatch.setattr(neighbors, "most_distant_nearest_neighbor", nn)
+
+
+class OracleMuseSpectra(object):
+    """The CPU oracle as the MUSE backend: ``loglike_batch(ypred[B, nx], mask)`` like
+    like.MuseSpectra, and ``loglike_batch_lines(params[B, 5], mask)`` with the three-line template of
+    massivedatans_amd.gen.muse_template evaluated on the host."""
+
+    def __init__(self, oracle, x, y, v):
+        self.o = oracle
+        self.x = np.ascontiguousarray(x, dtype=float)
+        self.y, self.v = np.ascontiguousarray(y, dtype=float), np.ascontiguousarray(v, dtype=float)
+        self.nx, self.ndata = self.y.shape
+
+    def loglike_batch(self, ypred, data_mask=None):
+        ypred = np.atleast_2d(ypred)
+        if data_mask is None:
+            data_mask = np.ones(self.ndata, dtype=bool)
+        data_mask = np.ascontiguousarray(data_mask, dtype=np.bool_)
+        out = np.empty((len(ypred), int(data_mask.sum())))
+        for b, m in enumerate(ypred):
+            Lout = np.zeros(self.ndata)
+            self.o.muse_like(self.y, self.v, np.ascontiguousarray(m, dtype=float), data_mask, Lout=Lout)
+            out[b] = Lout[data_mask]
+        return out
+
+    def loglike_batch_lines(self, params, data_mask=None):
+        from massivedatans_amd import gen
+        return self.loglike_batch(np.array([gen.muse_template(self.x, p) for p in np.atleast_2d(params)]), data_mask)

@@ -40,6 +40,15 @@ if os.environ.get("MDNS_E2E_PROFILE") == "1":        # cProfile of the whole run
 else:
     results, sampler, problem, duration = _go()
 _live["done"] = True
+if sampler._dgroups is not None and sampler._dgroups.size_log:
+    log = np.array(sampler._dgroups.size_log)
+    edges = [2, 8, 32, 128, 512, 2048, 8192, 1 << 30]
+    hist, lo = {}, 0
+    for e in edges:
+        pick = (log[:, 0] >= lo) & (log[:, 0] < e)
+        hist["M<%d" % e] = {"calls": int(pick.sum()), "split": int((log[pick, 1] > 1).sum())}
+        lo = e
+    print("grouping calls by selection size:", json.dumps(hist), file=sys.stderr)
 print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nlive, cap), "wall_s": duration,
                   "setup_s": time.time() - t0 - duration, "iterations": int(results["nsamples"]),
                   "ndraws": int(sampler.ndraws), "evals_useful": int(sampler.nevals),
