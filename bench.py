@@ -31,7 +31,8 @@ resident in HBM when the timed region starts and every decision taken on the dev
 `value` = (candidate, spectrum) likelihood evaluations per second over all ranks.  N > 1: weak
 scaling, 10 000 spectra per GPU cut from horns(10 000 N), one process per GPU.
 
-The same run also reports (N = 1): `e2e` -- a complete analysis of the same 10 000 spectra capped
+The same run also reports (N = 1): `e2e_full` -- the complete analysis of the same spectra to its
+termination criterion; `e2e` -- a complete analysis of the same 10 000 spectra capped
 at 400 iterations through the real host orchestration, i.e. SURVEY 8(d)'s "evals inside
 draw_constrained / wall time of those draws"; `roofline_hbm_regime` -- K1 one pass over 1.6 GB;
 `cpu_baseline` -- the reference's own clike.so on the host cores.
@@ -205,8 +206,41 @@ def e2e_leg(data, iterations, use_graph=False):
            "grouping": ("connected components on the device (USE_GRAPH=1), %d calls, %.1f rounds each"
                         % (sampler._dgroups.ncalls, sampler._dgroups.mean_rounds())) if sampler._dgroups is not None
            else ("connected components on the host (USE_GRAPH=1)" if use_graph else "discovery-order walk on the host (USE_GRAPH=0)")}
+    if sampler.native is not None:
+        # the constrained draws ran in the library (one native call per draw): its own counters
+        st = sampler.native.stats()
+        out["native_constrainer"] = st
+        out["draw_chunks"] = int(st["chunks"])
+        out["launch_sequences"] = int(st["chunks"] + st["radii"] + st["counts"])
+        out["evals_scored"] = int(st["pairs"] + NLIVE * data["y"].shape[1])
+    if iterations == 0:
+        out["workload"] = "COMPLETE analysis of the same spectra to the termination criterion (tolerance 0.5, nlive %d)" % NLIVE
     if joint is not None:
         joint.close()
+    return out
+
+
+def e2e_muse_leg(x, y_t, v_t, iterations, jitter):
+    """The same for the MUSE-style problem on this GPU's spectra: musefuse.py:520-535 behind the
+    sampler (massivedatans_amd.musefuse), K2 joint state on the device, native constrainer.
+    jitter: the N(0, 1e-5) noise of musefuse.py:535 drawn on the host from the global stream, per
+    evaluated candidate and data set, as the reference does (False: without)."""
+    from massivedatans_amd import musefuse
+    with np.errstate(all="ignore"):
+        results, sampler, problem, duration = musefuse.run(x, y_t, v_t, nlive_points=NLIVE, max_samples=iterations, jitter=jitter)
+    nd = y_t.shape[1]
+    evals_draws = int(sampler.nevals) - NLIVE * nd
+    st = sampler.native.stats() if sampler.native is not None else {}
+    out = {"workload": "complete MUSE-style analysis of these %d spectra x %d channels, capped at %d iterations (nlive %d), "
+                       "likelihood noise %s" % (nd, y_t.shape[0], iterations, NLIVE, "on (musefuse.py:535)" if jitter else "off"),
+           "wall_s": duration, "iterations": int(results["nsamples"]), "ndraws": int(sampler.ndraws),
+           "constrained_draws": int(sampler.ndraw_calls), "evals_useful": evals_draws,
+           "draw_constrained_wall_s": sampler.draw_seconds,
+           "evals_per_s_in_draw_constrained": evals_draws / sampler.draw_seconds if sampler.draw_seconds else None,
+           "evals_per_s_whole_run": int(sampler.nevals) / duration, "native_constrainer": st,
+           "logZ_first3": [float(v) for v in results["logZ"][:3]]}
+    if sampler.joint is not None:
+        sampler.joint.close()
     return out
 
 
@@ -565,6 +599,9 @@ def bench_gauss(args):
         if world == 1 and not args.no_e2e:
             res["e2e"] = e2e_leg(data, args.e2e_iterations)
             res["e2e_graph"] = e2e_leg(data, args.e2e_iterations, use_graph=True)
+            if not args.no_e2e_full:
+                # the whole analysis, not only its cheap first iterations (about 40 s)
+                res["e2e_full"] = e2e_leg(data, 0, use_graph=True)
         if world == 1 and not args.no_hbm_leg:
             res["roofline_hbm_regime"] = hbm_regime_leg(lib, _lib)
         if world == 1 and not args.no_cpu_baseline:
@@ -678,6 +715,9 @@ def bench_muse(args):
                           "flops_per_launch": flops, "hbm_frac_physical": gbs / HBM_PEAK_GBS,
                           "note": "10 flops per (template, channel, spectrum): two dot products and the residual sum"}),
         }
+        if world == 1 and not args.no_e2e:
+            res["e2e"] = e2e_muse_leg(x, y_t, v_t, args.e2e_iterations, jitter=True)
+            res["e2e_no_noise"] = e2e_muse_leg(x, y_t, v_t, args.e2e_iterations, jitter=False)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"], ref_L, which = cpu_baseline_muse(y_t, v_t, templates)
             err = np.max(np.abs(L[which] - ref_L) / np.abs(ref_L))
@@ -704,6 +744,7 @@ def main():
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1.6 GB one-pass HBM-regime measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the capped complete analysis")
     ap.add_argument("--e2e-iterations", type=int, default=400)
+    ap.add_argument("--no-e2e-full", action="store_true", help="skip the complete analysis (about 40 s)")
     ap.add_argument("--event-every", type=int, default=4, help="time every n-th launch of the dominant kernel")
     ap.add_argument("--no-events", action="store_true", help="no per-launch events in the timed loop (roofline empty)")
     ap.add_argument("--workload", default="horns", choices=["horns", "nothing", "muse"])

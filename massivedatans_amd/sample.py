@@ -11,11 +11,13 @@ this image has no h5py, so here both are ``.npz`` with the same dataset names.
     python -m massivedatans_amd.sample data_widths_100.npz 100
 
 Environment knobs as in the reference: NLIVE_POINTS (400), SUPERSET_DRAWS (10), MAXSAMPLES,
-MINSAMPLES, and USE_GRAPH -- which defaults to 0 here (the reference: 1): the grouping of data sets
-by the reference's ``generate_subsets_nograph`` walk is pinned bit for bit against reference runs,
-the igraph variant's point ORDER is restated from igraph's documented behaviour only (igraph is
-not installed here), so asking for it logs a warning.  CONSTRAINER must be MLFRIENDS (the other two draw methods live in
-third-party ``nestle`` and are outside the accelerated path).
+MINSAMPLES, USE_GRAPH (1, as in the reference: the grouping of data sets by connected components,
+computed on the device; 0: the reference's ``generate_subsets_nograph`` walk, native host code).
+Both groupings are pinned bit for bit against runs of the reference's own code -- the graph one
+through an igraph stand-in that implements igraph's documented vertex / cluster numbering, which is
+therefore the one thing assumed rather than observed (oracle/make_trace.py).  CONSTRAINER must be
+MLFRIENDS (the other two draw methods live in third-party ``nestle`` and are outside the accelerated
+path).
 """
 import json
 import logging
@@ -266,11 +268,7 @@ def main(argv=None):
     if constrainer_type != 'MLFRIENDS':
         sys.exit("CONSTRAINER=%s is not available: only MLFRIENDS runs on the accelerated path" % constrainer_type)
     nlive_points = int(os.environ.get('NLIVE_POINTS', '400'))
-    use_graph = os.environ.get('USE_GRAPH', '0') == '1'
-    if use_graph:
-        log.warning('USE_GRAPH=1: when a selection falls into several groups, their order and the point order '
-                    'inside them follow igraph\'s documented behaviour and are not pinned against a run of the '
-                    'reference (a single group is: numpy.unique; so is USE_GRAPH=0)')
+    use_graph = os.environ.get('USE_GRAPH', '1') == '1'               # the reference's default (sample.py:189)
     backend = distributed_backend(data['x'], data['y'])
     results, sampler, problem, duration = run(
         data['x'], data['y'], nlive_points=nlive_points, backend=backend,
