@@ -18,6 +18,7 @@
 // channels in ascending order, d = m - y, acc = fma(d, d, acc), padding channels contributing
 // fma(0, 0, acc) -- so a likelihood does not depend on which kernel computed it.
 #include "mdns_internal.h"
+#include <cstdlib>
 
 namespace mdns {
 
@@ -212,7 +213,9 @@ bool chunk_fits(const mdns_spectra *s, int M, int B)
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
 	const long long groups = (long long) ntiles * ((B + 3) / 4);
-	return ntiles <= 64 && groups <= 16LL * c->num_cus && cols_nx(s->nx) <= 8 * 32 && s->d_x != nullptr;
+	static const char *limit = getenv("MDNS_CHUNK_GROUPS");            // experiments: most workgroups of the accept kernel
+	const long long most = limit && atoll(limit) > 0 ? atoll(limit) : 16LL * c->num_cus;
+	return groups <= most && cols_nx(s->nx) <= 8 * 32 && s->d_x != nullptr;
 }
 
 bool launch_chunk_accept(const mdns_spectra *s, const double *d_params_mapped, int B, double scale,

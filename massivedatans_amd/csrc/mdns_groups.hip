@@ -11,7 +11,11 @@
 //                                of a data set are contiguous; one entry per running data set
 //                                changes per iteration (mdns_groups_replace)
 //   label  int32[ndata]          label of a data set: starts as its own index
-//   plabel int32[npoints]        label of a live point: starts above every index
+//   plabel {stamp, label}[npoints]  label of a live point, valid when `stamp` is the number of the
+//                                current call -- otherwise the point is unclaimed: "above every
+//                                index" -- so that no call has to clear npoints entries first (the
+//                                600 KB fill per call of the first version); one aligned 8-byte
+//                                word, read and written whole
 //
 // One wave per selected data set, one kernel per ROUND: the wave pulls the minimum over
 // label[d], the plabel of its ids and the label of that minimum, and pushes it to whatever
@@ -43,7 +47,6 @@ namespace mdns {
 static constexpr int kBlock = 256;
 static constexpr int kMaxRounds = 64;                 // rounds per batch: their "changed" flags are in the header
 static constexpr int kRoundLimit = 1 << 20;           // a call gives up after this many rounds (never seen)
-static constexpr int kUnclaimed = 0x7f7f7f7f;         // memset pattern: above every data-set index
 
 // counts, failure bits (1 = id out of range, 2 = bad replacement) and, per round, whether it
 // still moved a label
@@ -61,6 +64,11 @@ __device__ __forceinline__ void store_relaxed(int *p, int v)
 {
 	__hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// a point's label in this call: its stored label when the stamp is this call's, else unclaimed
+typedef unsigned long long PLabel;
+__device__ __forceinline__ int plabel_of_point(PLabel w, int call) { return (int) (w >> 32) == call ? (int) (unsigned) w : 0x7f7f7f7f; }
+__device__ __forceinline__ PLabel plabel_make(int call, int label) { return ((PLabel) (unsigned) call << 32) | (unsigned) label; }
 
 __device__ __forceinline__ int wave_min(int v)
 {
@@ -80,7 +88,7 @@ __device__ __forceinline__ int wave_min(int v)
 // store per edge made a round of 10^6 edges 250 us; a round that only looks takes 6).
 __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__ idsT, int nlive,
                                                          const int *__restrict__ rows, int M, long long npoints,
-                                                         int *plabel, int *label, int first,
+                                                         PLabel *plabel, int *label, int first, int call, int flag,
                                                          int *__restrict__ changed, int *__restrict__ status)
 {
 	const int lane = threadIdx.x & 63;
@@ -96,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__
 	for (int p = lane; p < nlive; p += 64) {
 		const int q = mine[p];
 		if (q < 0 || q >= npoints) { bad = true; continue; }
-		const int pl = plabel[q];
+		const int pl = plabel_of_point(plabel[q], call);
 		m = pl < m ? pl : m;
 	}
 	if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(status, 1); return; }
@@ -117,11 +125,12 @@ __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__
 	bool moved = false;
 	for (int p = lane; p < nlive; p += 64) {
 		const int q = mine[p];
-		if (m < plabel[q]) { plabel[q] = m; moved = true; }
+		if (m < plabel_of_point(plabel[q], call)) { plabel[q] = plabel_make(call, m); moved = true; }
 	}
 	if (lane == 0 && (m < l || first)) { label[d] = m; moved = moved || m < l; }
-	// one flag for the round, raised by a wave that moved something unless it is up already
-	if (__ballot(moved) != 0ull && lane == 0 && load_relaxed(changed) == 0) store_relaxed(changed, 1);
+	// one flag for the round -- the call's number: nothing has to be cleared between calls -- raised
+	// by a wave that moved something unless it is up already
+	if (__ballot(moved) != 0ull && lane == 0 && load_relaxed(changed) != flag) store_relaxed(changed, flag);
 }
 
 // [rows][cols] -> [cols][rows]
@@ -149,11 +158,11 @@ __global__ __launch_bounds__(kBlock) void k_groups_finish(const int *__restrict_
 }
 
 // bit q of the map = some selected data set holds live point q: a wave's ballot is the word
-__global__ __launch_bounds__(kBlock) void k_groups_touched(const int *__restrict__ plabel, long long npoints,
+__global__ __launch_bounds__(kBlock) void k_groups_touched(const PLabel *__restrict__ plabel, long long npoints, int call,
                                                            unsigned long long *__restrict__ touched)
 {
 	const long long q = (long long) blockIdx.x * kBlock + threadIdx.x;
-	const bool held = q < npoints && plabel[q] != kUnclaimed;
+	const bool held = q < npoints && (int) (plabel[q] >> 32) == call;
 	const unsigned long long word = __ballot(held);
 	if ((threadIdx.x & 63) == 0 && q < npoints) touched[q >> 6] = word;
 }
@@ -203,19 +212,20 @@ __global__ __launch_bounds__(1024) void k_groups_compact(const unsigned long lon
 		box->header.ncomponents = header->ncomponents;
 		box->header.ndistinct = total;
 		box->header.status = header->status;
+		header->ncomponents = 0;                                       // k_groups_finish of the next call counts from here
 	}
 	__threadfence_system();
 	__syncthreads();
 	if (t == 0) __hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-__global__ __launch_bounds__(kBlock) void k_groups_point_labels(const int *__restrict__ plabel, long long npoints,
+__global__ __launch_bounds__(kBlock) void k_groups_point_labels(const PLabel *__restrict__ plabel, long long npoints, int call,
                                                                 int *__restrict__ point_labels)
 {
 	const long long q = (long long) blockIdx.x * kBlock + threadIdx.x;
 	if (q >= npoints) return;
-	const int l = plabel[q];
-	point_labels[q] = l == kUnclaimed ? -1 : l;
+	const PLabel w = plabel[q];
+	point_labels[q] = (int) (w >> 32) == call ? (int) (unsigned) w : -1;
 }
 
 __global__ __launch_bounds__(kBlock) void k_groups_replace(int *__restrict__ idsT, int ndata, int nlive,
@@ -249,6 +259,10 @@ struct mdns_groups {
 	bool have_ids = false;
 	int last_M = -1;  long long last_npoints = 0;      // of the last components call (-1: ids changed since)
 	int rounds_hint = 4;                               // rounds the next call launches before it looks
+	int call = 0;                                      // number of the current components call (stamps)
+	int label_call = 0;                                // the stamp the point labels of the last call carry
+	char *h_rows = nullptr;  size_t rows_bytes = 0;    // pinned staging of a call's selection (its own block:
+	                                                   // every call ends by polling, so it is free at the next one)
 	long long rounds_total = 0, calls_total = 0;
 };
 
@@ -257,8 +271,8 @@ static_assert(sizeof(GroupsHeader) <= kHeaderBytes, "header grew");
 static size_t words_of(long long npoints) { return (size_t) ((npoints + 63) / 64); }
 static GroupsHeader *hdr_of(mdns_groups *g) { return (GroupsHeader *) g->d_points; }
 static unsigned long long *touched_of(mdns_groups *g) { return (unsigned long long *) (g->d_points + kHeaderBytes); }
-static int *plabel_of(mdns_groups *g) { return (int *) (touched_of(g) + words_of(g->cap_points)); }
-static int *pout_of(mdns_groups *g) { return plabel_of(g) + g->cap_points; }
+static PLabel *plabel_of(mdns_groups *g) { return (PLabel *) (touched_of(g) + words_of(g->cap_points)); }
+static int *pout_of(mdns_groups *g) { return (int *) (plabel_of(g) + g->cap_points); }
 
 static char *groups_pin(mdns_groups *g, size_t bytes)
 {
@@ -278,11 +292,12 @@ static bool groups_fit_points(mdns_groups *g, long long npoints)
 	long long cap = g->cap_points > 0 ? g->cap_points : 4096;
 	while (cap < npoints) cap *= 2;                                    // (a multiple of 64: the regions stay 8-byte aligned)
 	if (g->d_points) { (void) hipStreamSynchronize(c->stream); (void) hipFree(g->d_points); g->d_points = nullptr; g->cap_points = 0; }
-	const size_t bytes = kHeaderBytes + words_of(cap) * 8 + (size_t) cap * 2 * sizeof(int);
+	const size_t bytes = kHeaderBytes + words_of(cap) * 8 + (size_t) cap * (sizeof(PLabel) + sizeof(int));
 	if (!MDNS_HIP(hipMalloc((void **) &g->d_points, bytes))) return false;
 	g->cap_points = cap;
 	g->last_M = -1;
-	return MDNS_HIP(hipMemsetAsync(g->d_points, 0, kHeaderBytes, c->stream));
+	// header and stamps start at zero: call numbers start at 1
+	return MDNS_HIP(hipMemsetAsync(g->d_points, 0, kHeaderBytes + words_of(cap) * 8 + (size_t) cap * sizeof(PLabel), c->stream));
 }
 
 // mapped host block with room for `ids` distinct ids
@@ -308,6 +323,7 @@ extern "C" void mdns_groups_destroy(mdns_groups *g)
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
 	if (g->h_box) (void) hipHostFree(g->h_box);
+	if (g->h_rows) (void) hipHostFree(g->h_rows);
 	void *bufs[] = {g->d_idsT, g->d_tmp, g->d_label, g->d_rows, g->d_labels, g->d_points};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	if (g->h_pin) (void) hipHostFree(g->h_pin);
@@ -412,34 +428,42 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 	// the most this selection can hold
 	const long long most = (long long) M * g->nlive < npoints ? (long long) M * g->nlive : npoints;
 	if (!groups_fit_box(g, most)) return 1;
-	char *pin = groups_pin(g, (size_t) M * 4);
-	if (!pin) return 1;
 	if (rows) {
-		if (!MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;         // the staging block is free again
-		memcpy(pin, rows, (size_t) M * 4);
-		if (!MDNS_HIP(hipMemcpyAsync(g->d_rows, pin, (size_t) M * 4, hipMemcpyHostToDevice, c->stream))) return 1;
+		// (the selection's own pinned block: the previous call ended by polling for its outcome, so
+		// nothing reads the block any more -- no stream synchronisation)
+		if ((size_t) M * 4 > g->rows_bytes) {
+			if (g->h_rows) { (void) hipStreamSynchronize(c->stream); (void) hipHostFree(g->h_rows); g->h_rows = nullptr; g->rows_bytes = 0; }
+			if (!MDNS_HIP(hipHostMalloc((void **) &g->h_rows, (size_t) g->ndata * 4, hipHostMallocDefault))) return 1;
+			g->rows_bytes = (size_t) g->ndata * 4;
+		}
+		memcpy(g->h_rows, rows, (size_t) M * 4);
+		if (!MDNS_HIP(hipMemcpyAsync(g->d_rows, g->h_rows, (size_t) M * 4, hipMemcpyHostToDevice, c->stream))) return 1;
 	}
 	const int *d_rows = rows ? g->d_rows : nullptr;
-	// counts and round flags cleared (not the failure bits), no live point labelled
-	const size_t clear_bytes = sizeof(GroupsHeader) - offsetof(GroupsHeader, ncomponents);
-	if (!MDNS_HIP(hipMemsetAsync(&hdr_of(g)->ncomponents, 0, clear_bytes, c->stream)) ||
-	    !MDNS_HIP(hipMemsetAsync(plabel_of(g), 0x7f, (size_t) npoints * sizeof(int), c->stream))) return 1;
+	// Nothing is cleared: point labels and the rounds' "moved" flags carry the number of the batch
+	// of rounds they belong to, the component counter is put back to zero by the kernel that reads it.
+	if (g->call >= 0x7ffffff0) {                                     // stamps start over (once in 2^31 batches)
+		if (!MDNS_HIP(hipMemsetAsync(plabel_of(g), 0, (size_t) g->cap_points * sizeof(PLabel), c->stream)) ||
+		    !MDNS_HIP(hipMemsetAsync(hdr_of(g)->changed, 0, sizeof(hdr_of(g)->changed), c->stream))) return 1;
+		g->call = 0;
+	}
+	const int call = ++g->call;
 	const GroupsHeader *h = &g->h_box->header;
 	long long total = 0;
 	int batch = g->rounds_hint + 1, needed = 0;                      // one spare round costs 5 us, a second look 40
+	int flag = call;                                                 // what a round of the current batch writes into its flag
 	while (true) {
-		// counts and flags of this batch start cleared (the first batch's were cleared above)
-		if (total > 0 && !MDNS_HIP(hipMemsetAsync(&hdr_of(g)->ncomponents, 0, clear_bytes, c->stream))) return 1;
+		if (total > 0) flag = ++g->call;                              // (labels keep the stamp `call`; only the flags move on)
 		for (int r = 0; r < batch; r++)
 			hipLaunchKernelGGL(k_groups_round, dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, total == 0 && r == 0 ? 1 : 0,
-			                   &hdr_of(g)->changed[r], &hdr_of(g)->status);
+			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, total == 0 && r == 0 ? 1 : 0, call,
+			                   flag, &hdr_of(g)->changed[r], &hdr_of(g)->status);
 		total += batch;
 		// optimistically everything that follows a converged state, in the same round trip
 		hipLaunchKernelGGL(k_groups_finish, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
 		                   g->d_label, d_rows, M, g->d_labels, hdr_of(g));
 		hipLaunchKernelGGL(k_groups_touched, dim3((unsigned) ((npoints + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-		                   plabel_of(g), npoints, touched_of(g));
+		                   plabel_of(g), npoints, call, touched_of(g));
 		hipLaunchKernelGGL(k_groups_compact, dim3(1), dim3(1024), 0, c->stream, touched_of(g), (long long) nw, pout_of(g), hdr_of(g),
 		                   g->h_box_dev, ++g->box_seq);
 		if (!MDNS_HIP(hipGetLastError())) return 1;
@@ -461,9 +485,9 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 			                     : "mdns_groups_components: an id outside [0, %lld) was met", npoints);
 			return 1;
 		}
-		if (h->changed[batch - 1] == 0) {                            // the last round found nothing to do
+		if (h->changed[batch - 1] != flag) {                         // the last round found nothing to do
 			int clean = batch - 1;
-			while (clean > 0 && h->changed[clean - 1] == 0) clean--;
+			while (clean > 0 && h->changed[clean - 1] != flag) clean--;
 			needed = (int) (total - batch) + clean + 1;              // the deciding round is part of it
 			break;
 		}
@@ -485,6 +509,7 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		    !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
 	}
 	g->last_M = M; g->last_npoints = npoints;
+	g->label_call = call;
 	return 0;
 }
 
@@ -503,7 +528,7 @@ extern "C" int mdns_groups_labels(mdns_groups *g, int32_t *labels, int32_t *poin
 	const long long np = g->last_npoints;
 	if (point_labels)
 		hipLaunchKernelGGL(k_groups_point_labels, dim3((unsigned) ((np + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-		                   plabel_of(g), np, pout_of(g));
+		                   plabel_of(g), np, g->label_call, pout_of(g));
 	if (!MDNS_HIP(hipGetLastError())) return 1;
 	if (labels && !MDNS_HIP(hipMemcpyAsync(labels, g->d_labels, (size_t) M * 4, hipMemcpyDeviceToHost, c->stream))) return 1;
 	if (point_labels && !MDNS_HIP(hipMemcpyAsync(point_labels, pout_of(g), (size_t) np * 4, hipMemcpyDeviceToHost, c->stream))) return 1;

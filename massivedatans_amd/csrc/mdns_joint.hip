@@ -32,22 +32,74 @@ static constexpr int kZeroInts = kFlagInts + (int) (sizeof(JointHeader) / sizeof
 // Start of an iteration, one lane per running data set (multi_nested_sampler.py:130-143):
 // lowest live likelihood and its slot (first occurrence, as numpy.argmin), shelf entries that
 // do not beat it dropped in order, threshold for what is still waiting.
+//
+// ONE pass over the live column: a workgroup = 64 data sets x 4 slices of the live slots; thread
+// (slice g, data set) looks at slots g, g + 4, ... and keeps, besides its minimum, its n0 + 1
+// smallest values sorted in LDS (n0 = entries waiting before the purge: an upper bound of what
+// waits after it, so the threshold -- the (w+1)-th smallest of live + shelf -- lies among the four
+// slices' lists and the shelf).  Slice 0 then purges the shelf and merges.  (The first version
+// walked up the distinct values with one pass over the column per waiting entry: 0.41 ms per
+// iteration in a real run against 5 us with empty shelves.)  Shelves longer than kSelect - 1 take
+// that walk still.
+static constexpr int kSelect = 16;
+
+__device__ double threshold_by_walking(const JointArrays &st, int d, int w, double m)
+{
+	const size_t nd = (size_t) st.ndata;
+	double thr = m, prev = 0.0;
+	bool first = true;
+	int below = 0;
+	while (true) {
+		double cur = INFINITY;
+		int times = 0;
+		for (int p = 0; p < st.nlive; p++) {
+			const double v = st.live[p * nd + d];
+			if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
+		}
+		for (int e = 0; e < w; e++) {
+			const double v = st.shelfL[e * nd + d];
+			if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
+		}
+		below += times;
+		thr = cur;
+		if (below >= w + 1 || times == 0) break;
+		prev = cur;
+		first = false;
+	}
+	return thr;
+}
+
 __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const int *__restrict__ running, int nrun,
                                                           double *__restrict__ Lmin, int *__restrict__ argmin_run,
                                                           int *__restrict__ argmin, unsigned long long *__restrict__ keep,
                                                           int keep_words)
 {
-	// a workgroup = 64 data sets x 4 slices of the live slots: thread (slice g, data set) looks at
-	// slots g, g + 4, ... (a quarter of the serial loads), the four partial minima meet in LDS --
-	// ties go to the lower slot, which is numpy.argmin's first occurrence -- and slice 0 goes on
 	__shared__ double part_m[4][64];
 	__shared__ int part_i[4][64];
+	__shared__ int part_n[4][64];
+	__shared__ double low[4][kSelect][64];          // [slice][rank][data set]: a lane's addresses are 512 B apart, a wave's consecutive
+	__shared__ double waiting[kSelect][64];
 	const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
 	const int r = blockIdx.x * 64 + lane;
 	const int d = running[r < nrun ? r : nrun - 1];
 	const size_t nd = (size_t) st.ndata;
+	const int n0 = st.shelfn[d];
+	const int want = n0 + 1 <= kSelect ? n0 + 1 : 0;            // 0: the shelf is too long for the lists
 	double m = INFINITY;
-	int am = 0x7fffffff;
+	int am = 0x7fffffff, have = 0;
+	auto offer = [&](double v, int p) {
+		if (v < m) { m = v; am = p; }
+		if (want == 1 || !(v == v)) return;                       // the minimum is the list; a NaN is never counted
+		if (have < want) {
+			int k = have++;
+			for (; k > 0 && low[g][k - 1][lane] > v; k--) low[g][k][lane] = low[g][k - 1][lane];
+			low[g][k][lane] = v;
+		} else if (want > 1 && v < low[g][want - 1][lane]) {
+			int k = want - 1;
+			for (; k > 0 && low[g][k - 1][lane] > v; k--) low[g][k][lane] = low[g][k - 1][lane];
+			low[g][k][lane] = v;
+		}
+	};
 	{
 		int p = g;
 		for (; p + 28 < st.nlive; p += 32) {                     // eight loads in flight
@@ -55,15 +107,13 @@ __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const 
 #pragma unroll
 			for (int u = 0; u < 8; u++) v[u] = st.live[(p + 4 * u) * nd + d];
 #pragma unroll
-			for (int u = 0; u < 8; u++) if (v[u] < m) { m = v[u]; am = p + 4 * u; }
+			for (int u = 0; u < 8; u++) offer(v[u], p + 4 * u);
 		}
-		for (; p < st.nlive; p += 4) {
-			const double v = st.live[p * nd + d];
-			if (v < m) { m = v; am = p; }
-		}
+		for (; p < st.nlive; p += 4) offer(st.live[p * nd + d], p);
 	}
 	part_m[g][lane] = m;
 	part_i[g][lane] = am;
+	part_n[g][lane] = have;
 	__syncthreads();
 	if (g != 0 || r >= nrun) return;
 #pragma unroll
@@ -74,44 +124,49 @@ __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const 
 	}
 	if (am == 0x7fffffff) am = 0;                                // a column of NaNs: numpy.argmin's answer is moot
 	// purge (multi_nested_sampler.py:137-138: keep entries with L > Lmin, order kept)
-	const int n = st.shelfn[d];
 	int w = 0;
 	for (int word = 0; word < keep_words; word++) {
 		unsigned long long bits = 0;
-		const int e1 = min(n, 64 * (word + 1));
+		const int e1 = min(n0, 64 * (word + 1));
 		for (int e = 64 * word; e < e1; e++) {
 			const double v = st.shelfL[e * nd + d];
 			if (v > m) {
 				bits |= 1ull << (e & 63);
 				if (w != e) st.shelfL[w * nd + d] = v;
+				if (w < kSelect) waiting[w][lane] = v;
 				w++;
 			}
 		}
 		keep[(size_t) r * keep_words + word] = bits;
 	}
 	st.shelfn[d] = w;
-	// (w+1)-th smallest of live + shelf: walk up the distinct values, counting multiplicities
+	// threshold: the (w+1)-th smallest of live + shelf (find_nsmallest, :44-47)
 	double thr = m;
 	if (w > 0) {
-		double prev = 0.0;
-		bool first = true;
-		int below = 0;
-		while (true) {
-			double cur = INFINITY;
-			int times = 0;
-			for (int p = 0; p < st.nlive; p++) {
-				const double v = st.live[p * nd + d];
-				if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
+		if (want == 0) thr = threshold_by_walking(st, d, w, m);
+		else {
+			// w + 1 extractions from the four sorted lists and the (unsorted) waiting values
+			int head[4] = {0, 0, 0, 0};
+			unsigned used = 0;
+			thr = INFINITY;
+			for (int taken = 0; taken <= w; taken++) {
+				double best = INFINITY;
+				int from = -1;
+#pragma unroll
+				for (int o = 0; o < 4; o++)
+					if (head[o] < part_n[o][lane]) {
+						const double v = low[o][head[o]][lane];
+						if (v < best) { best = v; from = o; }
+					}
+				for (int e = 0; e < w; e++)
+					if (!(used >> e & 1u)) {
+						const double v = waiting[e][lane];
+						if (v < best) { best = v; from = 4 + e; }
+					}
+				if (from < 0) { thr = INFINITY; break; }            // fewer than w + 1 comparable values (NaNs)
+				if (from < 4) head[from]++; else used |= 1u << (from - 4);
+				thr = best;
 			}
-			for (int e = 0; e < w; e++) {
-				const double v = st.shelfL[e * nd + d];
-				if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
-			}
-			below += times;
-			thr = cur;
-			if (below >= w + 1 || times == 0) break;
-			prev = cur;
-			first = false;
 		}
 	}
 	st.higher[d] = thr;

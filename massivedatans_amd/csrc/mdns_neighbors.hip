@@ -658,7 +658,8 @@ bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const uns
 	Context *c = ctx();
 	static const char *forced = getenv("MDNS_K6_PATH");                   // "classic": the masked-NaN kernel (experiments)
 	const bool classic = forced && !strcmp(forced, "classic");
-	if (ndim >= 1 && ndim <= 5 && K >= 64 && !classic) {
+	// (pools of a few hundred points: one launch of the masked-NaN kernel is quicker than two of these)
+	if (ndim >= 1 && ndim <= 5 && K >= 640 && !classic) {
 		const int rt = nbootstraps <= 10 ? 10 : kRounds;
 		const int gy = uniform_chunks(K, c->num_cus);
 		int kchunk = (K + gy - 1) / gy;

@@ -153,6 +153,14 @@ def test_shelves_grow_past_their_first_capacity():
     hb, hm = host.thresholds()
     assert hn.max() > 4, "the test did not fill a shelf past the first capacity"
     assert np.array_equal(hn, hm) and np.array_equal(ha, hb)
+    # and the start of the next iteration with shelves this long: nothing is purged (the live points
+    # did not change), the thresholds -- (n+1)-th smallest of live + shelf, found in ONE pass with
+    # per-slice selection lists up to 15 waiting entries, by walking the values beyond -- stay
+    assert hn.max() >= 16 and (hn > 0).any() and (hn < 16).any(), "both threshold paths must be exercised"
+    a, b = dev.prepare(), host.prepare()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] is None and b[2] is None
+    ha2, hn2 = dev.thresholds()
+    assert np.array_equal(hn2, hn) and np.array_equal(ha2, ha)
     dev.close()
 
 
