@@ -215,6 +215,11 @@ bool chunk_fits(const mdns_spectra *s, int M, int B)
 	const long long groups = (long long) ntiles * ((B + 3) / 4);
 	static const char *limit = getenv("MDNS_CHUNK_GROUPS");            // experiments: most workgroups of the accept kernel
 	const long long most = limit && atoll(limit) > 0 ? atoll(limit) : 16LL * c->num_cus;
+	// Measured (tools/chunk_bench.py, us per chunk, this path / the five-command one): 300 spectra x 32
+	// candidates 24.7 / 39.5, 4096 x 32: 26.9 / 37.2, 3000 x 128: 44.6 / 47.6, 10 000 x 4: 22.3 / 31.6 -- but
+	// 10 000 x 32: 43.2 / 36.9 and 10 000 x 128: 49.5 / 44.8: with every spectrum selected and several
+	// candidate tiles the lane kernel on the channel-major replica reads perfectly coalesced.
+	if (M > 4096 && B > 8) return false;
 	return groups <= most && cols_nx(s->nx) <= 8 * 32 && s->d_x != nullptr;
 }
 
