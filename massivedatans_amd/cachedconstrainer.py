@@ -61,7 +61,7 @@ class CachedConstrainer(object):
             return False
         return (len(mask) < len(self.last_mask) and len(mask) > 0.80 * len(self.last_mask)
                 and len(points) <= len(self.last_points) and len(points) > 0.90 * len(self.last_points)
-                and numpy.mean(self.last_realmask == realmask) > 0.80
+                and (self.last_realmask is realmask or numpy.mean(self.last_realmask == realmask) > 0.80)
                 and self._all_among_last(points))
 
     def _all_among_last(self, points):

@@ -121,6 +121,29 @@ class _Shelves(object):
                  for k in range(self.n[d])] for d in range(len(self.n))]
 
 
+class _LazyMask(object):
+    """The boolean mask over ``n`` data sets that is True at ``members`` -- built when somebody looks
+    at it (the native draw path works from the member indices and never does)."""
+
+    def __init__(self, n, members):
+        self.n, self.members, self._mask = n, members, None
+
+    def __array__(self, dtype=None, copy=None):
+        if self._mask is None:
+            self._mask = numpy.zeros(self.n, dtype=bool)
+            self._mask[self.members] = True
+        return self._mask if dtype is None else self._mask.astype(dtype)
+
+    def __len__(self):
+        return self.n
+
+    def sum(self):
+        return len(self.members)
+
+    def tobytes(self):
+        return numpy.asarray(self).tobytes()
+
+
 class MultiNestedSampler(object):
     def __init__(self, priortransform, multi_loglikelihood, superset_draw_constrained,
                  individual_draw_constrained, draw_constrained, ndata, ndim, nlive_points=200,
@@ -559,11 +582,18 @@ class MultiNestedSampler(object):
                 yield data_mask, ids
                 return
             labels, point_labels = dg.labels()
+            # components in ascending order of their label (= their lowest data set: igraph's cluster
+            # order), members and ids ascending inside: two stable sorts instead of one pass over all
+            # data sets and ids per component (a selection can fall into dozens of components)
+            order = numpy.argsort(labels, kind='stable')
+            cuts = numpy.flatnonzero(numpy.diff(labels[order])) + 1
             of_id = point_labels[ids]
-            for root in numpy.unique(labels):            # ascending: clusters in order of their first vertex
-                member_mask = numpy.zeros(len(data_mask), dtype=bool)
-                member_mask[selected[labels == root]] = True
-                yield member_mask, ids[of_id == root]
+            id_order = numpy.argsort(of_id, kind='stable')
+            id_cuts = numpy.flatnonzero(numpy.diff(of_id[id_order])) + 1
+            members = numpy.split(selected[order], cuts)
+            for group_members, group_ids in zip(members, numpy.split(ids[id_order], id_cuts)):
+                # (mask built only for callers that ask: a _LazyMask is a mask for numpy.where & co.)
+                yield _LazyMask(len(data_mask), group_members), group_ids, group_members
             return
         lib = _host_lib()
         if lib is not None:
@@ -680,11 +710,14 @@ class MultiNestedSampler(object):
             assert len(groups) > 0
             rebuilding_draw = focussed or len(groups) > 1
 
-            for joint_data_mask, joint_live_pointsp in groups:
+            for group in groups:
+                joint_data_mask, joint_live_pointsp = group[0], group[1]
                 # (the grouping may have listed the members of the mask it handed back already)
                 known = self._last_selection
                 if known is not None and known[0] is joint_data_mask:
                     joint_indices, real_rows = known[1], known[2]
+                elif len(group) > 2:
+                    joint_indices, real_rows = group[2], None
                 else:
                     joint_indices, real_rows = numpy.where(joint_data_mask)[0], None
                 njoints = len(joint_indices)
