@@ -45,6 +45,7 @@
 namespace mdns {
 
 static constexpr int kBlock = 256;
+static constexpr int kSweeps = 2;                     // pull-and-push passes per launch of k_groups_round
 static constexpr int kMaxRounds = 64;                 // rounds per batch: their "changed" flags are in the header
 static constexpr int kRoundLimit = 1 << 20;           // a call gives up after this many rounds (never seen)
 
@@ -89,45 +90,59 @@ __device__ __forceinline__ int wave_min(int v)
 __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__ idsT, int nlive,
                                                          const int *__restrict__ rows, int M, long long npoints,
                                                          PLabel *plabel, int *label, int first, int call, int flag,
-                                                         int *__restrict__ changed, int *__restrict__ status)
+                                                         int *__restrict__ changed, int *__restrict__ status, int sweeps)
 {
 	const int lane = threadIdx.x & 63;
 	const int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	if (i >= M) return;                                               // whole waves
 	const int d = rows ? rows[i] : i;
 	const int *mine = idsT + (size_t) d * nlive;
-	// the first round of a call starts every data set from its own index (label[] still holds
-	// the previous call's values: nobody reads another data set's label in this round)
-	const int l = first ? d : label[d];
-	int m = l;
-	bool bad = false;
-	for (int p = lane; p < nlive; p += 64) {
-		const int q = mine[p];
-		if (q < 0 || q >= npoints) { bad = true; continue; }
-		const int pl = plabel_of_point(plabel[q], call);
-		m = pl < m ? pl : m;
-	}
-	if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(status, 1); return; }
-	m = wave_min(m);
-	if (!first) {
-		// m is a data set of this component: follow ITS label down to a data set that keeps its
-		// own (labels only point to lower indices, so this ends) ...
-		while (true) {
-			const int lm = label[m];
-			if (lm >= m) break;
-			m = lm;
-		}
-		// ... and hang the data set d stood under below it too: everybody who still points at
-		// that one gets there with the next jump (without this a path of n data sets in random
-		// order needs ~n rounds; with it a few dozen for n = 20 000)
-		if (lane == 0 && m < l && m < label[l]) label[l] = m;
-	}
 	bool moved = false;
-	for (int p = lane; p < nlive; p += 64) {
-		const int q = mine[p];
-		if (m < plabel_of_point(plabel[q], call)) { plabel[q] = plabel_make(call, m); moved = true; }
+	// `sweeps` passes of the same pull-and-push per launch: what a wave sees of the others' stores
+	// within a launch is whatever has reached its caches -- stale values only cost progress, as
+	// between launches -- and a launch in which NO sweep moved anything started from coherent memory
+	// and found the fixed point, exactly like a single-sweep round (each launch costs ~8 us of
+	// dispatch against ~5 us of work: two sweeps per launch halve the launches a call needs)
+	for (int sweep = 0; sweep < sweeps; sweep++) {
+		const bool start = first && sweep == 0;
+		// the first round of a call starts every data set from its own index (label[] still holds
+		// the previous call's values: nobody reads another data set's label in this round)
+		const int l = start ? d : label[d];
+		int m = l;
+		bool bad = false;
+		for (int p = lane; p < nlive; p += 64) {
+			const int q = mine[p];
+			if (q < 0 || q >= npoints) { bad = true; continue; }
+			const int pl = plabel_of_point(plabel[q], call);
+			m = pl < m ? pl : m;
+		}
+		if (__ballot(bad) != 0ull) { if (lane == 0) atomicOr(status, 1); return; }
+		m = wave_min(m);
+		if (!start) {
+			// m is a data set of this component: follow ITS label down to a data set that keeps its
+			// own (labels only point to lower indices, so this ends) ...
+			while (true) {
+				const int lm = label[m];
+				if (lm >= m) break;
+				m = lm;
+			}
+			// ... and hang the data set d stood under below it too: everybody who still points at
+			// that one gets there with the next jump (without this a path of n data sets in random
+			// order needs ~n rounds; with it a few dozen for n = 20 000)
+			if (lane == 0 && m < l && m < label[l]) label[l] = m;
+		}
+		for (int p = lane; p < nlive; p += 64) {
+			const int q = mine[p];
+			if (m < plabel_of_point(plabel[q], call)) { plabel[q] = plabel_make(call, m); moved = true; }
+		}
+		if (lane == 0 && (m < l || start)) { label[d] = m; moved = moved || m < l; }
+		if (first && sweeps > 1 && sweep == 0) {
+			// the sweep that follows reads other data sets' labels: all of them must have been
+			// initialised by THIS launch first (label[] holds the previous call's values), which
+			// only the next launch guarantees -- so the first launch of a call makes one sweep
+			break;
+		}
 	}
-	if (lane == 0 && (m < l || first)) { label[d] = m; moved = moved || m < l; }
 	// one flag for the round -- the call's number: nothing has to be cleared between calls -- raised
 	// by a wave that moved something unless it is up already
 	if (__ballot(moved) != 0ull && lane == 0 && load_relaxed(changed) != flag) store_relaxed(changed, flag);
@@ -457,7 +472,7 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		for (int r = 0; r < batch; r++)
 			hipLaunchKernelGGL(k_groups_round, dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
 			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, total == 0 && r == 0 ? 1 : 0, call,
-			                   flag, &hdr_of(g)->changed[r], &hdr_of(g)->status);
+			                   flag, &hdr_of(g)->changed[r], &hdr_of(g)->status, kSweeps);
 		total += batch;
 		// optimistically everything that follows a converged state, in the same round trip
 		hipLaunchKernelGGL(k_groups_finish, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,

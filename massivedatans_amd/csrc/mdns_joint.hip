@@ -1104,10 +1104,11 @@ extern "C" int mdns_backend_chunk_size(void *joint, int offered, int M, int hint
 	// and each speculative candidate also costs its jitter deviates on the host)
 	const bool muse = j && j->kind == 1;
 	const long long EVAL_BUDGET = muse ? 400000 : 2560000;
-	// (at least 8: early in a run two candidates in five are accepted and a chunk of 32 scored 30 of
-	// them for nothing -- with 8 a chunk over all 10 000 spectra is two launches and 22 us instead of
-	// five commands and 44)
-	const int MIN_CHUNK = muse ? 4 : 8;
+	// (over thousands of spectra at least 8: early in a run two candidates in five are accepted and a
+	// chunk of 32 scored 30 of them for nothing -- with 8 a chunk over all 10 000 spectra is two
+	// launches and 22 us instead of five commands and 44.  Over a few hundred spectra at least 32:
+	// there a chunk costs its round trip whatever it holds, and 8 meant a fifth more chunks.)
+	const int MIN_CHUNK = muse ? 4 : (M > 4096 ? 8 : 32);
 	long long budget = EVAL_BUDGET / (M > 0 ? M : 1);
 	if (budget < MIN_CHUNK) budget = MIN_CHUNK;
 	long long want = 4LL * (hint > 0 ? hint : 1);

@@ -585,9 +585,12 @@ class MultiNestedSampler(object):
             # components in ascending order of their label (= their lowest data set: igraph's cluster
             # order), members and ids ascending inside: two stable sorts instead of one pass over all
             # data sets and ids per component (a selection can fall into dozens of components)
+            # (labels are data-set indices: as 16-bit keys numpy's stable sort is a radix sort)
+            narrow = numpy.int16 if len(data_mask) < 32768 and dg.ndata < 32768 else labels.dtype
+            labels = labels.astype(narrow)
             order = numpy.argsort(labels, kind='stable')
             cuts = numpy.flatnonzero(numpy.diff(labels[order])) + 1
-            of_id = point_labels[ids]
+            of_id = point_labels[ids].astype(narrow)
             id_order = numpy.argsort(of_id, kind='stable')
             id_cuts = numpy.flatnonzero(numpy.diff(of_id[id_order])) + 1
             members = numpy.split(selected[order], cuts)
