@@ -324,7 +324,7 @@ def _split_with_superpoint(nlive=6):
 
 
 def _graph_groups(s, mask):
-    return [(np.flatnonzero(m).tolist(), [int(p) for p in pts]) for m, pts in s.generate_subsets_graph(mask, None)]
+    return [(np.flatnonzero(np.asarray(g[0])).tolist(), [int(p) for p in g[1]]) for g in s.generate_subsets_graph(mask, None)]
 
 
 def test_superpoint_shortcut_holds_while_the_graph_is_split():

@@ -1,0 +1,34 @@
+#!/bin/bash
+# Everything profiles/ keeps for a round, collected on the GPU box into gpurun_out/<tag>/:
+#   tools/collect_round.sh r03
+# (bench lines, complete analyses in both grouping modes + cProfile, rocprofv3 kernel stats of the
+# bench and of a real run, PMC passes, K6 sweep and counters, chunk round trips)
+set -x
+tag=$1
+out=gpurun_out/$tag
+mkdir -p "$out"
+python bench.py > "$out/bench.json" 2> "$out/bench.err"
+python bench.py --workload nothing --no-e2e-full > "$out/bench_nothing.json" 2> "$out/bench_nothing.err"
+python bench.py --workload muse > "$out/bench_muse_b1.json" 2> "$out/bench_muse_b1.err"
+python bench.py --workload muse --batch 64 --steps 50 --warmup 5 --no-cpu-baseline --no-e2e > "$out/bench_muse_b64.json" 2> "$out/bench_muse_b64.err"
+USE_GRAPH=1 python tools/e2e_run.py horns 10000 100 0 > "$out/e2e_c2_full_graph.json" 2> "$out/e2e_c2_full_graph.err"
+USE_GRAPH=0 python tools/e2e_run.py horns 10000 100 0 > "$out/e2e_c2_full.json" 2> "$out/e2e_c2_full.err"
+USE_GRAPH=1 python tools/e2e_run.py nothing 10000 100 0 > "$out/e2e_c3_full_graph.json" 2> "$out/e2e_c3_full_graph.err"
+USE_GRAPH=0 python tools/e2e_run.py nothing 10000 100 0 > "$out/e2e_c3_full.json" 2> "$out/e2e_c3_full.err"
+USE_GRAPH=1 MDNS_E2E_PROFILE=1 python tools/e2e_run.py horns 10000 100 0 > "$out/e2e_c2_full_graph_profiled.json" 2> "$out/e2e_c2_full_graph_profile.txt"
+USE_GRAPH=0 MDNS_E2E_PROFILE=1 python tools/e2e_run.py horns 10000 100 0 > "$out/e2e_c2_full_profiled.json" 2> "$out/e2e_c2_full_profile.txt"
+python tools/k6_sweep.py > "$out/k6_sweep.json" 2> "$out/k6_sweep.err"
+MDNS_K6_PATH=classic python tools/k6_sweep.py > "$out/k6_sweep_classic.json" 2> "$out/k6_sweep_classic.err"
+python tools/chunk_bench.py > "$out/chunk_bench.log" 2>&1
+python tools/chunk_bench.py classic > "$out/chunk_bench_classic.log" 2>&1
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+USE_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/e2e600_graph" -- python3 tools/e2e_run.py horns 10000 100 600 > "$out/e2e600_graph.log" 2>&1
+USE_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/e2e600" -- python3 tools/e2e_run.py horns 10000 100 600 > "$out/e2e600.log" 2>&1
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
+           "SQ_INSTS_SMEM SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INSTS_LDS"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $set --output-format csv -d "$out/k6_5000/sq$i" -- python3 tools/k6_one.py 5000 > "$out/k6_5000_sq$i.log" 2>&1 || echo "counter set $i failed"
+done
+echo collected "$out"
