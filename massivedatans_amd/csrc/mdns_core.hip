@@ -392,6 +392,8 @@ extern "C" mdns_spectra *mdns_spectra_create(const double *x, const double *y, c
 		const size_t telems = (size_t) cols_nx(nx) * s->ldT;
 		ok = MDNS_HIP(hipMalloc((void **) &s->d_yT, telems * sizeof(double)));
 		ok = ok && launch_tile_columns(s->d_y, s->ld, ndata, nx, nullptr, s->d_yT);
+		ok = ok && MDNS_HIP(hipMalloc((void **) &s->d_ysq, (size_t) ndata * sizeof(double)));
+		ok = ok && launch_row_sumsq(s->d_y, s->ld, nx, ndata, s->d_ysq);
 		ok = ok && MDNS_HIP(hipStreamSynchronize(c->stream));
 	}
 	if (ok && v) {
@@ -413,7 +415,7 @@ extern "C" void mdns_spectra_destroy(mdns_spectra *s)
 	if (!s) return;
 	Context *c = ctx();
 	if (c) (void) hipStreamSynchronize(c->stream);
-	void *bufs[] = {s->d_y, s->d_yT, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out, s->d_sel};
+	void *bufs[] = {s->d_y, s->d_yT, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out, s->d_sel, s->d_ysq};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	delete s;
 }

@@ -44,6 +44,7 @@ struct mdns_spectra {
 	int ldT = 0;             // ndata rounded up to a multiple of 64 (zero padded)
 	double *d_w = nullptr;   // [ndata, ld] inverse variances 1/v (K2), or nullptr
 	double *d_x = nullptr;   // [nx] wavelength grid, or nullptr
+	double *d_ysq = nullptr; // [ndata] sum of squares of every spectrum (K1 accept filter), or nullptr
 	// per-handle grow-only device buffers for the host-pointer batch API
 	double *d_model = nullptr; size_t model_cap = 0;   // [B, ldm]
 	double *d_params = nullptr; size_t params_cap = 0;
@@ -113,6 +114,13 @@ bool launch_chunk_commit(const int *d_thr_rows, int M, int B, const int *d_flags
 bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
                               const double *d_higher, int *d_flags, const JointTrail &trail);
+// the accept test as guarded filter + exact resolve (mdns_like.hip, k_gauss_cols_filter): same flags as
+// launch_gauss_cols_accept, no trail
+bool gauss_filter_pays(const mdns_spectra *s, int M, int B);
+bool launch_gauss_cols_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
+                              double scale, const int *d_rows, const int *d_thr_rows, int M,
+                              const double *d_higher, int *d_flags, double *d_msq, int *d_amb);
+bool launch_row_sumsq(const double *d_y, int ld, int nx, int ndata, double *d_out);
 // first flagged candidate from the trail of the accept pass: fill bits, shelf appends, thresholds
 // (flag_value: what the accept pass wrote into d_flags for an accepted candidate)
 bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,

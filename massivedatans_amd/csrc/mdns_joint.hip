@@ -347,6 +347,7 @@ struct mdns_joint {
 	// template scored with the scale-marginalised chi^2 (cmuselike.c; dense L[B, M] block)
 	int kind = 0;
 	int nparams = 3;
+	double *d_msq = nullptr;  int *d_amb = nullptr;         // scratch of the guarded accept filter (kind 0)
 	double *d_dense = nullptr;  size_t dense_cap = 0;       // L[B, M] of a chunk (kind 1)
 	double *d_jitter = nullptr;  size_t jitter_cap = 0;
 	// the draw in progress through the mdns_backend_* entry points: its selection, uploaded once
@@ -382,6 +383,7 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	if (j->d_sel_rows) (void) hipFree(j->d_sel_rows);
 	if (j->d_dense) (void) hipFree(j->d_dense);
+	if (j->d_msq) (void) hipFree(j->d_msq);
 	if (j->d_jitter) (void) hipFree(j->d_jitter);
 	if (j->h_in) (void) hipHostFree(j->h_in);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
@@ -736,10 +738,21 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 		yT = s->d_sel;
 		gather = nullptr;
 	}
-	JointTrail trail;
-	if (!joint_trail(j, B, M, &trail)) return 1;
-	if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, trail)) return 1;
-	j->trail_valid = true;
+	if (gauss_filter_pays(s, M, B)) {
+		// issue-bound launch: the guarded filter decides (same flags, bit for bit), no trail -- the
+		// commit recomputes the accepted candidate's row with the chain
+		if (!j->d_msq) {
+			if (!MDNS_HIP(hipMalloc((void **) &j->d_msq, (size_t) (MDNS_JOINT_MAX_BATCH + 16) * (sizeof(double) + sizeof(int))))) return 1;
+			j->d_amb = (int *) (j->d_msq + MDNS_JOINT_MAX_BATCH + 16);
+		}
+		if (!launch_gauss_cols_filter(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, j->d_msq, j->d_amb)) return 1;
+		j->trail_valid = false;
+	} else {
+		JointTrail trail;
+		if (!joint_trail(j, B, M, &trail)) return 1;
+		if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, trail)) return 1;
+		j->trail_valid = true;
+	}
 	j->last_yT = yT; j->last_gather = gather; j->last_bt = bt; j->last_B = B; j->last_scale = scale;
 	return 0;
 }

@@ -131,6 +131,19 @@ __global__ void k_gauss_model_t(const double *__restrict__ x, int nx, int nxp, c
 	model_t[e] = m;
 }
 
+// sum of squares of every candidate's template (tiled layout MT[tile][j][BT]): one wave per candidate
+__global__ __launch_bounds__(64) void k_model_sumsq(const double *__restrict__ model_t, int nxp, int bt_size, int B,
+                                                    double *__restrict__ msq, int *__restrict__ zero, int nzero)
+{
+	const int b = blockIdx.x, lane = threadIdx.x;
+	for (int e = b * 64 + lane; e < nzero; e += gridDim.x * 64) zero[e] = 0;      // the filter's "ambiguous" marks
+	const double *col = model_t + (size_t) (b / bt_size) * nxp * bt_size + b % bt_size;
+	double acc = 0.0;
+	for (int j = lane; j < nxp; j += 64) { const double m = col[(size_t) j * bt_size]; acc = fma(m, m, acc); }
+	acc = wave_sum(acc);
+	if (lane == 0) msq[b] = acc;
+}
+
 // three lines on a flat continuum (config C5; massivedatans_amd/gen.py muse_template)
 __global__ void k_muse3_model(const double *__restrict__ x, int nx, const double *__restrict__ params,
                               double *__restrict__ model, int ldm)
@@ -357,7 +370,7 @@ __device__ __forceinline__ bool cols_item(int ntiles, int tile_limit, int nq_xcd
 // width the templates were laid out for while the wave scores ONE candidate of it (BT == 1).
 // Every (candidate, spectrum) sum is the same chain of v_add_f64 / v_fma_f64 whatever BT is,
 // so the likelihood of a pair does not depend on the tile shape it was computed in.
-template <int BT, int SP, bool RUNTIME_STRIDE>
+template <int BT, int SP, bool RUNTIME_STRIDE, bool DOT = false>
 __device__ __forceinline__ void cols_accumulate(const double *__restrict__ YT, int nxp,
                                                 const double *mp, int mstride,
                                                 const int *__restrict__ rows, int M, int tile, int lane,
@@ -407,8 +420,14 @@ __device__ __forceinline__ void cols_accumulate(const double *__restrict__ YT, i
 				const double mv = mp[c * ms + b];
 #pragma unroll
 				for (int s = 0; s < SP; s++) {
-					const double d = mv - cur[s][c];
-					acc[s][b] = fma(d, d, acc[s][b]);
+					if constexpr (DOT) {
+						// the cross term of the expanded square only: ONE v_fmac_f64 with the template
+						// value as scalar operand per (candidate, channel, spectrum)
+						acc[s][b] = fma(mv, cur[s][c], acc[s][b]);
+					} else {
+						const double d = mv - cur[s][c];
+						acc[s][b] = fma(d, d, acc[s][b]);
+					}
 				}
 			}
 		}
@@ -566,6 +585,98 @@ __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_accept(
 			}
 		}
 	}
+}
+
+// The accept test as a GUARDED FILTER, for launches that are bound by vector issue (hundreds of
+// candidates over thousands of spectra).  sum_j (m_j - y_j)^2 = sum m^2 - 2 sum m y + sum y^2: the
+// first sum is a property of the candidate (`msq`, from the template kernel), the last one of the
+// spectrum (`ysq`, computed once at upload), so the launch only has to accumulate the cross term --
+// one v_fmac_f64 per (candidate, channel, spectrum) instead of v_add_f64 + v_fmac_f64.  The value
+// so obtained, Lf, is NOT the chain value L the rest of the library works with (the expanded form
+// cancels), but it lies within a bound that is cheap to compute:
+//     |Lf - L| <= |scale| (nx + 8) 2^-52 (msq + 2 |sum m y| + ysq) =: E     (forward error of three
+//     sums of nx terms and their combination, and of the chain itself)
+// so  Lf > thr + 4 E  implies  L > thr  (flag the candidate: exactly the decision of the chain
+// kernel) and  Lf < thr - 4 E  implies  L <= thr  (no vote).  Anything in between -- one pair in
+// ~10^9 -- marks the candidate AMBIGUOUS and k_gauss_cols_resolve re-scores its tile with the chain
+// kernel's own sums.  Decisions therefore equal those of k_gauss_cols_accept bit for bit; the
+// likelihoods that are KEPT (shelves) always come from the chain (k_gauss_cols_commit).
+template <int BT>
+__global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_filter(
+    const double *__restrict__ YT, int nxp, int nx, const double *__restrict__ model_t, const double *__restrict__ msq, int B,
+    double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
+    int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, const double *__restrict__ ysq,
+    int *__restrict__ flags, int *__restrict__ ambiguous)
+{
+	const int lane = threadIdx.x & 63;
+	int tile, bt;
+	int k[1];
+	double acc[1][BT];
+	if (!cols_item(ntiles, ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
+	const double *mp = model_t + (size_t) bt * nxp * BT;
+	cols_accumulate<BT, 1, false, true>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
+	const bool live = k[0] < M;
+	const int kk = live ? k[0] : M - 1;
+	const int d = thr_rows ? thr_rows[kk] : kk;
+	const double thr = live ? higher[d] : __builtin_nan("");          // NaN compares false: no vote
+	const double yy = ysq[d];
+	const double unit = fabs(scale) * (double) (nx + 8) * 0x1p-52;
+#pragma unroll
+	for (int b = 0; b < BT; b++) {
+		const double mm = msq[bt * BT + b];
+		const double Lf = scale * ((mm - 2.0 * acc[0][b]) + yy);
+		const double E4 = 4.0 * unit * ((mm + 2.0 * fabs(acc[0][b])) + yy);
+		const bool valid = bt * BT + b < B;
+		const unsigned long long hit = __ballot(valid && Lf > thr + E4);
+		const unsigned long long maybe = __ballot(valid && !(Lf > thr + E4) && Lf >= thr - E4);
+		if (lane == 0) {
+			if (hit != 0ull) flags[bt * BT + b] = 1;
+			else if (maybe != 0ull) ambiguous[bt * BT + b] = 1;
+		}
+	}
+}
+
+// Re-scores, with the chain kernel's own sums, the candidate tiles in which the filter left a
+// candidate ambiguous (no clear vote for it, some pair inside the guard band): sets its flag exactly
+// as k_gauss_cols_accept would.  Workgroups of all other tiles leave at once.
+template <int BT>
+__global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_resolve(
+    const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
+    double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
+    int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, int *__restrict__ flags,
+    const int *__restrict__ ambiguous)
+{
+	const int lane = threadIdx.x & 63;
+	int tile, bt;
+	if (!cols_item(ntiles, ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
+	bool any = false;
+#pragma unroll
+	for (int b = 0; b < BT; b++) any = any || (bt * BT + b < B && ambiguous[bt * BT + b] != 0);
+	if (!any) return;                                                  // wave-uniform
+	int k[1];
+	double acc[1][BT];
+	const double *mp = model_t + (size_t) bt * nxp * BT;
+	cols_accumulate<BT, 1, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
+	const bool live = k[0] < M;
+	const int kk = live ? k[0] : M - 1;
+	const double thr = live ? higher[thr_rows ? thr_rows[kk] : kk] : __builtin_nan("");
+#pragma unroll
+	for (int b = 0; b < BT; b++) {
+		const double L = acc[0][b] * scale;
+		const unsigned long long word = __ballot(L > thr);
+		if (word != 0ull && lane == 0 && bt * BT + b < B && ambiguous[bt * BT + b] != 0) flags[bt * BT + b] = 1;
+	}
+}
+
+// sum of squares of every spectrum (the filter's third sum), one thread per spectrum on the rows
+__global__ void k_row_sumsq(const double *__restrict__ Y, int ld, int nx, int ndata, double *__restrict__ out)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= ndata) return;
+	const double *yr = Y + (size_t) i * ld;
+	double acc = 0.0;
+	for (int j = 0; j < nx; j++) acc = fma(yr[j], yr[j], acc);
+	out[i] = acc;
 }
 
 // The commit when nobody wants the whole likelihood row: the first flagged candidate is THE
@@ -1081,6 +1192,53 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 	}
 #undef ACCEPT_LAUNCH
 	return launched("k_gauss_cols_accept");
+}
+
+bool launch_row_sumsq(const double *d_y, int ld, int nx, int ndata, double *d_out)
+{
+	Context *c = ctx();
+	if (ndata <= 0) return true;
+	hipLaunchKernelGGL(k_row_sumsq, dim3((ndata + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, d_y, ld, nx, ndata, d_out);
+	return launched("k_row_sumsq");
+}
+
+// whether the guarded filter pays for a chunk of B candidates over M spectra: launches the lane
+// kernel runs issue-bound (8+ candidates per wave)
+bool gauss_filter_pays(const mdns_spectra *s, int M, int B)
+{
+	static const char *forced = getenv("MDNS_K1_FILTER");                  // "0": the chain kernel decides everything (experiments)
+	if (forced && forced[0] == '0') return false;
+	return s->d_ysq != nullptr && gauss_cols_tile(M, B) >= 8;
+}
+
+// the accept pass as filter + resolve (see k_gauss_cols_filter); d_msq f64[>= B + 16] and d_amb
+// int32[>= B + 16] are scratch
+bool launch_gauss_cols_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
+                              double scale, const int *d_rows, const int *d_thr_rows, int M,
+                              const double *d_higher, int *d_flags, double *d_msq, int *d_amb)
+{
+	Context *c = ctx();
+	const int ntiles = (M + 63) / 64;
+	const int nbt = (B + bt - 1) / bt;
+	const int nxp = cols_nx(s->nx);
+	int nq_xcd, cu_slots;
+	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots, 4);
+	hipLaunchKernelGGL(k_model_sumsq, dim3(nbt * bt), dim3(64), 0, c->stream, d_model_t, nxp, bt, B, d_msq, d_amb, nbt * bt);
+	if (!launched("k_model_sumsq")) return false;
+	{
+		ProfileScope prof(0);
+		note_kernel(0, "k_gauss_cols_filter<%d>", bt);
+#define FILTER_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols_filter<BT>), dim3(blocks), dim3(256), 0, c->stream, \
+		d_yT, nxp, s->nx, d_model_t, (const double *) d_msq, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, (const double *) s->d_ysq, d_flags, d_amb)
+		if (bt == 16) FILTER_LAUNCH(16); else FILTER_LAUNCH(8);
+#undef FILTER_LAUNCH
+		if (!launched("k_gauss_cols_filter")) return false;
+	}
+#define RESOLVE_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols_resolve<BT>), dim3(blocks), dim3(256), 0, c->stream, \
+	d_yT, nxp, d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags, (const int *) d_amb)
+	if (bt == 16) RESOLVE_LAUNCH(16); else RESOLVE_LAUNCH(8);
+#undef RESOLVE_LAUNCH
+	return launched("k_gauss_cols_resolve");
 }
 
 bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,

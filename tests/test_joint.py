@@ -190,3 +190,61 @@ def test_chunk_with_no_acceptable_candidate_changes_nothing():
     idx, L, beats, n = dev.draw(sample.priortransform_batch(bad), rows)
     assert idx == -1
     dev.close()
+
+
+def test_guarded_filter_decides_like_the_chain(hip):
+    """Issue-bound chunks (256 candidates x 10 000 spectra) take the accept test as a guarded filter:
+    one FMA per (candidate, channel, spectrum) on the expanded square, a rigorous error band around
+    every threshold, and an exact re-score by the chain for whatever falls inside the band
+    (k_gauss_cols_filter / k_gauss_cols_resolve).  Its decisions must be the chain kernel's bit for bit
+    -- also when a threshold is planted EXACTLY on a candidate's chain likelihood (L > thr is false)
+    or one ulp below it (true): the cases only the resolve pass can get right."""
+    from massivedatans_amd import _lib
+    ndata, nlive, B = 10000, 100, 256
+    rng = np.random.RandomState(21)
+    data = gen.horns(ndata)
+    spectra = GaussLineSpectra(data["x"], data["y"], noise_level=0.01)
+    cube = rng.uniform(size=(B, 3))
+    xs = sample.priortransform_batch(cube)
+    params = sample.kernel_params(xs)
+    Lall = LaneScorer(spectra).loglike_batch(params)                  # the chain's values, [B, ndata]
+    best = Lall.max(axis=0)
+    who = Lall.argmax(axis=0)
+    js = jointstate.GaussJointState(spectra, nlive, sample.kernel_params, fetch_rows=False)
+    base = np.full((nlive, ndata), 0.0)
+    base[0] = best + np.abs(best) * 1e-3                               # thresholds nobody beats
+    planted = [(int(d), int(who[d])) for d in (17, 4242, 9999, 5000, 63, 64)]
+
+    def run(live):
+        _lib.check(hip.mdns_joint_set_live(js._h, _lib.ptr(np.ascontiguousarray(live))), "set_live")
+        js.prepare()
+        out = js.draw(xs, None)
+        assert (hip.mdns_profile_kernel(0) or b"").decode().startswith("k_gauss_cols_filter"), "the filter did not run"
+        return out
+
+    idx, _, beats, n = run(base)
+    assert idx == -1 and n == B
+    # thresholds exactly ON the best candidate's likelihood: still nobody (strict comparison)
+    live = base.copy()
+    for d, b in planted:
+        live[0, d] = Lall[b, d]
+    idx, _, beats, n = run(live)
+    assert idx == -1
+    # one ulp below: the first of those candidates is accepted, by exactly the planted data sets it tops
+    live = base.copy()
+    for d, b in planted:
+        live[0, d] = np.nextafter(Lall[b, d], -np.inf)
+    idx, _, beats, n = run(live)
+    first = min(b for _, b in planted)
+    assert idx == first
+    want = np.zeros(ndata, dtype=bool)
+    for d, b in planted:
+        want[d] = Lall[first, d] > live[0, d]
+    assert np.array_equal(beats, Lall[first] > live.min(axis=0)) and np.array_equal(beats, want) and beats.sum() >= 1
+    # and an ordinary chunk: thresholds in the middle of the candidates' range
+    live = base.copy()
+    live[0] = np.percentile(Lall, 99.9, axis=0)
+    idx, _, beats, n = run(live)
+    ok = (Lall > live[0]).any(axis=1)
+    assert idx == int(np.argmax(ok)) and np.array_equal(beats, Lall[idx] > live[0])
+    js.close()

@@ -24,6 +24,9 @@ python tools/chunk_bench.py classic > "$out/chunk_bench_classic.log" 2>&1
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 USE_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/e2e600_graph" -- python3 tools/e2e_run.py horns 10000 100 600 > "$out/e2e600_graph.log" 2>&1
 USE_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/e2e600" -- python3 tools/e2e_run.py horns 10000 100 600 > "$out/e2e600.log" 2>&1
+# (only 64 MiB travel back: the per-dispatch traces stay here, the --stats summaries go)
+find "$out" -name "*_kernel_trace.csv" -delete
+find "$out" -name "*.db" -delete
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY" \
@@ -31,4 +34,6 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
     i=$((i + 1))
     rocprofv3 --pmc $set --output-format csv -d "$out/k6_5000/sq$i" -- python3 tools/k6_one.py 5000 > "$out/k6_5000_sq$i.log" 2>&1 || echo "counter set $i failed"
 done
+find "$out" -name "*_kernel_trace.csv" -delete
+du -sh "$out"
 echo collected "$out"
