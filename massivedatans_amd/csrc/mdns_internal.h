@@ -114,12 +114,15 @@ bool launch_chunk_commit(const int *d_thr_rows, int M, int B, const int *d_flags
 bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
                               const double *d_higher, int *d_flags, const JointTrail &trail);
-// the accept test as guarded filter + exact resolve (mdns_like.hip, k_gauss_cols_filter): same flags as
-// launch_gauss_cols_accept, no trail
+// the accept test as guarded filter (mdns_like.hip, k_gauss_cols_filter): same flags and trail as
+// launch_gauss_cols_accept
 bool gauss_filter_pays(const mdns_spectra *s, int M, int B);
+int gauss_filter_tile(int M, int B);
+bool launch_gauss_model_tsq(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t, double *d_msq,
+                            int *d_zero, int nzero);
 bool launch_gauss_cols_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
-                              const double *d_higher, int *d_flags, double *d_msq, int *d_amb);
+                              const double *d_higher, int *d_flags, const double *d_msq, const JointTrail &trail, int *d_lowest);
 bool launch_row_sumsq(const double *d_y, int ld, int nx, int ndata, double *d_out);
 // first flagged candidate from the trail of the accept pass: fill bits, shelf appends, thresholds
 // (flag_value: what the accept pass wrote into d_flags for an accepted candidate)

@@ -347,7 +347,7 @@ struct mdns_joint {
 	// template scored with the scale-marginalised chi^2 (cmuselike.c; dense L[B, M] block)
 	int kind = 0;
 	int nparams = 3;
-	double *d_msq = nullptr;  int *d_amb = nullptr;         // scratch of the guarded accept filter (kind 0)
+	double *d_msq = nullptr;                                // templates' sums of squares (guarded accept filter, kind 0)
 	double *d_dense = nullptr;  size_t dense_cap = 0;       // L[B, M] of a chunk (kind 1)
 	double *d_jitter = nullptr;  size_t jitter_cap = 0;
 	// the draw in progress through the mdns_backend_* entry points: its selection, uploaded once
@@ -724,9 +724,13 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 		return MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kZeroInts * sizeof(int), c->stream)) ? 0 : 1;
 	}
 	const double scale = -0.5 / (noise_level * noise_level);
-	const int bt = gauss_cols_tile(M, B);
+	const bool filter = gauss_filter_pays(s, M, B);
+	const int bt = filter ? gauss_filter_tile(M, B) : gauss_cols_tile(M, B);
 	if (!ensure_model(s, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
-	if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_flags, kZeroInts)) return 1;
+	if (filter) {
+		if (!j->d_msq && !MDNS_HIP(hipMalloc((void **) &j->d_msq, (size_t) (MDNS_JOINT_MAX_BATCH + 16) * sizeof(double)))) return 1;
+		if (!launch_gauss_model_tsq(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_msq, j->d_flags, kZeroInts)) return 1;
+	} else if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_flags, kZeroInts)) return 1;
 	const double *yT = s->d_yT;
 	const int *gather = d_row_ids;
 	// a sparse selection, or many candidate tiles over a selection: first a compact replica of
@@ -738,21 +742,15 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 		yT = s->d_sel;
 		gather = nullptr;
 	}
-	if (gauss_filter_pays(s, M, B)) {
-		// issue-bound launch: the guarded filter decides (same flags, bit for bit), no trail -- the
-		// commit recomputes the accepted candidate's row with the chain
-		if (!j->d_msq) {
-			if (!MDNS_HIP(hipMalloc((void **) &j->d_msq, (size_t) (MDNS_JOINT_MAX_BATCH + 16) * (sizeof(double) + sizeof(int))))) return 1;
-			j->d_amb = (int *) (j->d_msq + MDNS_JOINT_MAX_BATCH + 16);
-		}
-		if (!launch_gauss_cols_filter(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, j->d_msq, j->d_amb)) return 1;
-		j->trail_valid = false;
-	} else {
-		JointTrail trail;
-		if (!joint_trail(j, B, M, &trail)) return 1;
-		if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, trail)) return 1;
-		j->trail_valid = true;
-	}
+	JointTrail trail;
+	if (!joint_trail(j, B, M, &trail)) return 1;
+	if (filter) {
+		// issue-bound launch: the guarded filter decides -- same flags and trail, bit for bit.  Its
+		// "lowest flagged candidate so far" lives in the header's spare word (cleared with the flags).
+		int *lowest = (int *) &((JointHeader *) j->d_result)->pad;
+		if (!launch_gauss_cols_filter(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, j->d_msq, trail, lowest)) return 1;
+	} else if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, trail)) return 1;
+	j->trail_valid = true;
 	j->last_yT = yT; j->last_gather = gather; j->last_bt = bt; j->last_B = B; j->last_scale = scale;
 	return 0;
 }

@@ -131,17 +131,36 @@ __global__ void k_gauss_model_t(const double *__restrict__ x, int nx, int nxp, c
 	model_t[e] = m;
 }
 
-// sum of squares of every candidate's template (tiled layout MT[tile][j][BT]): one wave per candidate
-__global__ __launch_bounds__(64) void k_model_sumsq(const double *__restrict__ model_t, int nxp, int bt_size, int B,
-                                                    double *__restrict__ msq, int *__restrict__ zero, int nzero)
+// k_gauss_model_t for the filter: one workgroup per candidate tile writes the tile and the sum of
+// squares of every candidate's template (deterministic: per-thread partial sums over the channels
+// 256 / BT apart, then one thread per candidate adds them in a fixed order)
+__global__ __launch_bounds__(256) void k_gauss_model_tsq(const double *__restrict__ x, int nx, int nxp, const double *__restrict__ params,
+                                                         int B, int bt_size, double *__restrict__ model_t, double *__restrict__ msq,
+                                                         int *__restrict__ zero, int nzero)
 {
-	const int b = blockIdx.x, lane = threadIdx.x;
-	for (int e = b * 64 + lane; e < nzero; e += gridDim.x * 64) zero[e] = 0;      // the filter's "ambiguous" marks
-	const double *col = model_t + (size_t) (b / bt_size) * nxp * bt_size + b % bt_size;
+	__shared__ double partial[256];
+	const int tile = blockIdx.x, t = threadIdx.x;
+	for (int e = tile * 256 + t; e < nzero; e += gridDim.x * 256) zero[e] = 0;      // accept flags + result header
+	const int bin = t % bt_size, b = tile * bt_size + bin;
+	double A = 0.0, mu = 0.0, sig = 1.0;
+	if (b < B) { A = params[3 * b]; mu = params[3 * b + 1]; sig = params[3 * b + 2]; }
 	double acc = 0.0;
-	for (int j = lane; j < nxp; j += 64) { const double m = col[(size_t) j * bt_size]; acc = fma(m, m, acc); }
-	acc = wave_sum(acc);
-	if (lane == 0) msq[b] = acc;
+	for (int j = t / bt_size; j < nxp; j += 256 / bt_size) {
+		double m = 0.0;
+		if (b < B && j < nx) {
+			const double u = (mu - x[j]) / sig;
+			m = A * exp(-0.5 * (u * u));
+		}
+		model_t[((size_t) tile * nxp + j) * bt_size + bin] = m;
+		acc = fma(m, m, acc);
+	}
+	partial[t] = acc;
+	__syncthreads();
+	if (t < bt_size) {
+		double sum = 0.0;
+		for (int q = t; q < 256; q += bt_size) sum += partial[q];
+		msq[tile * bt_size + t] = sum;
+	}
 }
 
 // three lines on a flat continuum (config C5; massivedatans_amd/gen.py muse_template)
@@ -495,6 +514,59 @@ __device__ __forceinline__ void cols_accumulate_deep(const double *__restrict__ 
 	}
 }
 
+// cols_accumulate with NB - 1 stages of spectra in flight instead of one, templates still scalar
+// operands from global memory (wave-uniform address).  With one stage of look-ahead a wave waits a
+// full memory round trip (~1.5 us) for every 8 channels: five waves per SIMD x 26 stages x 0.3 us =
+// 39 us whatever the arithmetic costs -- which is what both the add + fma kernel (31 us of issue)
+// and the FMA-only filter (16 us of issue) measured.  Same operations in the same order per
+// (candidate, spectrum): same bits.
+template <int BT, int NB, bool DOT>
+__device__ __forceinline__ void cols_accumulate_ring(const double *__restrict__ YT, int nxp,
+                                                     const double *mp,
+                                                     const int *__restrict__ rows, int M, int tile, int lane,
+                                                     int &k, double (&acc)[BT])
+{
+	constexpr int CH = 8;
+	k = tile * 64 + lane;
+	int col = k;
+	if (rows) col = rows[k < M ? k : M - 1];
+	else if (col >= ((M + 63) & ~63)) col = M - 1;
+	const double *yp = YT + ((size_t) (col >> 6) * nxp << 6) + (col & 63);
+#pragma unroll
+	for (int b = 0; b < BT; b++) acc[b] = 0.0;
+	const int nst = nxp / CH;
+	double y[NB][CH];
+#pragma unroll
+	for (int i = 0; i < NB - 1; i++) {
+		const double *p = yp + (size_t) min(i, nst - 1) * CH * 64;
+#pragma unroll
+		for (int c = 0; c < CH; c++) y[i][c] = p[c * 64];
+	}
+#pragma unroll 1
+	for (int s0 = 0; s0 < nst; s0 += NB) {
+#pragma unroll
+		for (int i = 0; i < NB; i++) {
+			const int s = s0 + i;                                // wave-uniform
+			if (s < nst) {
+				const double *p = yp + (size_t) min(s + NB - 1, nst - 1) * CH * 64;
+#pragma unroll
+				for (int c = 0; c < CH; c++) y[(i + NB - 1) % NB][c] = p[c * 64];
+				const double *m = mp + (size_t) s * CH * BT;
+#pragma unroll
+				for (int c = 0; c < CH; c++)
+#pragma unroll
+					for (int b = 0; b < BT; b++) {
+						if constexpr (DOT) acc[b] = fma(m[c * BT + b], y[i][c], acc[b]);
+						else {
+							const double d = m[c * BT + b] - y[i][c];
+							acc[b] = fma(d, d, acc[b]);
+						}
+					}
+			}
+		}
+	}
+}
+
 // copies n template values from global memory (stride `stride` doubles apart) into LDS, all of a
 // thread's loads in flight at once; ends with the workgroup barrier
 __device__ __forceinline__ void stage_templates(double *__restrict__ dst, const double *__restrict__ src, int n, int stride)
@@ -597,16 +669,17 @@ __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_accept(
 //     |Lf - L| <= |scale| (nx + 8) 2^-52 (msq + 2 |sum m y| + ysq) =: E     (forward error of three
 //     sums of nx terms and their combination, and of the chain itself)
 // so  Lf > thr + 4 E  implies  L > thr  (flag the candidate: exactly the decision of the chain
-// kernel) and  Lf < thr - 4 E  implies  L <= thr  (no vote).  Anything in between -- one pair in
-// ~10^9 -- marks the candidate AMBIGUOUS and k_gauss_cols_resolve re-scores its tile with the chain
-// kernel's own sums.  Decisions therefore equal those of k_gauss_cols_accept bit for bit; the
-// likelihoods that are KEPT (shelves) always come from the chain (k_gauss_cols_commit).
+// kernel) and  Lf < thr - 4 E  implies  L <= thr  (no vote).  For anything in between -- one pair in
+// ~10^9 -- and for a candidate with a clear vote that may be THE accepted one (no lower candidate
+// flagged yet) the wave computes the chain's own sums for that one candidate on its tile (1/BT of a
+// chain pass, rare) and votes / leaves the trail exactly as k_gauss_cols_accept does.  Flags, the
+// accepted index and every likelihood that is KEPT therefore equal the chain kernel's bit for bit.
 template <int BT>
 __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_filter(
     const double *__restrict__ YT, int nxp, int nx, const double *__restrict__ model_t, const double *__restrict__ msq, int B,
     double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
     int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, const double *__restrict__ ysq,
-    int *__restrict__ flags, int *__restrict__ ambiguous)
+    int *__restrict__ flags, JointTrail trail, int *__restrict__ lowest)
 {
 	const int lane = threadIdx.x & 63;
 	int tile, bt;
@@ -621,50 +694,45 @@ __global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_filter(
 	const double thr = live ? higher[d] : __builtin_nan("");          // NaN compares false: no vote
 	const double yy = ysq[d];
 	const double unit = fabs(scale) * (double) (nx + 8) * 0x1p-52;
+	unsigned hits = 0, maybes = 0;                                     // wave-uniform: one bit per candidate of the tile
 #pragma unroll
 	for (int b = 0; b < BT; b++) {
-		const double mm = msq[bt * BT + b];
+		const int cand = bt * BT + b;
+		const double mm = msq[cand];
 		const double Lf = scale * ((mm - 2.0 * acc[0][b]) + yy);
 		const double E4 = 4.0 * unit * ((mm + 2.0 * fabs(acc[0][b])) + yy);
-		const bool valid = bt * BT + b < B;
-		const unsigned long long hit = __ballot(valid && Lf > thr + E4);
-		const unsigned long long maybe = __ballot(valid && !(Lf > thr + E4) && Lf >= thr - E4);
-		if (lane == 0) {
-			if (hit != 0ull) flags[bt * BT + b] = 1;
-			else if (maybe != 0ull) ambiguous[bt * BT + b] = 1;
-		}
+		const bool valid = cand < B;
+		if (__ballot(valid && Lf > thr + E4) != 0ull) hits |= 1u << b;
+		else if (__ballot(valid && Lf >= thr - E4) != 0ull) maybes |= 1u << b;
 	}
-}
-
-// Re-scores, with the chain kernel's own sums, the candidate tiles in which the filter left a
-// candidate ambiguous (no clear vote for it, some pair inside the guard band): sets its flag exactly
-// as k_gauss_cols_accept would.  Workgroups of all other tiles leave at once.
-template <int BT>
-__global__ __launch_bounds__(2 * kBlock) void k_gauss_cols_resolve(
-    const double *__restrict__ YT, int nxp, const double *__restrict__ model_t, int B,
-    double scale, const int *__restrict__ rows, const int *__restrict__ thr_rows, int M,
-    int ntiles, int nq_xcd, int nbt, int cu_slots, const double *__restrict__ higher, int *__restrict__ flags,
-    const int *__restrict__ ambiguous)
-{
-	const int lane = threadIdx.x & 63;
-	int tile, bt;
-	if (!cols_item(ntiles, ntiles, nq_xcd, nbt, cu_slots, tile, bt)) return;
-	bool any = false;
-#pragma unroll
-	for (int b = 0; b < BT; b++) any = any || (bt * BT + b < B && ambiguous[bt * BT + b] != 0);
-	if (!any) return;                                                  // wave-uniform
-	int k[1];
-	double acc[1][BT];
-	const double *mp = model_t + (size_t) bt * nxp * BT;
-	cols_accumulate<BT, 1, false>(YT, nxp, mp, BT, rows, M, tile, lane, k, acc);
-	const bool live = k[0] < M;
-	const int kk = live ? k[0] : M - 1;
-	const double thr = live ? higher[thr_rows ? thr_rows[kk] : kk] : __builtin_nan("");
-#pragma unroll
-	for (int b = 0; b < BT; b++) {
-		const double L = acc[0][b] * scale;
+	// the rule: nobody accepts any candidate of the tile and the wave is done.  Otherwise, candidate
+	// by candidate (a rolled loop: the chain pass is inlined ONCE):
+	unsigned todo = hits | maybes;
+#pragma unroll 1
+	while (todo) {
+		const int b = __builtin_ctz(todo);
+		todo &= todo - 1;
+		const int cand = bt * BT + b;
+		// `lowest` holds B - (lowest candidate index flagged so far), 0 = none (atomicMax): a candidate
+		// above it cannot be the accepted one, so a clear vote for it needs no likelihoods
+		const int seen = B - __hip_atomic_load(lowest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if ((hits >> b & 1u) && cand > seen) { if (lane == 0) flags[cand] = 1; continue; }
+		// the chain's own sums for this candidate on this tile: the decision inside the band, and
+		// the likelihoods the commit pass wants (the trail) for a candidate that may be THE one
+		int k1[1];
+		double a1[1][1];
+		cols_accumulate<1, 1, true>(YT, nxp, mp + b, BT, rows, M, tile, lane, k1, a1);
+		const double L = a1[0][0] * scale;
 		const unsigned long long word = __ballot(L > thr);
-		if (word != 0ull && lane == 0 && bt * BT + b < B && ambiguous[bt * BT + b] != 0) flags[bt * BT + b] = 1;
+		if (word != 0ull) {
+			const size_t at = (size_t) cand * ntiles + tile;
+			if (trail.stamp_of) trail.L[at * 64 + lane] = L;
+			if (lane == 0) {
+				flags[cand] = 1;
+				atomicMax(lowest, B - cand);
+				if (trail.stamp_of) { trail.word[at] = word; trail.stamp_of[at] = trail.stamp; }
+			}
+		}
 	}
 }
 
@@ -1206,16 +1274,46 @@ bool launch_row_sumsq(const double *d_y, int ld, int nx, int ndata, double *d_ou
 // kernel runs issue-bound (8+ candidates per wave)
 bool gauss_filter_pays(const mdns_spectra *s, int M, int B)
 {
-	static const char *forced = getenv("MDNS_K1_FILTER");                  // "0": the chain kernel decides everything (experiments)
-	if (forced && forced[0] == '0') return false;
+	// MDNS_K1_FILTER=1 turns it on.  Off by default: the vector-FMA form measured here gains little --
+	// 33.9 us against 41-43 at 10 000 x 256 (rocprofv3), because the kernel is bound by the delivery of
+	// its scalar template operands, not by issue (SQ counters: VALU active 49 %, waves 65 % of their
+	// time in s_waitcnt) -- and the chain sub-pass of the accepted candidate (one wave-length of
+	// latency-bound loads at the END of its waves) gives the gain back: 57 us.
+	static const char *forced = getenv("MDNS_K1_FILTER");
+	if (!forced || forced[0] != '1') return false;
 	return s->d_ysq != nullptr && gauss_cols_tile(M, B) >= 8;
 }
 
-// the accept pass as filter + resolve (see k_gauss_cols_filter); d_msq f64[>= B + 16] and d_amb
-// int32[>= B + 16] are scratch
+// candidates per wave of the filter: with ONE vector instruction per (candidate, channel, spectrum)
+// a wave of 8 candidates asks the L1 for 4 KB of spectra per 64 instructions -- 64 B per clock and
+// CU, all the L1 delivers (measured: 39.6 us at 10 000 x 256, hardly better than the 45 of the
+// add + fma kernel) -- so 16 wherever that still leaves two waves per SIMD
+int gauss_filter_tile(int M, int B)
+{
+	Context *c = ctx();
+	static const char *forced = getenv("MDNS_K1_FILTER_BT");               // experiments only
+	if (forced && (atoi(forced) == 8 || atoi(forced) == 16)) return atoi(forced);
+	const long long waves = (long long) ((M + 63) / 64) * ((B + 15) / 16);
+	return waves >= 2LL * 4 * c->num_cus ? 16 : 8;
+}
+
+// templates + their sums of squares for the filter (also clears d_zero[0 .. nzero))
+bool launch_gauss_model_tsq(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t, double *d_msq,
+                            int *d_zero, int nzero)
+{
+	Context *c = ctx();
+	const int ntile = (B + bt - 1) / bt;
+	hipLaunchKernelGGL(k_gauss_model_tsq, dim3(ntile), dim3(256), 0, c->stream, d_x, nx, cols_nx(nx), d_params, B, bt, d_model_t, d_msq,
+	                   d_zero, d_zero ? nzero : 0);
+	return launched("k_gauss_model_tsq");
+}
+
+// the accept pass as guarded filter (see k_gauss_cols_filter): same flags and trail as
+// launch_gauss_cols_accept; d_msq f64[>= B + 16] from launch_gauss_model_tsq; d_lowest: an int the
+// template kernel cleared
 bool launch_gauss_cols_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
-                              const double *d_higher, int *d_flags, double *d_msq, int *d_amb)
+                              const double *d_higher, int *d_flags, const double *d_msq, const JointTrail &trail, int *d_lowest)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
@@ -1223,22 +1321,13 @@ bool launch_gauss_cols_filter(const mdns_spectra *s, const double *d_yT, const d
 	const int nxp = cols_nx(s->nx);
 	int nq_xcd, cu_slots;
 	const int blocks = cols_grid(c, ntiles, nbt, nq_xcd, cu_slots, 4);
-	hipLaunchKernelGGL(k_model_sumsq, dim3(nbt * bt), dim3(64), 0, c->stream, d_model_t, nxp, bt, B, d_msq, d_amb, nbt * bt);
-	if (!launched("k_model_sumsq")) return false;
-	{
-		ProfileScope prof(0);
-		note_kernel(0, "k_gauss_cols_filter<%d>", bt);
+	ProfileScope prof(0);
+	note_kernel(0, "k_gauss_cols_filter<%d>", bt);
 #define FILTER_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols_filter<BT>), dim3(blocks), dim3(256), 0, c->stream, \
-		d_yT, nxp, s->nx, d_model_t, (const double *) d_msq, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, (const double *) s->d_ysq, d_flags, d_amb)
-		if (bt == 16) FILTER_LAUNCH(16); else FILTER_LAUNCH(8);
+	d_yT, nxp, s->nx, d_model_t, d_msq, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, (const double *) s->d_ysq, d_flags, trail, d_lowest)
+	if (bt == 16) FILTER_LAUNCH(16); else FILTER_LAUNCH(8);
 #undef FILTER_LAUNCH
-		if (!launched("k_gauss_cols_filter")) return false;
-	}
-#define RESOLVE_LAUNCH(BT) hipLaunchKernelGGL((k_gauss_cols_resolve<BT>), dim3(blocks), dim3(256), 0, c->stream, \
-	d_yT, nxp, d_model_t, B, scale, d_rows, d_thr_rows, M, ntiles, nq_xcd, nbt, cu_slots, d_higher, d_flags, (const int *) d_amb)
-	if (bt == 16) RESOLVE_LAUNCH(16); else RESOLVE_LAUNCH(8);
-#undef RESOLVE_LAUNCH
-	return launched("k_gauss_cols_resolve");
+	return launched("k_gauss_cols_filter");
 }
 
 bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,

@@ -192,7 +192,7 @@ def test_chunk_with_no_acceptable_candidate_changes_nothing():
     dev.close()
 
 
-def test_guarded_filter_decides_like_the_chain(hip):
+def test_guarded_filter_decides_like_the_chain(hip, monkeypatch):
     """Issue-bound chunks (256 candidates x 10 000 spectra) take the accept test as a guarded filter:
     one FMA per (candidate, channel, spectrum) on the expanded square, a rigorous error band around
     every threshold, and an exact re-score by the chain for whatever falls inside the band
@@ -200,6 +200,14 @@ def test_guarded_filter_decides_like_the_chain(hip):
     -- also when a threshold is planted EXACTLY on a candidate's chain likelihood (L > thr is false)
     or one ulp below it (true): the cases only the resolve pass can get right."""
     from massivedatans_amd import _lib
+    import subprocess, sys, os
+    if os.environ.get("MDNS_K1_FILTER") != "1":
+        # the library reads the switch once per process: run this test in a child with the filter on
+        env = dict(os.environ, MDNS_K1_FILTER="1")
+        out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "gpu",
+                              __file__ + "::test_guarded_filter_decides_like_the_chain"], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+        return
     ndata, nlive, B = 10000, 100, 256
     rng = np.random.RandomState(21)
     data = gen.horns(ndata)
