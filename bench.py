@@ -556,7 +556,12 @@ def bench_gauss(args):
     if rank == 0:
         evals_per_step = B * nd * world
         value = evals_per_step * args.steps / elapsed
-        flops = 3.0 * nx * B * nd                         # per launch: subtract, multiply, add
+        mfma = kernel.startswith("k_gauss_mfma_filter")
+        # per launch.  Chain kernels: subtract, multiply, add per (channel, candidate, spectrum).  The
+        # matrix-core filter EXECUTES one multiply-add per element (the cross term of the expanded
+        # square): `achieved` counts those 2 flops; the 3 flops of the reference's formula that they
+        # stand for are reported beside it, never as the roofline fraction.
+        flops = (2.0 if mfma else 3.0) * nx * B * nd
         tflops = flops / (k1_us * 1e-6) / 1e12 if k1_us > 0 else 0.0
         alg_bytes = (8 * nx + 8) * B * nd                 # 1608 B per eval
         phys_bytes = 8 * nx * nd + 8 * nd + 8 * B * nx    # spectra once + thresholds + templates; flags
@@ -578,15 +583,21 @@ def bench_gauss(args):
                                        "per step: pool all-gather, MAX all-reduce of the accept flags, fill-bit all-gather; "
                                        + ("RCCL called directly on the kernels' stream" if direct is not None
                                           else "torch.distributed (nccl)"))},
-            "roofline": {"bound": "fp64_valu", "kernel": kernel, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
+            "roofline": {"bound": "mfma" if mfma else "fp64_valu", "kernel": kernel, "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": tflops / FP64_VALU_PEAK_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "launch_us": k1_us, "launches_timed": n_launch,
                          "flops_per_launch": flops,
-                         "note": "B candidates are scored per pass over the spectra, so every spectrum byte is used B "
-                                 "times and the kernel is bound by fp64 vector issue (v_add_f64 + v_fma_f64 per "
-                                 "candidate, channel and spectrum: at most 0.75 of the FMA peak), not by HBM; "
-                                 "flops = 3 x channels x candidates x spectra",
+                         "note": ("guarded accept filter on the matrix cores: the cross term of the expanded square as "
+                                  "v_mfma_f64_16x16x4_f64 (fp64 matrix peak = fp64 vector peak on gfx950: 78.6 TFLOP/s; the "
+                                  "instruction alone sustains 69.7, tools/probes/mfma_f64_probe.hip), decisions identical to "
+                                  "the chain kernel's (k_exact_list re-scores what the error band cannot settle); flops = 2 x "
+                                  "channels x candidates x spectra EXECUTED; in the reference's 3 flops per element the same "
+                                  "launch is %.1f TFLOP/s" % (1.5 * tflops)) if mfma else
+                                 ("B candidates are scored per pass over the spectra, so every spectrum byte is used B "
+                                  "times and the kernel is bound by fp64 vector issue (v_add_f64 + v_fma_f64 per "
+                                  "candidate, channel and spectrum: at most 0.75 of the FMA peak), not by HBM; "
+                                  "flops = 3 x channels x candidates x spectra"),
                          "hbm": {"algorithmic_bytes_per_launch": alg_bytes,
                                  "frac_effective": (alg_bytes / (k1_us * 1e-6) / 1e9) / HBM_PEAK_GBS if k1_us > 0 else 0.0,
                                  "physical_bytes_per_launch": phys_bytes,

@@ -199,6 +199,288 @@ __global__ __launch_bounds__(1024) void k_chunk_commit(
 	__hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// ---------------------------------------------------------------------------------------
+// The accept test of an issue-bound chunk (hundreds of candidates x thousands of spectra) as a
+// GUARDED FILTER ON THE MATRIX CORES.
+//
+// sum_j (m_bj - y_ij)^2 = sum_j m_bj^2 - 2 sum_j m_bj y_ij + sum_j y_ij^2.  The first sum belongs to the
+// candidate (`msq`, from the template kernel), the last one to the spectrum (`ysq`, computed at
+// upload); the middle one is a matrix product [candidates x channels] . [channels x spectra] -- the
+// one piece of this hot path that IS GEMM-shaped -- and runs as v_mfma_f64_16x16x4_f64: a wave owns
+// 16 candidates x 64 spectra, both operands arrive as plain coalesced vector loads (the vector-FMA
+// form of the same sum was bound by the delivery of its scalar template operands: SQ counters in
+// profiles/), 1024 multiply-adds per instruction.
+// The filtered value Lf = scale (msq - 2 S + ysq) is NOT the chain value L the library works with
+// (the expanded form cancels), but  |Lf - L| <= E := |scale| (nx + 8) 2^-52 (msq + 2 |S| + ysq)  (forward
+// error of three sums of nx terms in any order with fused multiply-adds, of their combination, and
+// of the chain itself: (3 nx + 6) u against the (2 nx + 16) u of E, and 4 E is what is used).  So
+// Lf > thr + 4 E  implies  L > thr  -- a CLEAR vote: the candidate is flagged, exactly the decision
+// of the chain kernel -- and  Lf < thr - 4 E  implies  L <= thr.  A candidate with a pair in between
+// (about one pair in 10^9) and no clear vote is AMBIGUOUS.  k_exact_list then lists the ambiguous
+// candidates below the lowest clear one and that one itself, and scores the listed candidates
+// with the chain (votes, and the trail of likelihoods the commit pass keeps).  Flags,
+// accepted index and every likelihood that is KEPT are therefore the chain kernel's, bit for bit.
+// ---------------------------------------------------------------------------------------
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+// lane l holds A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16], D[i = 4 v + l / 16][j = l % 16] in
+// its v-th result (tools/probes/mfma_f64_probe.hip checks this on the hardware).
+//
+// A workgroup (4 waves) owns one tile of SPEC spectra and FOUR tiles of 16 candidates, one per wave.
+// The spectra -- 16 MB at 10 000 x 200, against 0.4 MB of templates -- arrive from L2 once per
+// workgroup: chunks of CHUNK channels x SPEC spectra (rows of the tiled replica) are
+// staged through LDS, two chunks ahead, and every wave feeds its MFMAs from there; its own
+// templates come straight from global memory (512 B per k-step, coalesced).  Workgroups of the same
+// spectrum tile run on the same XCD (blockIdx % 8), so the tile also reaches that L2 only once.
+template <int SPEC, int CHUNK, int DEPTH, int PROBE>
+__global__ __launch_bounds__(256) void k_gauss_mfma_filter(
+    const double *__restrict__ YT, int nxp, int nx, const double *__restrict__ model_t, const double *__restrict__ msq, int B,
+    double scale, const int *__restrict__ thr_rows, int M, int ntiles, int nbt, int ngroups,
+    const double *__restrict__ higher, const double *__restrict__ ysq, int *__restrict__ flags, int *__restrict__ ambiguous,
+    int stamp, int *__restrict__ lowest)
+{
+	constexpr int NB = SPEC / 16;                                         // 16-spectrum blocks per wave: MFMAs per k-step
+	constexpr int kRow2 = SPEC / 2;                                       // 16-byte pieces per channel row
+	constexpr int kPieces = CHUNK * kRow2 / 256;                          // per thread and chunk
+	constexpr int kRowsPerPass = 256 / kRow2;
+	static_assert(kPieces * 256 == CHUNK * kRow2, "chunk");
+	constexpr int kSteps = CHUNK / 4;
+	__shared__ __attribute__((aligned(16))) double stage[DEPTH + 1][CHUNK * SPEC];
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+	const int tile = (local / ngroups) * 8 + xcd, grp = local - (local / ngroups) * ngroups;       // tiles of SPEC spectra
+	if (tile >= ntiles) return;                                           // whole workgroups
+	const int bt = grp * 4 + wave;
+	const bool working = bt < nbt;                                        // wave-uniform; an idle wave still stages
+	const int kq = lane >> 4, jq = lane & 15;
+	const double *ap = model_t + (size_t) (working ? bt : 0) * nxp * 16 + lane;     // A of k-step c: ap[c * 64]
+	// this thread's pieces of a chunk: channel rows (threadIdx / kRow2) + i kRowsPerPass, 16 bytes at (threadIdx % kRow2)
+	const int first = tile * SPEC;                                        // first spectrum
+	const int prow = threadIdx.x / kRow2, pcol = threadIdx.x % kRow2;
+	const double2 *src = reinterpret_cast<const double2 *>(YT + ((size_t) (first >> 6) * nxp << 6) + (first & 63)) + (size_t) prow * 32 + pcol;
+	// DEPTH + 1 register sets and LDS stages, used in rotation (the chunk loop is unrolled by that many
+	// so that every set is named at compile time -- a copy between sets would wait for the loads):
+	// while chunk c is multiplied, chunk c + 1 is on its way into LDS and, at DEPTH 2, the loads of
+	// chunk c + 2 are in flight.
+	double2 piece[DEPTH + 1][kPieces];
+	double a[DEPTH + 1][kSteps];
+	double4_t acc[NB];
+#pragma unroll
+	for (int t = 0; t < NB; t++) acc[t] = double4_t{0, 0, 0, 0};
+	const int nchunks = (nxp + CHUNK - 1) / CHUNK;
+	const int nk = nxp / 4;
+	// (loads are unconditional and nothing looks at their results before the stage that needs them
+	// -- a chunk number past the end fetches the last chunk again, a channel past the end the last
+	// row, which is written to LDS as zeros, and a k-step past the end the last templates, which
+	// then meet those zeros -- so that the compiler can COUNT the loads in flight: behind a branch, or
+	// with a select on the loaded value, it waits for all of them, vmcnt(0), and the second chunk in
+	// flight buys nothing)
+#define FILTER_FETCH(SET, CHUNK_NO) { \
+	const int cn_ = (CHUNK_NO) < nchunks ? (CHUNK_NO) : nchunks - 1; \
+	_Pragma("unroll") for (int i = 0; i < kPieces; i++) { \
+		const int ch = cn_ * CHUNK + prow + i * kRowsPerPass; \
+		piece[SET][i] = src[(size_t) ((ch < nxp ? ch : nxp - 1) - prow) * 32]; \
+	} \
+	_Pragma("unroll") for (int i = 0; i < kSteps; i++) { \
+		const int k = cn_ * kSteps + i; \
+		a[SET][i] = ap[(size_t) (k < nk ? k : nk - 1) * 64]; \
+	} }
+#define FILTER_STAGE(SET, CHUNK_NO) { \
+	const int cn_ = (CHUNK_NO) < nchunks ? (CHUNK_NO) : nchunks - 1; \
+	_Pragma("unroll") for (int i = 0; i < kPieces; i++) { \
+		const bool inside = cn_ * CHUNK + prow + i * kRowsPerPass < nxp; \
+		double2 v = piece[SET][i]; \
+		v.x = inside ? v.x : 0.0; v.y = inside ? v.y : 0.0; \
+		reinterpret_cast<double2 *>(stage[SET])[i * 256 + threadIdx.x] = v; \
+	} }
+	// the B operands of a k-step are read from LDS one k-step ahead of the MFMAs that use them
+#define FILTER_BODY(R, R1, RF, CHUNK_NO) { \
+	const int c_ = (CHUNK_NO); \
+	if (PROBE != 2 && PROBE != 3) FILTER_FETCH(RF, c_ + DEPTH) \
+	if (working && c_ < nchunks && PROBE != 1) { \
+		const double *cur = stage[R]; \
+		double b[2][NB]; \
+		_Pragma("unroll") for (int t = 0; t < NB; t++) b[0][t] = cur[kq * SPEC + jq + 16 * t]; \
+		_Pragma("unroll") for (int i = 0; i < kSteps; i++) { \
+			if (i + 1 < kSteps) { \
+				_Pragma("unroll") for (int t = 0; t < NB; t++) b[(i + 1) & 1][t] = cur[((i + 1) * 4 + kq) * SPEC + jq + 16 * t]; \
+			} \
+			_Pragma("unroll") for (int t = 0; t < NB; t++) \
+				acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[R][i], PROBE == 3 ? a[R][(i + t + 1) % kSteps] : b[i & 1][t], acc[t], 0, 0, 0); \
+		} \
+	} \
+	if (PROBE != 2 && PROBE != 3) FILTER_STAGE(R1, c_ + 1) \
+	__syncthreads(); }
+	FILTER_FETCH(0, 0)
+	if (DEPTH == 2) FILTER_FETCH(1, 1)
+	FILTER_STAGE(0, 0)
+	__syncthreads();
+	// (whole rounds of the register sets: past the last chunk a body still fetches, stages and meets
+	// the barrier -- straight-line memory operations keep the load counts exact -- but multiplies nothing)
+	if (DEPTH == 2) {
+#pragma unroll 1
+		for (int c = 0; c < nchunks; c += 3) {
+			FILTER_BODY(0, 1, 2, c)
+			FILTER_BODY(1, 2 % (DEPTH + 1), 0, c + 1)
+			FILTER_BODY(2 % (DEPTH + 1), 0, 1, c + 2)
+		}
+	} else {
+#pragma unroll 1
+		for (int c = 0; c < nchunks; c += 2) {
+			FILTER_BODY(0, 1, 1, c)
+			FILTER_BODY(1, 0, 0, c + 1)
+		}
+	}
+#undef FILTER_BODY
+#undef FILTER_STAGE
+#undef FILTER_FETCH
+	if (!working) return;
+	if (PROBE == 3) { double sum = 0.0; for (int t = 0; t < NB; t++) sum += acc[t][t]; if (sum == 12345.678) flags[0] = 1; return; }
+	// votes: lane (kq, jq) holds, of block t, candidates 4 v + kq (v = 0..3) for spectrum 16 t + jq
+	const double unit = fabs(scale) * (double) (nx + 8) * 0x1p-52;
+	double mm[4];
+#pragma unroll
+	for (int v = 0; v < 4; v++) mm[v] = msq[bt * 16 + 4 * v + kq];
+	bool hit[4] = {false, false, false, false}, maybe[4] = {false, false, false, false};
+#pragma unroll
+	for (int t = 0; t < NB; t++) {
+		const int k = first + 16 * t + jq;
+		const bool live = k < M;
+		const int kk = live ? k : M - 1;
+		const int d = thr_rows ? thr_rows[kk] : kk;
+		const double thr = live ? higher[d] : __builtin_nan("");       // NaN compares false: no vote
+		const double yy = ysq[d];
+#pragma unroll
+		for (int v = 0; v < 4; v++) {
+			const double S = acc[t][v];
+			const double Lf = scale * ((mm[v] - 2.0 * S) + yy);
+			const double E4 = 4.0 * unit * ((mm[v] + 2.0 * fabs(S)) + yy);
+			const bool valid = bt * 16 + 4 * v + kq < B;
+			const bool h = valid && Lf > thr + E4;
+			hit[v] = hit[v] || h;
+			maybe[v] = maybe[v] || (valid && !h && Lf >= thr - E4);
+		}
+	}
+	int best = 0x7fffffff;                                                // lowest clearly accepted candidate of this wave
+#pragma unroll
+	for (int v = 0; v < 4; v++) {
+		const unsigned long long hm = __ballot(hit[v]), mb = __ballot(maybe[v]);
+		if (lane == 0) {
+#pragma unroll
+			for (int g = 0; g < 4; g++) {
+				const int cand = bt * 16 + 4 * v + g;
+				if ((hm >> (16 * g)) & 0xffffull) { flags[cand] = 1; best = cand < best ? cand : best; }
+				else if ((mb >> (16 * g)) & 0xffffull) ambiguous[cand] = stamp;    // (never cleared: stamped with the call)
+			}
+		}
+	}
+	if (lane == 0 && best != 0x7fffffff) atomicMax(lowest, B - best);
+}
+
+// The chain's own sums for the candidates the filter could not settle -- the ambiguous ones below
+// the lowest clear vote -- and for that one itself (its likelihoods are wanted): votes (flags) and
+// the trail of likelihoods, exactly as the chain accept kernels leave them.  Every workgroup (one
+// tile of 64 spectra) first lists those candidates (a few hundred flags: cheaper than a launch of
+// its own), then scores them four at a time in the layout of k_chunk_accept: a quad of lanes shares
+// one spectrum row and scores four listed candidates.
+static constexpr int kExactMost = 64;
+template <int NST>
+__global__ __launch_bounds__(256) void k_exact_list(
+    const double *__restrict__ Y, int ld, int nxp, const double *__restrict__ model_t, double scale,
+    const int *__restrict__ rows, int M, int ntiles, const double *__restrict__ higher, int B,
+    const int *__restrict__ ambiguous, int stamp, const int *__restrict__ lowest, int *__restrict__ flags, JointTrail trail,
+    JointHeader *__restrict__ header)
+{
+	extern __shared__ __attribute__((aligned(16))) double lds[];
+	double2 *tpl = reinterpret_cast<double2 *>(lds);                     // [nxp / 2][4] pairs of channels
+	unsigned long long *votes = reinterpret_cast<unsigned long long *>(lds + (size_t) nxp * 4);
+	__shared__ int list[kExactMost];
+	__shared__ int s_n;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	if (wave == 0) {
+		const int low = *lowest > 0 ? B - *lowest : B;                  // lowest clearly accepted candidate, or B
+		int n = 0;
+		for (int b0 = 0; b0 < B && b0 <= low; b0 += 64) {
+			const int b = b0 + lane;
+			// (below `low` nobody has a clear vote; flags are not read here: other workgroups of this launch write them)
+			const bool take = b < B && ((b < low && ambiguous[b] == stamp) || b == low);
+			const unsigned long long m = __ballot(take);
+			if (take) {
+				const int at = n + __popcll(m & ((1ull << lane) - 1ull));
+				if (at < kExactMost) list[at] = b;
+			}
+			n += __popcll(m);
+		}
+		if (lane == 0) {
+			s_n = n < kExactMost ? n : kExactMost;
+			// more ambiguous candidates than the list holds: never seen; the chunk fails loudly
+			if (n > kExactMost && blockIdx.x == 0) atomicOr(&header->status, 2);
+		}
+	}
+	__syncthreads();
+	const int n = s_n;
+	if (n == 0) return;
+	const int q = lane & 3;
+	const int tile = blockIdx.x;
+	const int r = wave * 16 + (lane >> 2);
+	const int k = tile * 64 + r;
+	const bool live = k < M;
+	const int kk = live ? k : M - 1;
+	const int row = rows ? rows[kk] : kk;
+	const double *yr = Y + (size_t) row * ld;
+	const int nst = nxp / kCH;
+	double2 y[NST];
+#pragma unroll
+	for (int s = 0; s < NST; s++) {
+		const int j = s * kCH + 2 * q;
+		const double2 v = *reinterpret_cast<const double2 *>(yr + (j < ld ? j : 0));
+		y[s].x = j < ld ? v.x : 0.0;
+		y[s].y = j < ld ? v.y : 0.0;
+	}
+	const double thr = live ? higher[row] : __builtin_nan("");
+	for (int g = 0; g < n; g += 4) {
+		const int mine = g + q < n ? list[g + q] : -1;
+		// the listed candidates' template columns (tiled templates MT[tile16][channel][16]) into LDS
+		for (int e = threadIdx.x; e < nxp * 4; e += 256) {
+			const int j = e >> 2, bb = e & 3;
+			const int c = g + bb < n ? list[g + bb] : -1;
+			const double m = c >= 0 ? model_t[((size_t) (c >> 4) * nxp + j) * 16 + (c & 15)] : 0.0;
+			lds[((size_t) (j >> 1) * 4 + bb) * 2 + (j & 1)] = m;
+		}
+		__syncthreads();
+		double acc = 0.0;
+#pragma unroll
+		for (int s = 0; s < NST; s++) {
+			if (s < nst) {
+				const double2 *m = tpl + (size_t) s * 16 + q;
+				double d;
+#define QUARTER(QQ) { const double2 mv = m[QQ * 4]; \
+				d = mv.x - quad_bcast<QQ>(y[s].x); acc = fma(d, d, acc); \
+				d = mv.y - quad_bcast<QQ>(y[s].y); acc = fma(d, d, acc); }
+				QUARTER(0) QUARTER(1) QUARTER(2) QUARTER(3)
+#undef QUARTER
+			}
+		}
+		const double L = acc * scale;
+		const bool beat = mine >= 0 && L > thr;
+		const unsigned long long vote = __ballot(beat);
+		if (lane == 0) votes[wave] = vote;
+		if (beat) trail.L[((size_t) mine * ntiles + tile) * 64 + r] = L;
+		__syncthreads();
+		{
+			const int c = g + wave < n ? list[g + wave] : -1;
+			const unsigned long long word = __ballot((votes[lane >> 4] >> (4 * (lane & 15) + wave)) & 1ull);
+			if (c >= 0 && word != 0ull && lane == 0) {
+				const size_t at = (size_t) c * ntiles + tile;
+				flags[c] = 1;
+				trail.word[at] = word;
+				trail.stamp_of[at] = trail.stamp;
+			}
+		}
+		__syncthreads();
+	}
+}
+
 static bool launched(const char *name)
 {
 	hipError_t e = hipGetLastError();
@@ -253,6 +535,58 @@ bool launch_chunk_commit(const int *d_thr_rows, int M, int B, const int *d_flags
 	hipLaunchKernelGGL(k_chunk_commit, dim3(1), dim3(1024), 0, c->stream, d_thr_rows, M, B, ntiles, d_flags, stamp, trail, st,
 	                   (JointHeader *) d_header, d_fillbits, (ChunkMailbox *) box_dev, seq);
 	return launched("k_chunk_commit");
+}
+
+// the accept pass of an issue-bound chunk on the matrix cores (see k_gauss_mfma_filter): the same
+// flags and trail as launch_gauss_cols_accept.  d_yT: the tiled replica of exactly the M spectra
+// scored (no column gather); d_model_t must be tiled 16 candidates wide, d_msq
+// from launch_gauss_model_tsq; d_scratch int32[MDNS_JOINT_MAX_BATCH + 16], zeroed once (ambiguous
+// marks, stamped with the trail's stamp); d_lowest: an int the template kernel cleared.
+bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int B, double scale,
+                              const int *d_thr_rows, int M, const double *d_higher, int *d_flags,
+                              const double *d_msq, const JointTrail &trail, int *d_lowest, int *d_scratch, void *d_header)
+{
+	Context *c = ctx();
+	const int ntiles = (M + 63) / 64, nbt = (B + 15) / 16;
+	const int nxp = cols_nx(s->nx);
+	int *d_amb = d_scratch;
+	{
+		// Tiles of 32 spectra, chunks of 32 channels, one chunk ahead (100 VGPRs, 16 KB of LDS).  Measured
+		// at 10 000 x 256 (rocprofv3, us): 64 spectra x 40 channels 30.3-32.4; 32 x 32 29-32; two chunks
+		// ahead 36.9 (132 VGPRs: three waves per SIMD instead of four or five -- this kernel wants
+		// independent workgroups around its barriers more than it wants distance to its loads; with the
+		// L2s flushed between launches it takes the same 31); 16-channel chunks 30-31.
+		// MDNS_FILTER_PROBE (experiments; results are wrong): 1 no MFMAs 12.8, 2 no loads after the first
+		// chunk 26.5, 3 MFMAs on registers only 23.5 -- against 14.8 for the 502 400 MFMAs at the rate the
+		// instruction sustains alone (69.7 TFLOP/s) on perfectly balanced SIMDs.
+		static const char *probe = getenv("MDNS_FILTER_PROBE");
+		const int pr = probe ? atoi(probe) : 0;
+		const int nspec = (M + 31) / 32;
+		const int ngroups = (nbt + 3) / 4;
+		const int blocks = 8 * ((nspec + 7) / 8) * ngroups;
+		ProfileScope prof(0);
+		note_kernel(0, "k_gauss_mfma_filter");
+#define MFMA_LAUNCH(D, P) hipLaunchKernelGGL((k_gauss_mfma_filter<32, 32, D, P>), dim3(blocks), dim3(256), 0, c->stream, \
+		                   d_yT, nxp, s->nx, d_model_t, d_msq, B, scale, d_thr_rows, M, nspec, nbt, ngroups, d_higher, \
+		                   (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest)
+		switch (pr) {
+		case 1: MFMA_LAUNCH(1, 1); break;
+		case 2: MFMA_LAUNCH(1, 2); break;
+		case 3: MFMA_LAUNCH(1, 3); break;
+		case 4: MFMA_LAUNCH(2, 0); break;       // two chunks ahead (correct results)
+		default: MFMA_LAUNCH(1, 0); break;
+		}
+#undef MFMA_LAUNCH
+		if (!launched("k_gauss_mfma_filter")) return false;
+	}
+	const size_t lds = ((size_t) nxp * 4 + 4) * sizeof(double);
+	const int nst = nxp / kCH;
+#define EXACT_LAUNCH(NST) hipLaunchKernelGGL((k_exact_list<NST>), dim3(ntiles), dim3(256), lds, c->stream, \
+	s->d_y, s->ld, nxp, d_model_t, scale, d_thr_rows, M, ntiles, d_higher, B, (const int *) d_amb, trail.stamp, (const int *) d_lowest, d_flags, trail, \
+	(JointHeader *) d_header)
+	if (nst <= 8) EXACT_LAUNCH(8); else if (nst <= 16) EXACT_LAUNCH(16); else if (nst <= 26) EXACT_LAUNCH(26); else EXACT_LAUNCH(32);
+#undef EXACT_LAUNCH
+	return launched("k_exact_list");
 }
 
 }  // namespace mdns

@@ -116,7 +116,8 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
                               const double *d_higher, int *d_flags, const JointTrail &trail);
 // the accept test as guarded filter (mdns_like.hip, k_gauss_cols_filter): same flags and trail as
 // launch_gauss_cols_accept
-bool gauss_filter_pays(const mdns_spectra *s, int M, int B);
+// 0: the chain kernel decides; 1: vector-FMA filter; 2: matrix-core filter
+int gauss_filter_pays(const mdns_spectra *s, int M, int B);
 int gauss_filter_tile(int M, int B);
 bool launch_gauss_model_tsq(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t, double *d_msq,
                             int *d_zero, int nzero);
@@ -124,6 +125,11 @@ bool launch_gauss_cols_filter(const mdns_spectra *s, const double *d_yT, const d
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
                               const double *d_higher, int *d_flags, const double *d_msq, const JointTrail &trail, int *d_lowest);
 bool launch_row_sumsq(const double *d_y, int ld, int nx, int ndata, double *d_out);
+// the same decision on the matrix cores (mdns_chunk.hip, k_gauss_mfma_filter + k_exact_list);
+// templates tiled 16 wide; d_scratch int32[MDNS_JOINT_MAX_BATCH + 16], zeroed once
+bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int B, double scale,
+                              const int *d_thr_rows, int M, const double *d_higher, int *d_flags,
+                              const double *d_msq, const JointTrail &trail, int *d_lowest, int *d_scratch, void *d_header);
 // first flagged candidate from the trail of the accept pass: fill bits, shelf appends, thresholds
 // (flag_value: what the accept pass wrote into d_flags for an accepted candidate)
 bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,

@@ -348,6 +348,7 @@ struct mdns_joint {
 	int kind = 0;
 	int nparams = 3;
 	double *d_msq = nullptr;                                // templates' sums of squares (guarded accept filter, kind 0)
+	int *d_filter_scratch = nullptr;                        // matrix-core filter: ambiguous marks
 	double *d_dense = nullptr;  size_t dense_cap = 0;       // L[B, M] of a chunk (kind 1)
 	double *d_jitter = nullptr;  size_t jitter_cap = 0;
 	// the draw in progress through the mdns_backend_* entry points: its selection, uploaded once
@@ -384,6 +385,7 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	if (j->d_sel_rows) (void) hipFree(j->d_sel_rows);
 	if (j->d_dense) (void) hipFree(j->d_dense);
 	if (j->d_msq) (void) hipFree(j->d_msq);
+	if (j->d_filter_scratch) (void) hipFree(j->d_filter_scratch);
 	if (j->d_jitter) (void) hipFree(j->d_jitter);
 	if (j->h_in) (void) hipHostFree(j->h_in);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
@@ -700,6 +702,13 @@ static bool joint_trail(mdns_joint *j, int B, int M, JointTrail *out)
 	return true;
 }
 
+// what a chunk's status word says (bit 0: commit, bit 1: the matrix-core filter's pick pass)
+static void status_error(const char *who, int status, int cap)
+{
+	if (status & 2) set_error("%s: more ambiguous candidates than the exact pass lists (guarded filter)", who);
+	else set_error("%s: a shelf overflowed its capacity %d (mdns_joint_reserve)", who, cap);
+}
+
 static bool check_draw(const mdns_joint *j, int B, int M, const char *who)
 {
 	if (!j) { set_error("%s: null handle", who); return false; }
@@ -724,11 +733,15 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 		return MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kZeroInts * sizeof(int), c->stream)) ? 0 : 1;
 	}
 	const double scale = -0.5 / (noise_level * noise_level);
-	const bool filter = gauss_filter_pays(s, M, B);
-	const int bt = filter ? gauss_filter_tile(M, B) : gauss_cols_tile(M, B);
+	const int filter = gauss_filter_pays(s, M, B);
+	const int bt = filter == 2 ? 16 : filter ? gauss_filter_tile(M, B) : gauss_cols_tile(M, B);
 	if (!ensure_model(s, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
 	if (filter) {
 		if (!j->d_msq && !MDNS_HIP(hipMalloc((void **) &j->d_msq, (size_t) (MDNS_JOINT_MAX_BATCH + 16) * sizeof(double)))) return 1;
+		if (filter == 2 && !j->d_filter_scratch) {
+			const size_t bytes = (size_t) (MDNS_JOINT_MAX_BATCH + 16) * sizeof(int);
+			if (!MDNS_HIP(hipMalloc((void **) &j->d_filter_scratch, bytes)) || !MDNS_HIP(hipMemsetAsync(j->d_filter_scratch, 0, bytes, c->stream))) return 1;
+		}
 		if (!launch_gauss_model_tsq(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_msq, j->d_flags, kZeroInts)) return 1;
 	} else if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_flags, kZeroInts)) return 1;
 	const double *yT = s->d_yT;
@@ -736,7 +749,7 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 	// a sparse selection, or many candidate tiles over a selection: first a compact replica of
 	// the selected spectra (one coalesced pass) instead of gathering columns in every tile
 	const bool sparse = (size_t) M * 8 < (size_t) s->ndata;
-	if (d_row_ids && (B >= 128 || sparse)) {
+	if (d_row_ids && (B >= 128 || sparse || filter == 2)) {
 		if (!ensure_selection(s, (size_t) ((M + 63) / 64) * 64 * cols_nx(s->nx))) return 1;
 		if (!launch_tile_columns(s->d_y, s->ld, M, s->nx, d_row_ids, s->d_sel)) return 1;
 		yT = s->d_sel;
@@ -744,7 +757,11 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 	}
 	JointTrail trail;
 	if (!joint_trail(j, B, M, &trail)) return 1;
-	if (filter) {
+	if (filter == 2) {
+		int *lowest = (int *) &((JointHeader *) j->d_result)->pad;
+		if (!launch_gauss_mfma_filter(s, yT, s->d_model, B, scale, d_row_ids, M, j->st.higher, j->d_flags, j->d_msq, trail, lowest,
+		                              j->d_filter_scratch, j->d_result)) return 1;
+	} else if (filter) {
 		// issue-bound launch: the guarded filter decides -- same flags and trail, bit for bit.  Its
 		// "lowest flagged candidate so far" lives in the header's spare word (cleared with the flags).
 		int *lowest = (int *) &((JointHeader *) j->d_result)->pad;
@@ -824,7 +841,7 @@ extern "C" int mdns_joint_fetch(mdns_joint *j, int M, int *accepted, unsigned lo
 	if (!ctx() || !j || !accepted) return 1;
 	if (M < 0 || M > j->ndata) { set_error("mdns_joint_fetch: M=%d", M); return 1; }
 	if (!joint_wait_box(j, "mdns_joint_fetch")) return 1;
-	if (j->h_box->status) { set_error("mdns_joint_fetch: a shelf overflowed its capacity %d (mdns_joint_reserve)", j->cap); return 1; }
+	if (j->h_box->status) { status_error("mdns_joint_fetch", j->h_box->status, j->cap); return 1; }
 	*accepted = j->h_box->accepted;
 	if (fillbits && j->h_box->accepted >= 0) memcpy(fillbits, (const void *) j->h_box->bits, (size_t) ((M + 63) / 64) * 8);
 	return 0;
@@ -875,7 +892,7 @@ static int joint_commit_and_fetch(mdns_joint *j, int *accepted, double *Lrow, un
 		// no likelihood row wanted: the kernel leaves {accepted, status, fill words} in mapped host
 		// memory -- no copy, no stream synchronisation
 		if (!joint_wait_box(j, who)) return 1;
-		if (j->h_box->status) { set_error("%s: a shelf overflowed its capacity %d (mdns_joint_reserve)", who, j->cap); return 1; }
+		if (j->h_box->status) { status_error(who, j->h_box->status, j->cap); return 1; }
 		*accepted = j->h_box->accepted;
 		if (fillbits && j->h_box->accepted >= 0) memcpy(fillbits, (const void *) j->h_box->bits, (size_t) ((M + 63) / 64) * 8);
 		return 0;
@@ -886,7 +903,7 @@ static int joint_commit_and_fetch(mdns_joint *j, int *accepted, double *Lrow, un
 	char *out = j->h_pin + j->staged_in_bytes;
 	if (!MDNS_HIP(hipMemcpyAsync(out, j->d_result, out_bytes, hipMemcpyDeviceToHost, c->stream)) || !joint_sync(c)) return 1;
 	const JointHeader *h = (const JointHeader *) out;
-	if (h->status) { set_error("%s: a shelf overflowed its capacity %d (mdns_joint_reserve)", who, j->cap); return 1; }
+	if (h->status) { status_error(who, h->status, j->cap); return 1; }
 	*accepted = h->accepted;
 	if (h->accepted >= 0) {
 		const size_t nb = (size_t) ((M + 63) / 64) * 8;

@@ -1272,16 +1272,25 @@ bool launch_row_sumsq(const double *d_y, int ld, int nx, int ndata, double *d_ou
 
 // whether the guarded filter pays for a chunk of B candidates over M spectra: launches the lane
 // kernel runs issue-bound (8+ candidates per wave)
-bool gauss_filter_pays(const mdns_spectra *s, int M, int B)
+int gauss_filter_pays(const mdns_spectra *s, int M, int B)
 {
-	// MDNS_K1_FILTER=1 turns it on.  Off by default: the vector-FMA form measured here gains little --
-	// 33.9 us against 41-43 at 10 000 x 256 (rocprofv3), because the kernel is bound by the delivery of
-	// its scalar template operands, not by issue (SQ counters: VALU active 49 %, waves 65 % of their
-	// time in s_waitcnt) -- and the chain sub-pass of the accepted candidate (one wave-length of
-	// latency-bound loads at the END of its waves) gives the gain back: 57 us.
+	// MDNS_K1_FILTER=1: the vector-FMA form.  It gains little -- 33.9 us against 41-43 at
+	// 10 000 x 256 (rocprofv3), because the kernel is bound by the delivery of its scalar template
+	// operands, not by issue (SQ counters: VALU active 49 %, waves 65 % of their time in s_waitcnt) --
+	// and the chain sub-pass of the accepted candidate (one wave-length of latency-bound loads at
+	// the END of its waves) gives the gain back: 57 us.
+	// The matrix-core form (mdns_chunk.hip; MDNS_K1_FILTER=mfma forces it, 0 turns it off): the filter
+	// kernel itself takes 29-32 us against the chain kernel's 40-45 at 10 000 x 256, but its route has
+	// two more passes -- templates with sums of squares 7.7 us against 3.9, and the chain score of the
+	// accepted candidate 9.9 -- so that a sampler step there gains nothing (rocprofv3 of bench.py:
+	// 49.5 us against 43.9 for the three / two kernels).  It is the default where those passes are
+	// small beside the product: 122 us against 189 at 50 000 x 256, 101 against 162 at 10 000 x 1024.
 	static const char *forced = getenv("MDNS_K1_FILTER");
-	if (!forced || forced[0] != '1') return false;
-	return s->d_ysq != nullptr && gauss_cols_tile(M, B) >= 8;
+	if (s->d_ysq == nullptr || gauss_cols_tile(M, B) < 8) return 0;
+	if (forced && forced[0] == '1') return 1;
+	if (forced && forced[0] == '0') return 0;
+	if (forced && forced[0] == 'm') return 2;
+	return B >= 128 && (long long) M * B >= 8000000LL ? 2 : 0;
 }
 
 // candidates per wave of the filter: with ONE vector instruction per (candidate, channel, spectrum)

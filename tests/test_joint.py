@@ -192,23 +192,29 @@ def test_chunk_with_no_acceptable_candidate_changes_nothing():
     dev.close()
 
 
-def test_guarded_filter_decides_like_the_chain(hip, monkeypatch):
+@pytest.mark.parametrize("mode", ["1", "mfma", "default"])
+def test_guarded_filter_decides_like_the_chain(hip, monkeypatch, mode):
     """Issue-bound chunks (256 candidates x 10 000 spectra) take the accept test as a guarded filter:
     one FMA per (candidate, channel, spectrum) on the expanded square, a rigorous error band around
     every threshold, and an exact re-score by the chain for whatever falls inside the band
-    (k_gauss_cols_filter / k_gauss_cols_resolve).  Its decisions must be the chain kernel's bit for bit
+    (k_gauss_cols_filter with vector FMAs; k_gauss_mfma_filter + k_exact_list on the
+    matrix cores).  Its decisions must be the chain kernel's bit for bit
     -- also when a threshold is planted EXACTLY on a candidate's chain likelihood (L > thr is false)
     or one ulp below it (true): the cases only the resolve pass can get right."""
     from massivedatans_amd import _lib
     import subprocess, sys, os
-    if os.environ.get("MDNS_K1_FILTER") != "1":
+    if mode == "default":
+        # 1024 candidates x 10 000 spectra: the matrix-core filter is what the library picks by itself
+        if os.environ.get("MDNS_K1_FILTER") is not None:
+            pytest.skip("MDNS_K1_FILTER is set")
+    elif os.environ.get("MDNS_K1_FILTER") != mode:
         # the library reads the switch once per process: run this test in a child with the filter on
-        env = dict(os.environ, MDNS_K1_FILTER="1")
+        env = dict(os.environ, MDNS_K1_FILTER=mode)
         out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "gpu",
-                              __file__ + "::test_guarded_filter_decides_like_the_chain"], env=env, capture_output=True, text=True, timeout=600)
+                              __file__ + "::test_guarded_filter_decides_like_the_chain[%s]" % mode], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
         return
-    ndata, nlive, B = 10000, 100, 256
+    ndata, nlive, B = 10000, 100, (1024 if mode == "default" else 256)
     rng = np.random.RandomState(21)
     data = gen.horns(ndata)
     spectra = GaussLineSpectra(data["x"], data["y"], noise_level=0.01)
@@ -227,7 +233,8 @@ def test_guarded_filter_decides_like_the_chain(hip, monkeypatch):
         _lib.check(hip.mdns_joint_set_live(js._h, _lib.ptr(np.ascontiguousarray(live))), "set_live")
         js.prepare()
         out = js.draw(xs, None)
-        assert (hip.mdns_profile_kernel(0) or b"").decode().startswith("k_gauss_cols_filter"), "the filter did not run"
+        name = "k_gauss_cols_filter" if mode == "1" else "k_gauss_mfma_filter"
+        assert (hip.mdns_profile_kernel(0) or b"").decode().startswith(name), "the filter did not run"
         return out
 
     idx, _, beats, n = run(base)
