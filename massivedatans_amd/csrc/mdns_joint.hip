@@ -33,40 +33,27 @@ static constexpr int kZeroInts = kFlagInts + (int) (sizeof(JointHeader) / sizeof
 // lowest live likelihood and its slot (first occurrence, as numpy.argmin), shelf entries that
 // do not beat it dropped in order, threshold for what is still waiting.
 //
-// ONE pass over the live column: a workgroup = 64 data sets x 4 slices of the live slots; thread
-// (slice g, data set) looks at slots g, g + 4, ... and keeps, besides its minimum, its n0 + 1
-// smallest values sorted in LDS (n0 = entries waiting before the purge: an upper bound of what
-// waits after it, so the threshold -- the (w+1)-th smallest of live + shelf -- lies among the four
-// slices' lists and the shelf).  Slice 0 then purges the shelf and merges.  (The first version
-// walked up the distinct values with one pass over the column per waiting entry: 0.41 ms per
-// iteration in a real run against 5 us with empty shelves.)  Shelves longer than kSelect - 1 take
-// that walk still.
-static constexpr int kSelect = 16;
+// SIXTEEN lanes per data set, four data sets per wave (lane = 4 slice + data set: the four data
+// sets of a wave are neighbours in `running`, so a load touches 16 rows x 32 B): slice s holds live
+// slots and shelf entries s, s + 16, ... in registers, and everything that concerns one data set
+// -- minimum, purge, threshold -- is settled among its sixteen lanes with cross-lane operations:
+// no LDS, no barrier, and a data set that is done only waits for the other three of its wave.
+// History, per iteration of a real run whose shelves hold tens of entries (rocprofv3, first 600
+// iterations of C2; one lane per data set and slice, 64 data sets x 4 slices per workgroup):
+// walking up the distinct values with one pass over the column per waiting entry 416 us; sorted
+// lists of the 16-24 smallest per slice in LDS, merged in rounds, 62 us (the insertions are chains
+// of dependent LDS accesses); quickselect on counts with the values in registers 95 us (two
+// barriers and three scans of 64 registers per round); this form: see profiles/.
+static constexpr int kSlices = 16, kHeld = 8;                  // kHeld values per lane in registers: 128 slots / entries
 
-__device__ double threshold_by_walking(const JointArrays &st, int d, int w, double m)
+// reductions over the sixteen lanes of a data set (lanes q, q + 4, ..., q + 60)
+template <typename T, typename F> __device__ __forceinline__ T over_slices(T v, F f)
 {
-	const size_t nd = (size_t) st.ndata;
-	double thr = m, prev = 0.0;
-	bool first = true;
-	int below = 0;
-	while (true) {
-		double cur = INFINITY;
-		int times = 0;
-		for (int p = 0; p < st.nlive; p++) {
-			const double v = st.live[p * nd + d];
-			if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
-		}
-		for (int e = 0; e < w; e++) {
-			const double v = st.shelfL[e * nd + d];
-			if (first || v > prev) { if (v < cur) { cur = v; times = 1; } else if (v == cur) times++; }
-		}
-		below += times;
-		thr = cur;
-		if (below >= w + 1 || times == 0) break;
-		prev = cur;
-		first = false;
-	}
-	return thr;
+	v = f(v, __shfl_xor(v, 4));
+	v = f(v, __shfl_xor(v, 8));
+	v = f(v, __shfl_xor(v, 16));
+	v = f(v, __shfl_xor(v, 32));
+	return v;
 }
 
 __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const int *__restrict__ running, int nrun,
@@ -74,101 +61,141 @@ __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const 
                                                           int *__restrict__ argmin, unsigned long long *__restrict__ keep,
                                                           int keep_words)
 {
-	__shared__ double part_m[4][64];
-	__shared__ int part_i[4][64];
-	__shared__ int part_n[4][64];
-	__shared__ double low[4][kSelect][64];          // [slice][rank][data set]: a lane's addresses are 512 B apart, a wave's consecutive
-	__shared__ double waiting[kSelect][64];
-	const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-	const int r = blockIdx.x * 64 + lane;
-	const int d = running[r < nrun ? r : nrun - 1];
+	const int lane = threadIdx.x & 63;
+	const int q = lane & 3, sl = lane >> 2;
+	const int r = (blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)) * 4 + q;
+	const bool real = r < nrun;
+	const int d = running[real ? r : nrun - 1];
 	const size_t nd = (size_t) st.ndata;
+	// live slots sl, sl + 16, ...: all loads in flight at once; a NaN stands for "no such slot" (it
+	// is never the minimum and never counted); slots beyond 128 are read again where needed
+	double lv[kHeld];
+#pragma unroll
+	for (int u = 0; u < kHeld; u++) {
+		const int p = sl + kSlices * u;
+		lv[u] = st.live[(size_t) (p < st.nlive ? p : 0) * nd + d];
+	}
 	const int n0 = st.shelfn[d];
-	const int want = n0 + 1 <= kSelect ? n0 + 1 : 0;            // 0: the shelf is too long for the lists
+	double sv[kHeld];                                            // shelf entries sl, sl + 16, ...
+#pragma unroll
+	for (int u = 0; u < kHeld; u++) {
+		const int e = sl + kSlices * u;
+		sv[u] = st.shelfL[(size_t) (e < n0 ? e : 0) * nd + d];
+	}
 	double m = INFINITY;
-	int am = 0x7fffffff, have = 0;
-	auto offer = [&](double v, int p) {
-		if (v < m) { m = v; am = p; }
-		if (want == 1 || !(v == v)) return;                       // the minimum is the list; a NaN is never counted
-		if (have < want) {
-			int k = have++;
-			for (; k > 0 && low[g][k - 1][lane] > v; k--) low[g][k][lane] = low[g][k - 1][lane];
-			low[g][k][lane] = v;
-		} else if (want > 1 && v < low[g][want - 1][lane]) {
-			int k = want - 1;
-			for (; k > 0 && low[g][k - 1][lane] > v; k--) low[g][k][lane] = low[g][k - 1][lane];
-			low[g][k][lane] = v;
-		}
-	};
+	int am = 0x7fffffff;
+#pragma unroll
+	for (int u = 0; u < kHeld; u++) if (sl + kSlices * u >= n0) sv[u] = __builtin_nan("");
+#pragma unroll
+	for (int u = 0; u < kHeld; u++) {
+		const int p = sl + kSlices * u;
+		if (p >= st.nlive) lv[u] = __builtin_nan("");
+		if (lv[u] < m) { m = lv[u]; am = p; }
+	}
+	for (int p = sl + kSlices * kHeld; p < st.nlive; p += kSlices) { const double v = st.live[(size_t) p * nd + d]; if (v < m) { m = v; am = p; } }
+	// the minimum and its first slot (numpy.argmin)
 	{
-		int p = g;
-		for (; p + 28 < st.nlive; p += 32) {                     // eight loads in flight
-			double v[8];
+		const double mm = over_slices(m, [](double x, double y) { return y < x ? y : x; });
+		am = over_slices(m == mm ? am : 0x7fffffff, [](int x, int y) { return y < x ? y : x; });
+		m = mm;
+		if (am == 0x7fffffff) am = 0;                            // a column of NaNs: numpy.argmin's answer is moot
+	}
+	// purge (multi_nested_sampler.py:137-138: keep entries with L > Lmin, order kept): the sixteen
+	// lanes take sixteen consecutive entries; an entry moves down by the number of dropped ones
+	// before it.  (A batch is read whole before any of it is written, and kept entries only move
+	// down, to slots of this or an earlier batch.)
+	const unsigned long long mine = 0x1111111111111111ull << q;   // the lanes of this data set
+	const unsigned long long before = mine & ((1ull << lane) - 1ull);
+	int w = 0;                                                     // kept so far (the same in all sixteen lanes)
+	int w_held = -1;                                               // ... when the entries held in registers were through
+	unsigned long long word = 0;                                   // this lane's keep bits of the current 64 entries
+	for (int e0 = 0; e0 < keep_words * 64; e0 += kSlices) {        // (wave-uniform bounds: n0 differs between the four data sets)
+		const int e = e0 + sl;
+		const int u = e0 / kSlices;
+		if (u == kHeld) w_held = w;
+		double v;
+		if (u < kHeld) {
+			v = sv[0];
 #pragma unroll
-			for (int u = 0; u < 8; u++) v[u] = st.live[(p + 4 * u) * nd + d];
+			for (int k = 1; k < kHeld; k++) if (u == k) v = sv[k];
+		} else v = st.shelfL[(size_t) (e < n0 ? e : 0) * nd + d];
+		const bool kept = real && e < n0 && v > m;
+		const unsigned long long votes = __ballot(kept) & mine;
+		const int at = w + __popcll(votes & before);
+		if (kept && at != e) st.shelfL[(size_t) at * nd + d] = v;
+		if (kept) word |= 1ull << (e & 63);
+		w += __popcll(votes);
+		// what this lane keeps for the selection below: its own entries that were kept
+		if (u < kHeld) {
 #pragma unroll
-			for (int u = 0; u < 8; u++) offer(v[u], p + 4 * u);
+			for (int k = 0; k < kHeld; k++) if (u == k && !kept) sv[k] = __builtin_nan("");
 		}
-		for (; p < st.nlive; p += 4) offer(st.live[p * nd + d], p);
+		if (((e0 + kSlices) & 63) == 0) {
+			const unsigned long long all = over_slices(word, [](unsigned long long x, unsigned long long y) { return x | y; });
+			if (real && sl == 0) keep[(size_t) r * keep_words + (e0 >> 6)] = all;
+			word = 0;
+		}
 	}
-	part_m[g][lane] = m;
-	part_i[g][lane] = am;
-	part_n[g][lane] = have;
-	__syncthreads();
-	if (g != 0 || r >= nrun) return;
+	if (real && sl == 0) st.shelfn[d] = w;
+	if (w_held < 0) w_held = w;
+	// The (w+1)-th smallest of live + shelf (find_nsmallest, :44-47) by quickselect on counts: the
+	// answer is the smallest value x with at least w + 1 values at or below it.  It is known to lie
+	// in (lo, hi]; a round takes a pivot strictly inside -- every lane proposes the middle one, in
+	// slot order, of its own values in there, and the lane with most of them wins -- counts the
+	// values at or below the pivot and moves one end.  About log2(100 + w) rounds settle it.
+	// (Entries beyond the 128 held in registers are read from the purged shelf, where they follow
+	// the w_held kept ones of the first 128.)
+	double thr = m;                                                // nothing waits: the threshold is the minimum
+	bool done = !real || w == 0;
+	const int target = w + 1;
+	const bool far = n0 > kSlices * kHeld || st.nlive > kSlices * kHeld;   // values beyond the registers
+	double lo = __builtin_nan(""), hi = __builtin_nan("");        // NaN: no bound on that side yet
+	while (__any(!done)) {
+		int inside = 0;
+		double proposal = 0.0;
+		auto in_range = [&](double v) { return v == v && !(v <= lo) && !(v >= hi); };
 #pragma unroll
-	for (int o = 1; o < 4; o++) {
-		const double v = part_m[o][lane];
-		const int i = part_i[o][lane];
-		if (v < m || (v == m && i < am)) { m = v; am = i; }
-	}
-	if (am == 0x7fffffff) am = 0;                                // a column of NaNs: numpy.argmin's answer is moot
-	// purge (multi_nested_sampler.py:137-138: keep entries with L > Lmin, order kept)
-	int w = 0;
-	for (int word = 0; word < keep_words; word++) {
-		unsigned long long bits = 0;
-		const int e1 = min(n0, 64 * (word + 1));
-		for (int e = 64 * word; e < e1; e++) {
-			const double v = st.shelfL[e * nd + d];
-			if (v > m) {
-				bits |= 1ull << (e & 63);
-				if (w != e) st.shelfL[w * nd + d] = v;
-				if (w < kSelect) waiting[w][lane] = v;
-				w++;
+		for (int u = 0; u < kHeld; u++) inside += in_range(lv[u]);
+#pragma unroll
+		for (int u = 0; u < kHeld; u++) inside += in_range(sv[u]);
+		if (far) {
+			for (int p = sl + kSlices * kHeld; p < st.nlive; p += kSlices) inside += in_range(st.live[(size_t) p * nd + d]);
+			for (int e = w_held + sl; e < w; e += kSlices) inside += in_range(st.shelfL[(size_t) e * nd + d]);
+		}
+		{
+			int countdown = inside / 2;                            // the middle one in slot order
+			auto pick = [&](double v) { if (in_range(v) && countdown-- == 0) proposal = v; };
+#pragma unroll
+			for (int u = 0; u < kHeld; u++) pick(lv[u]);
+#pragma unroll
+			for (int u = 0; u < kHeld; u++) pick(sv[u]);
+			if (far) {
+				for (int p = sl + kSlices * kHeld; p < st.nlive; p += kSlices) pick(st.live[(size_t) p * nd + d]);
+				for (int e = w_held + sl; e < w; e += kSlices) pick(st.shelfL[(size_t) e * nd + d]);
 			}
 		}
-		keep[(size_t) r * keep_words + word] = bits;
-	}
-	st.shelfn[d] = w;
-	// threshold: the (w+1)-th smallest of live + shelf (find_nsmallest, :44-47)
-	double thr = m;
-	if (w > 0) {
-		if (want == 0) thr = threshold_by_walking(st, d, w, m);
-		else {
-			// w + 1 extractions from the four sorted lists and the (unsorted) waiting values
-			int head[4] = {0, 0, 0, 0};
-			unsigned used = 0;
-			thr = INFINITY;
-			for (int taken = 0; taken <= w; taken++) {
-				double best = INFINITY;
-				int from = -1;
-#pragma unroll
-				for (int o = 0; o < 4; o++)
-					if (head[o] < part_n[o][lane]) {
-						const double v = low[o][head[o]][lane];
-						if (v < best) { best = v; from = o; }
-					}
-				for (int e = 0; e < w; e++)
-					if (!(used >> e & 1u)) {
-						const double v = waiting[e][lane];
-						if (v < best) { best = v; from = 4 + e; }
-					}
-				if (from < 0) { thr = INFINITY; break; }            // fewer than w + 1 comparable values (NaNs)
-				if (from < 4) head[from]++; else used |= 1u << (from - 4);
-				thr = best;
-			}
+		// the proposal of the lane with most values inside (ties: the lowest slice)
+		const int most = over_slices(inside, [](int x, int y) { return y > x ? y : x; });
+		const int from = over_slices(inside == most ? sl : kSlices, [](int x, int y) { return y < x ? y : x; });
+		const double pivot = __shfl(proposal, 4 * from + q);
+		if (!done && most == 0) {
+			// nothing strictly between: hi it is -- or there are fewer than w + 1 comparable values (NaNs)
+			thr = hi == hi ? hi : INFINITY;
+			done = true;
 		}
+		int count = 0;
+#pragma unroll
+		for (int u = 0; u < kHeld; u++) count += lv[u] <= pivot;  // (a NaN is never counted)
+#pragma unroll
+		for (int u = 0; u < kHeld; u++) count += sv[u] <= pivot;
+		if (far) {
+			for (int p = sl + kSlices * kHeld; p < st.nlive; p += kSlices) count += st.live[(size_t) p * nd + d] <= pivot;
+			for (int e = w_held + sl; e < w; e += kSlices) count += st.shelfL[(size_t) e * nd + d] <= pivot;
+		}
+		const int total = over_slices(count, [](int x, int y) { return x + y; });
+		if (!done) { if (total >= target) hi = pivot; else lo = pivot; }
 	}
+	if (!real || sl != 0) return;
 	st.higher[d] = thr;
 	Lmin[r] = m;
 	argmin_run[r] = am;
@@ -615,7 +642,7 @@ extern "C" int mdns_joint_prepare_dev(mdns_joint *j)
 	}
 	j->prepared = true;
 	if (j->nrun == 0) return 0;
-	hipLaunchKernelGGL(k_joint_prepare, dim3((j->nrun + 63) / 64), dim3(kBlock), 0, c->stream,
+	hipLaunchKernelGGL(k_joint_prepare, dim3((j->nrun + 15) / 16), dim3(kBlock), 0, c->stream,
 	                   j->st, j->d_running, j->nrun, j->d_Lmin, j->d_argmin_run, j->d_argmin, j->d_keep, kw);
 	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
 }

@@ -426,7 +426,9 @@ __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
 			for (int b = 0; b < RT; b++) {
 				const double S = (m >> b & 1u) ? NINF : PINF;             // scalar: s_bitcmp1 + s_cselect_b64
 				// (written as asm: left to itself the compiler turns max(d, +-inf) into two
-				// v_cndmask_b32 per round -- three vector instructions instead of two)
+				// v_cndmask_b32 per round -- three vector instructions instead of two; so does the
+				// quiet-NaN form d.hi | 0x7ff80000 of the classic kernel with a scalar mask: it needs a
+				// copy of d.lo per round to form the register pair)
 				double t;
 				asm("v_max_f64 %0, %1, %2" : "=v"(t) : "v"(d), "s"(S));
 				nearest[b] = min_or_skip(nearest[b], t);
@@ -626,26 +628,20 @@ bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_
 	return launch_nearest<false>(d_members, K, ndim, d_chosen, nbootstraps, d_round_sq, finish);
 }
 
-// grid.y of k_nearest_uniform: member chunks, so that the workgroups fill the CUs evenly about
-// three deep (more waves per SIMD than that buys nothing: the loop is issue-bound)
+// grid.y of k_nearest_uniform: member chunks.  Measured (tools/k6_gy_sweep.py, us for the pair of
+// kernels at 10 rounds; 1 / 4 / 8 / 16 / 32 / 64 chunks):
+//     K =  5 000:  174 /  68 /  55 /  51 /  59 /  62        K = 20 000:  813 / 430 / 407 / 405 / 411 / 418
+//     K =  9 000:  302 / 139 / 118 / 110 / 114 / 127        K = 50 000: 3258 / 2331 / 2193 / 2155 / 2194 / 2195
+// i.e. many small workgroups (12 500 at 50 000 points) beat the few long ones a model of "fill the
+// CUs three deep" picks (it chose 1 chunk at 50 000: 782 workgroups on 256 CUs, 3 217 us): sixteen
+// chunks wherever a chunk still has 128 members (fewer is all prologue).  At 50 000 points the pair
+// then runs within 12 % of the issue bound of its 28 vector instructions per pair and round set.
 static int uniform_chunks(int K, int num_cus)
 {
-	const int groups = (K + 63) / 64;
-	int most = K / 128;                              // a chunk of fewer than 128 members is all prologue
+	(void) num_cus;
+	int most = K / 128;
 	if (most < 1) most = 1;
-	if (most > 64) most = 64;
-	int best = 1;
-	double best_cost = 1e300;
-	for (int gy = 1; gy <= most; gy++) {
-		const long long wgs = (long long) groups * gy;
-		const long long rounds = (wgs + num_cus - 1) / num_cus;          // workgroups the busiest CU gets
-		if (rounds > 4 && gy > 1) break;
-		// time ~ (workgroups of the busiest CU) x (members per chunk + a fixed cost per workgroup);
-		// a wave alone on its SIMD also pays for its scalar instructions (nothing to overlap with)
-		const double alone = rounds == 1 ? 1.6 : (rounds == 2 ? 1.15 : 1.0);
-		const double cost = alone * (double) rounds * ((double) K / gy + 96.0);
-		if (cost < best_cost) { best_cost = cost; best = gy; }
-	}
+	int best = most < 16 ? most : 16;
 	static const char *forced = getenv("MDNS_K6_GY");                    // experiments only
 	if (forced && atoi(forced) > 0) best = atoi(forced) < most ? atoi(forced) : most;
 	return best;

@@ -152,9 +152,8 @@ def test_shelves_grow_past_their_first_capacity():
             assert np.array_equal(ba, bb) and np.array_equal(La, Lb)
         if k in (9, 39):
             # the start of an iteration with shelves this long: nothing is purged (the live points did
-            # not change), and the thresholds -- the (n+1)-th smallest of live + shelf, found in ONE
-            # pass with per-slice selection lists for up to 15 waiting entries (k = 9) and by walking
-            # the values beyond that (k = 39) -- come out as the commits left them
+            # not change), and the thresholds -- the (n+1)-th smallest of live + shelf, by quickselect
+            # among the sixteen lanes of a data set -- come out as the commits left them
             ha, hn = dev.thresholds()
             lengths.append((int(hn.min()), int(hn.max())))
             a, b = dev.prepare(), host.prepare()
@@ -165,7 +164,63 @@ def test_shelves_grow_past_their_first_capacity():
     hb, hm = host.thresholds()
     assert hn.max() > 4, "the test did not fill a shelf past the first capacity"
     assert np.array_equal(hn, hm) and np.array_equal(ha, hb)
-    assert 0 < lengths[0][1] < 16 <= lengths[1][0], ("both threshold paths must be exercised", lengths)
+    assert 0 < lengths[0][1] < 16 <= lengths[1][0], ("short and long shelves must be exercised", lengths)
+    dev.close()
+
+
+def test_long_shelves_purge_and_threshold():
+    """Shelves longer than the 128 entries a data set's sixteen lanes hold in registers
+    (k_joint_prepare): more than 128 accepted points waiting, then iterations -- every one replaces the worst
+    live point by the head of the shelf, purges what no longer beats the new minimum (entries move
+    down, in order) and selects the threshold among live + shelf -- against the numpy statement."""
+    ndata, nlive = 70, 12
+    rng = np.random.RandomState(5)
+    data = gen.nothing(ndata)
+    spectra = GaussLineSpectra(data["x"], data["y"], noise_level=0.01)
+    dev = jointstate.GaussJointState(spectra, nlive, sample.kernel_params, shelf_cap=4)
+    host = jointstate.HostJointState(LaneScorer(spectra), nlive, ndata, sample.kernel_params)
+    xs0 = sample.priortransform_batch(rng.uniform(size=(nlive, 3)))
+    dev.init(xs0)
+    host.init(xs0)
+    dev.prepare()
+    host.prepare()
+    for k in range(300):
+        if k % 3 != 2:
+            # ever fainter lines at one place: on spectra of pure noise every such draw beats the one
+            # before until the amplitude reaches the noise, so the shelves of all data sets keep growing
+            cube = np.column_stack([0.3 * 0.985 ** k * rng.uniform(0.9, 1.0, size=6), np.full(6, 0.5), np.full(6, 0.5)])
+        else:
+            # and lines anywhere, which some data sets take and others do not: shelves out of order
+            cube = rng.uniform(size=(20, 3))
+            cube[:, 0] *= 0.3 * 0.985 ** k
+        xs = sample.priortransform_batch(cube)
+        ia, La, ba, na = dev.draw(xs, None)
+        ib, Lb, bb, _ = host.draw(xs[:na], None)
+        assert ia == ib
+    # the same (best) candidate again and again: equal likelihoods wait in the shelves (ties at the
+    # threshold, which is then one of the copies); the thresholds see to it that the purge never
+    # finds anything to drop -- what is kept and where is compared all the same
+    cube = np.column_stack([np.full(3, 0.3 * 0.985 ** 300), np.full(3, 0.5), np.full(3, 0.5)])
+    for k in range(20):
+        xs = sample.priortransform_batch(cube)
+        ia, La, ba, na = dev.draw(xs, None)
+        ib, Lb, bb, _ = host.draw(xs[:na], None)
+        assert ia == ib
+    ha, hn = dev.thresholds()
+    assert hn.max() > 128, ("the shelves did not grow past the registers", int(hn.max()))
+    for it in range(int(hn.max())):
+        if hn.min() <= 1:
+            break
+        dev.advance()
+        host.advance()
+        a, b = dev.prepare(), host.prepare()
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        ha, hn = dev.thresholds()
+        hb, hm = host.thresholds()
+        assert np.array_equal(hn, hm), it
+        assert np.array_equal(ha, hb), it
+        assert np.array_equal(dev.live_matrix(), host.live_matrix())
+    assert it > 40
     dev.close()
 
 

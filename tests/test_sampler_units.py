@@ -1,5 +1,6 @@
 """Unit tests of the array-backed bookkeeping against the reference's list-based statement."""
 import numpy as np
+import pytest
 
 from massivedatans_amd.multi_nested_sampler import _Shelves, find_nsmallest
 from massivedatans_amd.clustering.sdml import IdentityMetric, SimpleScaling, TruncatedScaling
@@ -441,3 +442,16 @@ def test_hdf5_roundtrip_with_real_h5py(tmp_path):
         assert set(f.keys()) == {"logZ", "logZerr", "u", "x", "L", "w", "mask", "ndraws"}
         assert f["u"].shape == (3, 6, 3) and f["L"].compression == "gzip" and f["L"].shuffle
         assert int(f["ndraws"][()]) == 12 and np.array_equal(f["logZ"][()], np.arange(6.))
+
+
+@pytest.mark.gpu
+def test_hdf5_roundtrip_with_real_h5py_on_the_gpu_box(tmp_path):
+    """The same round trip in the ``-m gpu`` tier, so that a recorded run on the GPU box says whether
+    h5py was there: it SKIPS with that reason when it is not (SURVEY row f4 stays partial until one
+    recorded run executes it)."""
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        pytest.skip("h5py is not installed on this box: the real-file round trip (row f4) did not run")
+    test_hdf5_roundtrip_with_real_h5py(tmp_path)
+
