@@ -1130,32 +1130,24 @@ extern "C" int mdns_region_count_dev(mdns_region *r, const double *d_points, int
 	                           d_points, M, d_counts) ? 0 : 1;
 }
 
-// counts of a membership launch -> host memory mapped into the device, `seq` last: the host polls
-// instead of copying and synchronising the stream
-__global__ __launch_bounds__(1024) void k_export_counts(const int *__restrict__ src, int n, int *__restrict__ dst,
-                                                        unsigned long long *__restrict__ seq_at, unsigned long long seq)
-{
-	for (int i = threadIdx.x; i < n; i += 1024) dst[i] = src[i];
-	__threadfence_system();
-	__syncthreads();
-	if (threadIdx.x == 0) __hip_atomic_store(seq_at, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // one staging block for the membership round trips of the native constrainer: pinned + mapped,
 // layout { seq | counts int32[cap] | points f64[cap * ndim] }
 static char *g_stage = nullptr, *g_stage_dev = nullptr;
 static size_t g_stage_points = 0, g_stage_doubles = 0;
 static unsigned long long g_stage_seq = 0;
+static int *g_stage_ticket = nullptr;                 // device: workgroups of the current launch that are through
 
-// K3 for host points with the least round trip: points through the pinned block (one asynchronous
-// copy), counts exported by a kernel into the mapped block, the host polls (mdns_region_count
-// copies pageable memory both ways and synchronises the stream: 42 us per call measured in a real
-// run, against 8 us of kernel)
+// K3 for host points with the least round trip: ONE kernel.  The points sit in a pinned block mapped
+// into the device, the kernel reads them there, stores the counts there and its last workgroup
+// raises a sequence number the host polls for.  (History, per call in a real run: pageable copies
+// both ways and a stream synchronisation 42 us; pinned copy in + count + export kernel + polling
+// 35 us, of which four device commands -- copy, clear, count, export -- for 6 us of counting.)
 extern "C" int mdns_region_count_polled(mdns_region *r, const double *points, int M, int *counts)
 {
 	Context *c = ctx();
 	if (!c || !r) return 1;
 	if (M <= 0) return M < 0;
+	if (!r->on_device && r->radius != r->radius) { set_error("mdns_region_count: the region has no radius yet"); return 1; }
 	const size_t n = (size_t) M * r->ndim;
 	if ((size_t) M > g_stage_points || n > g_stage_doubles) {
 		if (g_stage) { (void) hipStreamSynchronize(c->stream); (void) hipHostFree(g_stage); g_stage = nullptr; }
@@ -1165,23 +1157,31 @@ extern "C" int mdns_region_count_polled(mdns_region *r, const double *points, in
 		g_stage_points = np; g_stage_doubles = nd;
 		*(volatile unsigned long long *) g_stage = g_stage_seq;
 	}
+	if (!g_stage_ticket) {
+		if (!MDNS_HIP(hipMalloc((void **) &g_stage_ticket, sizeof(int))) ||
+		    !MDNS_HIP(hipMemsetAsync(g_stage_ticket, 0, sizeof(int), c->stream))) { g_stage_ticket = nullptr; return 1; }
+	}
 	const size_t off_counts = 64, off_points = (64 + g_stage_points * sizeof(int) + 63) & ~(size_t) 63;
 	memcpy(g_stage + off_points, points, n * sizeof(double));
-	if (!pool_fit(&r->d_points, &r->points_bytes, n * sizeof(double)) ||
-	    !pool_fit(&r->d_counts, &r->counts_bytes, (size_t) M * sizeof(int))) return 1;
-	if (!MDNS_HIP(hipMemcpyAsync(r->d_points, g_stage + off_points, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
-	if (mdns_region_count_dev(r, (const double *) r->d_points, M, (int *) r->d_counts) != 0) return 1;
 	const unsigned long long seq = ++g_stage_seq;
-	hipLaunchKernelGGL(k_export_counts, dim3(1), dim3(1024), 0, c->stream, (const int *) r->d_counts, M,
-	                   (int *) (g_stage_dev + off_counts), (unsigned long long *) g_stage_dev, seq);
-	if (!MDNS_HIP(hipGetLastError())) return 1;
+	const CountMail mail = {g_stage_ticket, (unsigned long long *) g_stage_dev, seq};
+	// right after a radius computation the kernel takes the threshold the bootstrap kernel left in
+	// device memory (stream order)
+	if (!launch_count_within(r->d_members, r->K, r->ndim, r->thresh_sq, r->on_device ? r->d_res : nullptr,
+	                         (const double *) (g_stage_dev + off_points), M, (int *) (g_stage_dev + off_counts), &mail)) return 1;
 	volatile unsigned long long *at = (volatile unsigned long long *) g_stage;
 	for (unsigned spin = 0; *at != seq; spin++) {
 		if ((spin & 1023) != 1023) continue;
 		const hipError_t e = hipStreamQuery(c->stream);
 		if (e == hipErrorNotReady) continue;
 		if (e != hipSuccess) { set_error("membership count failed: %s", hipGetErrorString(e)); return 1; }
-		if (*at != seq) { set_error("membership count finished without a result"); return 1; }
+		if (*at != seq) {
+			// (the stream drained and the number is not there: the launch failed; the ticket counter
+			// may be anywhere)
+			(void) hipMemsetAsync(g_stage_ticket, 0, sizeof(int), c->stream);
+			set_error("membership count finished without a result");
+			return 1;
+		}
 	}
 	std::atomic_thread_fence(std::memory_order_acquire);
 	memcpy(counts, g_stage + off_counts, (size_t) M * sizeof(int));

@@ -88,14 +88,21 @@ __device__ __forceinline__ int wave_min(int v)
 // holders before the others look: a handful of stores per id instead of one per holder (a
 // store per edge made a round of 10^6 edges 250 us; a round that only looks takes 6).
 __global__ __launch_bounds__(kBlock) void k_groups_round(const int *__restrict__ idsT, int nlive,
-                                                         const int *__restrict__ rows, int M, long long npoints,
+                                                         int *rows, const int *__restrict__ rows_host, int M, long long npoints,
                                                          PLabel *plabel, int *label, int first, int call, int flag,
                                                          int *__restrict__ changed, int *__restrict__ status, int sweeps)
 {
 	const int lane = threadIdx.x & 63;
 	const int i = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
 	if (i >= M) return;                                               // whole waves
-	const int d = rows ? rows[i] : i;
+	// the first launch of a call takes the selection from the host block mapped into the device
+	// (one 4-byte read per wave instead of a copy command in front of the launch) and leaves it in
+	// device memory for the launches that follow
+	int d = i;
+	if (rows_host) {
+		d = rows_host[i];
+		if (lane == 0) rows[i] = d;
+	} else if (rows) d = rows[i];
 	const int *mine = idsT + (size_t) d * nlive;
 	bool moved = false;
 	// `sweeps` passes of the same pull-and-push per launch: what a wave sees of the others' stores
@@ -161,22 +168,24 @@ __global__ __launch_bounds__(kBlock) void k_groups_transpose(const int *__restri
 		if (c0 + k < ncols && r0 + tx < nrows) dst[(size_t) (c0 + k) * nrows + r0 + tx] = tile[tx][k];
 }
 
+// After the rounds, one launch: workgroups [0, finish_blocks) note the label of every selected data
+// set and count the components (a data set that kept its own index); the others build the bit map
+// of the ids held -- bit q = some selected data set holds live point q: a wave's ballot is the word.
 __global__ __launch_bounds__(kBlock) void k_groups_finish(const int *__restrict__ label, const int *__restrict__ rows, int M,
-                                                          int *__restrict__ labels, GroupsHeader *__restrict__ header)
+                                                          int *__restrict__ labels, GroupsHeader *__restrict__ header, int finish_blocks,
+                                                          const PLabel *__restrict__ plabel, long long npoints, int call,
+                                                          unsigned long long *__restrict__ touched)
 {
-	const int i = blockIdx.x * kBlock + threadIdx.x;
-	if (i >= M) return;
-	const int d = rows ? rows[i] : i;
-	const int l = label[d];
-	labels[i] = l;
-	if (l == d) atomicAdd(&header->ncomponents, 1);
-}
-
-// bit q of the map = some selected data set holds live point q: a wave's ballot is the word
-__global__ __launch_bounds__(kBlock) void k_groups_touched(const PLabel *__restrict__ plabel, long long npoints, int call,
-                                                           unsigned long long *__restrict__ touched)
-{
-	const long long q = (long long) blockIdx.x * kBlock + threadIdx.x;
+	if ((int) blockIdx.x < finish_blocks) {
+		const int i = blockIdx.x * kBlock + threadIdx.x;
+		if (i >= M) return;
+		const int d = rows ? rows[i] : i;
+		const int l = label[d];
+		labels[i] = l;
+		if (l == d) atomicAdd(&header->ncomponents, 1);
+		return;
+	}
+	const long long q = (long long) (blockIdx.x - finish_blocks) * kBlock + threadIdx.x;
 	const bool held = q < npoints && (int) (plabel[q] >> 32) == call;
 	const unsigned long long word = __ballot(held);
 	if ((threadIdx.x & 63) == 0 && q < npoints) touched[q >> 6] = word;
@@ -276,7 +285,7 @@ struct mdns_groups {
 	int rounds_hint = 4;                               // rounds the next call launches before it looks
 	int call = 0;                                      // number of the current components call (stamps)
 	int label_call = 0;                                // the stamp the point labels of the last call carry
-	char *h_rows = nullptr;  size_t rows_bytes = 0;    // pinned staging of a call's selection (its own block:
+	char *h_rows = nullptr, *h_rows_dev = nullptr;  size_t rows_bytes = 0;    // pinned + mapped block of a call's selection (its own:
 	                                                   // every call ends by polling, so it is free at the next one)
 	long long rounds_total = 0, calls_total = 0;
 };
@@ -448,13 +457,13 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		// nothing reads the block any more -- no stream synchronisation)
 		if ((size_t) M * 4 > g->rows_bytes) {
 			if (g->h_rows) { (void) hipStreamSynchronize(c->stream); (void) hipHostFree(g->h_rows); g->h_rows = nullptr; g->rows_bytes = 0; }
-			if (!MDNS_HIP(hipHostMalloc((void **) &g->h_rows, (size_t) g->ndata * 4, hipHostMallocDefault))) return 1;
+			if (!MDNS_HIP(hipHostMalloc((void **) &g->h_rows, (size_t) g->ndata * 4, hipHostMallocMapped)) ||
+			    !MDNS_HIP(hipHostGetDevicePointer((void **) &g->h_rows_dev, g->h_rows, 0))) return 1;
 			g->rows_bytes = (size_t) g->ndata * 4;
 		}
 		memcpy(g->h_rows, rows, (size_t) M * 4);
-		if (!MDNS_HIP(hipMemcpyAsync(g->d_rows, g->h_rows, (size_t) M * 4, hipMemcpyHostToDevice, c->stream))) return 1;
 	}
-	const int *d_rows = rows ? g->d_rows : nullptr;
+	int *d_rows = rows ? g->d_rows : nullptr;
 	// Nothing is cleared: point labels and the rounds' "moved" flags carry the number of the batch
 	// of rounds they belong to, the component counter is put back to zero by the kernel that reads it.
 	if (g->call >= 0x7ffffff0) {                                     // stamps start over (once in 2^31 batches)
@@ -471,14 +480,14 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		if (total > 0) flag = ++g->call;                              // (labels keep the stamp `call`; only the flags move on)
 		for (int r = 0; r < batch; r++)
 			hipLaunchKernelGGL(k_groups_round, dim3((M + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-			                   g->d_idsT, g->nlive, d_rows, M, npoints, plabel_of(g), g->d_label, total == 0 && r == 0 ? 1 : 0, call,
+			                   g->d_idsT, g->nlive, d_rows, rows && total == 0 && r == 0 ? (const int *) g->h_rows_dev : nullptr, M, npoints,
+			                   plabel_of(g), g->d_label, total == 0 && r == 0 ? 1 : 0, call,
 			                   flag, &hdr_of(g)->changed[r], &hdr_of(g)->status, kSweeps);
 		total += batch;
 		// optimistically everything that follows a converged state, in the same round trip
-		hipLaunchKernelGGL(k_groups_finish, dim3((M + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream,
-		                   g->d_label, d_rows, M, g->d_labels, hdr_of(g));
-		hipLaunchKernelGGL(k_groups_touched, dim3((unsigned) ((npoints + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
-		                   plabel_of(g), npoints, call, touched_of(g));
+		const int finish_blocks = (M + kBlock - 1) / kBlock;
+		hipLaunchKernelGGL(k_groups_finish, dim3(finish_blocks + (unsigned) ((npoints + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+		                   g->d_label, (const int *) d_rows, M, g->d_labels, hdr_of(g), finish_blocks, plabel_of(g), npoints, call, touched_of(g));
 		hipLaunchKernelGGL(k_groups_compact, dim3(1), dim3(1024), 0, c->stream, touched_of(g), (long long) nw, pout_of(g), hdr_of(g),
 		                   g->h_box_dev, ++g->box_seq);
 		if (!MDNS_HIP(hipGetLastError())) return 1;

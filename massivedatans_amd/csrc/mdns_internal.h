@@ -175,8 +175,13 @@ struct BootstrapFinish {
 
 // threshold on the squared distance: thresh_sq, or -- when d_res != nullptr -- the one the
 // preceding radius computation left on the device
+// mail != nullptr: `d_cands` and `d_counts` may be host memory mapped into the device -- the kernel
+// reads the candidates from there, stores the counts there (no member split) and its last
+// workgroup raises *seq_at to `seq`: the host polls instead of copying both ways
+struct CountMail { int *ticket; unsigned long long *seq_at; unsigned long long seq; };
 bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
-                         const RegionResult *d_res, const double *d_cands, int M, int *d_counts);
+                         const RegionResult *d_res, const double *d_cands, int M, int *d_counts,
+                         const CountMail *mail = nullptr);
 bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_chosen,
                       int nbootstraps, double *d_round_sq, const BootstrapFinish *finish = nullptr);
 // the same with the choice already packed: bit b of d_packed[i] = point i is chosen in round b

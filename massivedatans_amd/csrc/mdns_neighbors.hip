@@ -91,7 +91,7 @@ template <int D, int SL>
 __global__ __launch_bounds__(kBlock) void k_count_within(
     const double *__restrict__ members, int K, int ndim, double thresh_value,
     const RegionResult *__restrict__ res, const double *__restrict__ cands, int M,
-    int *__restrict__ counts, int kchunk, int tile_n, int accumulate)
+    int *__restrict__ counts, int kchunk, int tile_n, int accumulate, CountMail mail)
 {
 	constexpr int PTS = Geo<SL>::PTS, NSLICE = Geo<SL>::NSLICE;
 	// the threshold either came with the launch (host-known radius) or was left in device
@@ -139,6 +139,19 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 		const int total = (part[pt] + part[PTS + pt]) + (part[2 * PTS + pt] + part[3 * PTS + pt]);
 		if (accumulate) { if (total) atomicAdd(counts + j, total); }
 		else counts[j] = total;
+	}
+	if (mail.seq_at) {
+		// `counts` is host memory mapped into the device (no member split: plain stores): once every
+		// workgroup's stores are out, the last one to get here raises `seq` for the polling host
+		__threadfence_system();
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			const int done = atomicAdd(mail.ticket, 1);
+			if (done == (int) (gridDim.x * gridDim.y) - 1) {
+				__hip_atomic_store(mail.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (stream order)
+				__hip_atomic_store(mail.seq_at, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
 	}
 }
 
@@ -539,9 +552,11 @@ static int pick_tile(int ndim, size_t per_member_extra, size_t fixed_bytes)
 	case 7: LAUNCH(7); break; case 8: LAUNCH(8); break; default: LAUNCH(0); break; }
 
 bool launch_count_within(const double *d_members, int K, int ndim, double thresh_sq,
-                         const RegionResult *d_res, const double *d_cands, int M, int *d_counts)
+                         const RegionResult *d_res, const double *d_cands, int M, int *d_counts, const CountMail *mail)
 {
 	Context *c = ctx();
+	const CountMail none = {nullptr, nullptr, 0};
+	const CountMail post = mail ? *mail : none;
 	const size_t fixed = 4 * 64 * sizeof(int);
 	const int tile_n = pick_tile(ndim, 0, fixed);
 	if (tile_n <= 0) { set_error("ndim=%d too large for the member tile", ndim); return false; }
@@ -553,6 +568,7 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	int want = (2 * c->num_cus + gx - 1) / gx;
 	int max_split = (K + tile_n - 1) / tile_n;
 	int gy = want < max_split ? want : max_split;
+	if (mail) gy = 1;                                  // results go straight to the host: no partial counts
 	if (gy < 1) gy = 1;
 	if (gy > 65535) gy = 65535;
 	int kchunk = (K + gy - 1) / gy;
@@ -564,9 +580,9 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	dim3 grid(gx, gy);
 	ProfileScope prof(2);
 #define COUNT_LAUNCH(D) do { if (small) hipLaunchKernelGGL((k_count_within<D, 4>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate); \
+		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate, post); \
 	else hipLaunchKernelGGL((k_count_within<D, 1>), grid, dim3(kBlock), lds, c->stream, \
-		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate); } while (0)
+		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate, post); } while (0)
 	MDNS_DIM_SWITCH(ndim, COUNT_LAUNCH)
 #undef COUNT_LAUNCH
 	return launched("k_count_within");
