@@ -424,6 +424,12 @@ typedef struct mdns_draw_backend {
 	/* How many of `offered` candidates one chunk should hold for M selected data sets when the last
 	 * draw of this constrainer needed `hint` tries (a speed choice: results do not depend on it). */
 	int (*chunk_size)(void *user, int offered, int M, int hint);
+	/* Optional (NULL: region_create is used).  region_create with packed != NULL in two halves, so
+	 * that the caller can work while K6 runs: region_begin uploads the members and launches K6 and
+	 * returns the region at once, region_radius waits for the radius of such a region.  At most one
+	 * region per backend is between the two calls at any time. */
+	void *(*region_begin)(void *user, const double *members, int K, int ndim, const unsigned *packed, int nbootstraps);
+	int (*region_radius)(void *user, void *region, double *radius);
 } mdns_draw_backend;
 
 /* The prior transform of the problem (sample.py:52-58) and the kernel's parameters (sample.py:103),
@@ -511,6 +517,8 @@ int mdns_backend_draw_begin(void *joint, const int *rows, int M);
 int mdns_backend_draw_chunk(void *joint, const double *params, int B, const double *jitter, int *accepted,
                             unsigned long long *fillbits, int *nscored);
 int mdns_backend_chunk_size(void *joint, int offered, int M, int hint);
+void *mdns_backend_region_begin(void *joint, const double *members, int K, int ndim, const unsigned *packed, int nbootstraps);
+int mdns_backend_region_radius(void *joint, void *region, double *radius);
 
 #ifdef __cplusplus
 }

@@ -40,6 +40,7 @@ ABI_SYMBOLS = (
     "mdns_groups_replace", "mdns_groups_components", "mdns_groups_labels", "mdns_groups_mean_rounds",
     "mdns_backend_region_create", "mdns_backend_region_destroy", "mdns_backend_region_count",
     "mdns_backend_draw_begin", "mdns_backend_draw_chunk", "mdns_backend_chunk_size",
+    "mdns_backend_region_begin", "mdns_backend_region_radius",
 )
 
 #: the symbols of include/mdns.h Part 5 that live in libmdns_host.so (plain host code, no GPU)
@@ -159,6 +160,8 @@ def _declare(lib):
         "mdns_backend_draw_begin": (i, [vp, vp, i]),
         "mdns_backend_draw_chunk": (i, [vp, vp, i, vp, vp, vp, vp]),
         "mdns_backend_chunk_size": (i, [vp, i, i, i]),
+        "mdns_backend_region_begin": (vp, [vp, vp, i, i, vp, i]),
+        "mdns_backend_region_radius": (i, [vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -17,6 +17,7 @@ joint state / member-set implementation in Python -- the CPU oracle in tests), t
 transform and the two numpy operations the constrainer leaves to numpy.
 """
 import ctypes as C
+import os
 
 import numpy
 
@@ -32,6 +33,8 @@ _DRAW_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_int)
 _DRAW_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int),
                           C.POINTER(C.c_ulonglong), C.POINTER(C.c_int))
 _CHUNK_SIZE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
+_REGION_BEGIN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int)
+_REGION_RADIUS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double))
 _CUSTOM_PRIOR = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _VEC_POW = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double)
 _FIT_METRIC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int,
@@ -41,7 +44,9 @@ _FIT_METRIC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C
 class DrawBackend(C.Structure):            # mdns_draw_backend
     _fields_ = [("user", C.c_void_p), ("region_create", _REGION_CREATE), ("region_destroy", _REGION_DESTROY),
                 ("region_count", _REGION_COUNT), ("draw_begin", _DRAW_BEGIN), ("draw_chunk", _DRAW_CHUNK),
-                ("chunk_size", _CHUNK_SIZE)]
+                ("chunk_size", _CHUNK_SIZE),
+                # optional halves of region_create (NULL: not offered): K6 launched / its radius awaited
+                ("region_begin", _REGION_BEGIN), ("region_radius", _REGION_RADIUS)]
 
 
 class Prior(C.Structure):                  # mdns_prior
@@ -159,7 +164,9 @@ def hip_backend(joint):
                                ("region_count", _REGION_COUNT, "mdns_backend_region_count"),
                                ("draw_begin", _DRAW_BEGIN, "mdns_backend_draw_begin"),
                                ("draw_chunk", _DRAW_CHUNK, "mdns_backend_draw_chunk"),
-                               ("chunk_size", _CHUNK_SIZE, "mdns_backend_chunk_size")):
+                               ("chunk_size", _CHUNK_SIZE, "mdns_backend_chunk_size"),
+                               ("region_begin", _REGION_BEGIN, "mdns_backend_region_begin"),
+                               ("region_radius", _REGION_RADIUS, "mdns_backend_region_radius")):
         setattr(be, field, C.cast(getattr(lib, name), proto))
     be._keep = joint
     return be
@@ -196,7 +203,24 @@ def python_backend(joint, member_set_factory=None):
         except Exception:       # noqa: BLE001
             return None
 
+    radii = {}
+
+    def region_begin(user, members_ptr, K, ndim, packed_ptr, nboot):
+        # (nothing runs beside Python here: the two halves only keep the native side's bookkeeping honest)
+        radius = (C.c_double * 1)()
+        key = region_create(user, members_ptr, K, ndim, packed_ptr, nboot, radius)
+        if key is not None:
+            radii[key] = radius[0]
+        return key
+
+    def region_radius(_user, key, radius_ptr):
+        if key not in radii:
+            return 1
+        radius_ptr[0] = radii.pop(key)
+        return 0
+
     def region_destroy(_user, key):
+        radii.pop(key, None)
         ms = regions.pop(key, None)
         if ms is not None and hasattr(ms, "close"):
             ms.close()
@@ -251,6 +275,9 @@ def python_backend(joint, member_set_factory=None):
     be.user = None
     be.region_create = _REGION_CREATE(region_create)
     be.region_destroy = _REGION_DESTROY(region_destroy)
+    if os.environ.get("MDNS_PYTHON_BACKEND_ASYNC", "1") == "1":
+        be.region_begin = _REGION_BEGIN(region_begin)
+        be.region_radius = _REGION_RADIUS(region_radius)
     be.region_count = _REGION_COUNT(region_count)
     be.draw_begin = _DRAW_BEGIN(draw_begin)
     be.draw_chunk = _DRAW_CHUNK(draw_chunk)

@@ -215,13 +215,29 @@ struct Region {
 
 	~Region() { if (handle && be) be->region_destroy(be->user, handle); }
 
+	bool started = false;                 // K6 is running (region_begin): region_radius delivers
+
+	// K6 launched, nobody waits: what the caller does until it asks for `maxdistance` overlaps with it
+	// (backends without region_begin compute the radius when it is asked for)
+	bool start()
+	{
+		if (has_radius || started || !be->region_begin || !be->region_radius) return true;
+		const long long t0 = now_ns();
+		handle = be->region_begin(be->user, members.data(), K, ndim, masks.data(), nbootstraps);
+		if (stat) stat->add(T_REGION, now_ns() - t0);
+		if (!handle) { set_error("region_begin (K6) failed for %d points", K); return false; }
+		started = true;
+		return true;
+	}
 	// `maxdistance` of the reference: the bootstrapped radius, computed when first asked for
 	bool maxdistance(double *out)
 	{
 		if (!has_radius) {
 			double r = 0;
 			const long long t0 = now_ns();
-			handle = be->region_create(be->user, members.data(), K, ndim, masks.data(), nbootstraps, &r);
+			if (started) {
+				if (be->region_radius(be->user, handle, &r) != 0) { set_error("region_radius (K6) failed for %d points", K); return false; }
+			} else handle = be->region_create(be->user, members.data(), K, ndim, masks.data(), nbootstraps, &r);
 			if (stat) stat->add(T_REGION, now_ns() - t0);
 			if (!handle) { set_error("region_create (K6) failed for %d points", K); return false; }
 			radius = r;
@@ -291,6 +307,7 @@ struct mdns_constrainer {
 	RegionRef region;                      // `self.region` (may be empty: None)
 	bool has_prev = false;                 // `self.prev_maxdistance is not None`
 	double prev_maxdistance = 0;
+	RegionRef prev_region;                 // set: prev_maxdistance is THIS region's radius, not asked for yet
 	bool has_last = false;                 // `self.last_cluster_points`
 	std::vector<double> last_cluster_points;
 	int last_K = 0;
@@ -371,11 +388,24 @@ RegionRef new_region(Env &e, const double *members, int K, bool given, double ma
 // `force_shrink`: a rebuilt region may not have a larger radius than the one it replaces
 // (hiermetriclearn.py:53-54,88-90); `prev_maxdistance is None` counts as smaller than anything
 // (Python 2) and then the replacement draws its own bootstrap choice
+// `self.prev_maxdistance`: the radius of the region the last cluster() installed, whose K6 may
+// still be running
+bool prev_value(mdns_constrainer *c)
+{
+	if (!c->prev_region) return true;
+	double r;
+	if (!c->prev_region->maxdistance(&r)) return false;
+	c->prev_maxdistance = r;
+	c->prev_region.reset();
+	return true;
+}
+
 RegionRef never_grow(Env &e, RegionRef region, const double *members_old_metric, int K)
 {
 	mdns_constrainer *c = e.c;
 	if (!c->force_shrink) return region;
 	if (c->has_prev) {
+		if (!prev_value(c)) return RegionRef();
 		double r;
 		if (!region->maxdistance(&r)) return RegionRef();
 		if (!(r > c->prev_maxdistance)) return region;
@@ -429,9 +459,11 @@ bool cluster(Env &e, const double *u, int K, bool keepMetric)
 		}
 	}
 	c->region = region;
-	double r;
-	if (!region->maxdistance(&r)) return false;
-	c->prev_maxdistance = r;
+	// self.prev_maxdistance = self.region.maxdistance (hiermetriclearn.py:91): K6 starts here and
+	// the value is taken when somebody needs it -- the proposals of the generator draw their random
+	// numbers first (next_batch_inner)
+	if (!region->start()) return false;
+	c->prev_region = region;
 	c->has_prev = true;
 	return true;
 }
@@ -523,10 +555,19 @@ bool next_batch_inner(Env &e)
 			break;
 		case mdns_constrainer::BOX: {
 			Region *r = c->gen_region.get();
-			if (!c->gen_started) {
+			// numpy.random.uniform(lo, hi, size=(N, ndim)): lo + (hi - lo) * double, row by row.  The
+			// doubles do not depend on the box: a generator that starts draws them BEFORE it waits
+			// for the radius of its region, whose K6 cluster() has just launched (nothing else takes
+			// numbers from the stream in between, and a generator that starts always proposes:
+			// `proposed` is 0)
+			const bool starting = !c->gen_started;
+			if (starting) {
+				c->us.resize((size_t) N * ndim);
+				for (size_t t = 0; t < (size_t) N * ndim; t++) c->us[t] = mt_double(e.mt);
 				// like the reference, the ball proposals keep the members and the radius the generator
 				// started with (radfriendsregion.py:118-120)
 				if (!r->maxdistance(&c->gen_maxdistance)) return false;
+				if (c->prev_region.get() == r) { c->prev_maxdistance = c->gen_maxdistance; c->prev_region.reset(); }
 				c->gen_started = true;
 			}
 			if (!(c->proposed < REGION_BATCH)) {
@@ -538,13 +579,15 @@ bool next_batch_inner(Env &e)
 			c->proposed += N;
 			c->stat.add(N_PROPOSALS, N);
 			if (!r->box()) return false;
-			// numpy.random.uniform(lo, hi, size=(N, ndim)): lo + (hi - lo) * double, row by row
-			c->us.resize((size_t) N * ndim);
+			if (!starting) {
+				c->us.resize((size_t) N * ndim);
+				for (size_t t = 0; t < (size_t) N * ndim; t++) c->us[t] = mt_double(e.mt);
+			}
 			double range[MDNS_MAX_DIM];
 			for (int k = 0; k < ndim; k++) range[k] = r->hi[k] - r->lo[k];
 			for (int i = 0; i < N; i++)
 				for (int k = 0; k < ndim; k++) {
-					const double t = range[k] * mt_double(e.mt);
+					const double t = range[k] * c->us[(size_t) i * ndim + k];
 					c->us[(size_t) i * ndim + k] = r->lo[k] + t;
 				}
 			c->counts.resize(N);

@@ -967,12 +967,14 @@ extern "C" mdns_region *mdns_region_create(const double *members, int K, int ndi
 // Members and packed bootstrap choice staged together, K6 launched, radius waited for: what
 // RadFriendsRegion.__init__ (radfriendsregion.py:59-70) needs from the device, in ONE call --
 // one pinned staging copy, one H2D, one launch, one poll of the mapped result.
-extern "C" mdns_region *mdns_region_create_bootstrapped(const double *members, int K, int ndim,
-                                                        const unsigned *packed, int nbootstraps, double *radius)
+// wait == false: the radius stays in flight (mdns_region_radius waits for it); the pinned staging
+// block is busy until then -- the caller creates no other region meanwhile
+static mdns_region *create_bootstrapped(const double *members, int K, int ndim, const unsigned *packed, int nbootstraps,
+                                        double *radius, bool wait)
 {
 	Context *c = ctx();
 	if (!c) return nullptr;
-	if (!members || !packed || !radius || K <= 0 || ndim <= 0 || nbootstraps <= 0 || nbootstraps > 16) {
+	if (!members || !packed || (wait && !radius) || K <= 0 || ndim <= 0 || nbootstraps <= 0 || nbootstraps > 16) {
 		set_error("mdns_region_create_bootstrapped: bad arguments (K=%d ndim=%d rounds=%d)", K, ndim, nbootstraps);
 		return nullptr;
 	}
@@ -997,9 +999,21 @@ extern "C" mdns_region *mdns_region_create_bootstrapped(const double *members, i
 	}
 	r->on_device = true;
 	r->pending = true;
+	if (!wait) return r;
 	*radius = mdns_region_radius(r);          // waits: the pinned staging block is free again
 	if (*radius != *radius) { mdns_region_destroy(r); return nullptr; }
 	return r;
+}
+
+extern "C" mdns_region *mdns_region_create_bootstrapped(const double *members, int K, int ndim,
+                                                        const unsigned *packed, int nbootstraps, double *radius)
+{
+	return create_bootstrapped(members, K, ndim, packed, nbootstraps, radius, true);
+}
+
+mdns_region *mdns::region_begin_bootstrapped(const double *members, int K, int ndim, const unsigned *packed, int nbootstraps)
+{
+	return create_bootstrapped(members, K, ndim, packed, nbootstraps, nullptr, false);
 }
 
 extern "C" mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int ndim)

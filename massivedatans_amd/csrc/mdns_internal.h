@@ -175,6 +175,9 @@ struct BootstrapFinish {
 
 // threshold on the squared distance: thresh_sq, or -- when d_res != nullptr -- the one the
 // preceding radius computation left on the device
+// mdns_region_create_bootstrapped without the wait for the radius (mdns_core.hip)
+mdns_region *region_begin_bootstrapped(const double *members, int K, int ndim, const unsigned *packed, int nbootstraps);
+
 // mail != nullptr: `d_cands` and `d_counts` may be host memory mapped into the device -- the kernel
 // reads the candidates from there, stores the counts there (no member split) and its last
 // workgroup raises *seq_at to `seq`: the host polls instead of copying both ways

@@ -980,6 +980,20 @@ extern "C" void *mdns_backend_region_create(void *joint, const double *members, 
 	return r;
 }
 
+extern "C" void *mdns_backend_region_begin(void *joint, const double *members, int K, int ndim, const unsigned *packed, int nbootstraps)
+{
+	(void) joint;
+	return region_begin_bootstrapped(members, K, ndim, packed, nbootstraps);
+}
+
+extern "C" int mdns_backend_region_radius(void *joint, void *region, double *radius)
+{
+	(void) joint;
+	if (!region || !radius) { set_error("mdns_backend_region_radius: null argument"); return 1; }
+	*radius = mdns_region_radius((mdns_region *) region);
+	return *radius != *radius;
+}
+
 extern "C" void mdns_backend_region_destroy(void *joint, void *region)
 {
 	(void) joint;
