@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 	if (mail.seq_at) {
 		// `counts` is host memory mapped into the device (no member split: plain stores): once every
 		// workgroup's stores are out, the last one to get here raises `seq` for the polling host
-		__threadfence_system();
+		if (wv == 0) __threadfence_system();                      // (only wave 0 stored)
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			const int done = atomicAdd(mail.ticket, 1);

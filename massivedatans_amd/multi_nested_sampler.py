@@ -557,10 +557,11 @@ class MultiNestedSampler(object):
         reference obtains from igraph (multi_nested_sampler.py:268-355): components in order of
         their lowest data-set index, point ids ascending (igraph numbers the vertices of a
         subgraph in the order they had in the graph -- data sets first, then points by id -- and
-        lists a cluster's vertices in that order).  igraph is not available in this image, so the
-        ORDER is restated from igraph's documented behaviour and is not pinned against a
-        reference run; the PARTITION is that of the pinned walk (the components come from the
-        same native code) and is cross-checked against networkx in tests/test_sampler_units.py."""
+        lists a cluster's vertices in that order).  igraph is not available in this image: the ORDER is
+        pinned against runs of the reference's own generate_subsets_graph over a stand-in that
+        restates igraph's documented numbering (tests/golden/trace_*_graph.npz, oracle/make_trace.py)
+        -- i.e. up to igraph's own contract; the PARTITION is that of the pinned walk and is
+        cross-checked against networkx in tests/test_sampler_units.py."""
         dg = self._device_groups()
         if dg is not None:
             selected = numpy.flatnonzero(data_mask)

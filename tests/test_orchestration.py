@@ -71,8 +71,8 @@ def test_trace_bit_exact(case, mode, oracle, monkeypatch):
 
 
 def test_graph_grouping_is_the_same_partition(oracle, monkeypatch):
-    """``generate_subsets_graph`` (connected components; igraph ordering restated, not pinned)
-    must at least produce the same PARTITION of data sets and live points as the pinned
+    """``generate_subsets_graph`` (connected components; its ORDER is pinned by the ``*_graph`` traces
+    above, up to igraph's contract) must also produce the same PARTITION of data sets and live points as the pinned
     ``generate_subsets_nograph`` walk, on real sampler states where the data sets have split."""
     from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
     patch_neighbors(monkeypatch, oracle)

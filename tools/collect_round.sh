@@ -35,5 +35,13 @@ for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU" \
     rocprofv3 --pmc $set --output-format csv -d "$out/k6_5000/sq$i" -- python3 tools/k6_one.py 5000 > "$out/k6_5000_sq$i.log" 2>&1 || echo "counter set $i failed"
 done
 find "$out" -name "*_kernel_trace.csv" -delete
+# the accept pass of issue-bound chunks: chain kernel against the matrix-core filter
+for shape in "10000 256" "10000 128" "50000 256" "10000 1024"; do
+    for m in 0 mfma; do MDNS_K1_FILTER=$m python tools/filter_bench.py $shape 2>&1 | tail -1; done
+done > "$out/filter_bench.jsonl"
+for p in 1 2 3; do MDNS_FILTER_PROBE=$p MDNS_K1_FILTER=mfma python tools/filter_bench.py 10000 256 2>&1 | tail -1; done > "$out/filter_probes.jsonl"
+python tools/k6_gy_sweep.py > "$out/k6_gy_sweep.log" 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_f64_probe.hip -o /tmp/mfma_probe 2>/dev/null && /tmp/mfma_probe > "$out/mfma_f64_probe.log" 2>&1
+hipcc --offload-arch=gfx950 -O3 tools/probes/valu_rate_probe.hip -o /tmp/valu_probe 2>/dev/null && /tmp/valu_probe > "$out/valu_rate_probe.log" 2>&1
 du -sh "$out"
 echo collected "$out"
