@@ -367,6 +367,8 @@ struct mdns_joint {
 	bool prepared = false;
 	// what mdns_joint_score staged for the commit that follows
 	bool staged_rows = false;
+	bool staged_valid = false;                              // a host-pointer score is waiting for its commit
+	int scored_M = -1;                                      // selection size of the score whose flags / trail are in place (-1: none)
 	int staged_M = 0;
 	size_t staged_in_bytes = 0;
 	double noise_level = 0;            // of mdns_joint_init_gauss (the backend entry points score with it)
@@ -757,6 +759,7 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 	j->trail_valid = false;
 	if (B == 0 || M == 0) {
 		// nothing to score: no flag can be set; still hand commit a clean header
+		j->scored_M = M;
 		return MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kZeroInts * sizeof(int), c->stream)) ? 0 : 1;
 	}
 	const double scale = -0.5 / (noise_level * noise_level);
@@ -796,6 +799,7 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 	} else if (!launch_gauss_cols_accept(s, yT, s->d_model, bt, B, scale, gather, d_row_ids, M, j->st.higher, j->d_flags, trail)) return 1;
 	j->trail_valid = true;
 	j->last_yT = yT; j->last_gather = gather; j->last_bt = bt; j->last_B = B; j->last_scale = scale;
+	j->scored_M = M;
 	return 0;
 }
 
@@ -806,6 +810,12 @@ static int joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M, bool wan
 {
 	Context *c = ctx();
 	if (!c || !check_draw(j, 0, M, who)) return 1;
+	// flags and trail belong to ONE score: the commit must name the same selection size, once
+	if (j->scored_M != M) {
+		set_error("%s: M=%d, but the score that precedes had M=%d (-1: none, or already committed)", who, M, j->scored_M);
+		return 1;
+	}
+	j->scored_M = -1;
 	if (j->last_B == 0 || M == 0) {
 		// an empty chunk accepts nothing (no kernel runs: the mailbox is filled from here, once
 		// whatever may still be writing to it has finished)
@@ -906,13 +916,18 @@ static int joint_stage_and_score(mdns_joint *j, const double *params, int B, dou
 	j->staged_rows = row_ids != nullptr;
 	j->staged_M = M;
 	j->staged_in_bytes = in_bytes;
-	return mdns_joint_score_dev(j, j->d_params, B, noise_level, row_ids ? j->d_rows : nullptr, M);
+	const int rc = mdns_joint_score_dev(j, j->d_params, B, noise_level, row_ids ? j->d_rows : nullptr, M);
+	j->staged_valid = rc == 0;
+	return rc;
 }
 
 static int joint_commit_and_fetch(mdns_joint *j, int *accepted, double *Lrow, unsigned long long *fillbits, const char *who)
 {
 	Context *c = ctx();
 	if (!c || !j) return 1;
+	// (the selection, its size and the pinned block are those of the mdns_joint_score that precedes)
+	if (!j->staged_valid) { set_error("%s: no mdns_joint_score with host pointers precedes this commit", who); return 1; }
+	j->staged_valid = false;
 	const int M = j->staged_M;
 	if (joint_commit_dev(j, j->staged_rows ? j->d_rows : nullptr, M, Lrow != nullptr, who) != 0) return 1;
 	if (!Lrow) {

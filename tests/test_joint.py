@@ -224,6 +224,28 @@ def test_long_shelves_purge_and_threshold():
     dev.close()
 
 
+def test_commit_without_its_score_is_refused(hip):
+    """Flags and trail of the accept pass belong to one score: a second commit, a commit that names
+    another selection size, or a host-pointer commit with nothing scored fail with a message."""
+    from massivedatans_amd import _lib
+    import ctypes as C
+    ndata, nlive = 130, 8
+    rng = np.random.RandomState(2)
+    data = gen.horns(ndata)
+    spectra = GaussLineSpectra(data["x"], data["y"], noise_level=0.01)
+    js = jointstate.GaussJointState(spectra, nlive, sample.kernel_params, fetch_rows=False)
+    js.init(sample.priortransform_batch(rng.uniform(size=(nlive, 3))))
+    js.prepare()
+    accepted = C.c_int(0)
+    assert hip.mdns_joint_commit(js._h, C.byref(accepted), None, None) != 0        # nothing scored yet
+    assert b"score" in hip.mdns_last_error()
+    js.draw(sample.priortransform_batch(rng.uniform(size=(5, 3))), None)             # score + commit
+    assert hip.mdns_joint_commit_bits_dev(js._h, None, ndata) != 0                   # that score is used up
+    assert b"score" in hip.mdns_last_error()
+    js.draw(sample.priortransform_batch(rng.uniform(size=(5, 3))), None)             # and the state still works
+    js.close()
+
+
 def test_chunk_with_no_acceptable_candidate_changes_nothing():
     ndata, nlive = 200, 20
     rng = np.random.RandomState(11)
