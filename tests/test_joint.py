@@ -86,7 +86,8 @@ def _drive(dev, host, ndata, rng, iterations, exact):
 
 
 @pytest.mark.parametrize("fetch_rows", [True, False, "backend"])
-@pytest.mark.parametrize("ndata,nlive,nx", [(1, 5, 200), (7, 9, 33), (100, 50, 200), (1000, 40, 200), (4100, 25, 64), (700, 30, 201)])
+@pytest.mark.parametrize("ndata,nlive,nx", [(1, 5, 200), (7, 9, 33), (100, 50, 200), (1000, 40, 200), (4100, 25, 64), (700, 30, 201),
+                                           (90, 150, 48)])        # more live points than a data set's sixteen lanes hold in registers (128)
 def test_joint_state_equals_its_numpy_statement(ndata, nlive, nx, fetch_rows):
     """fetch_rows=False: the outcome of a draw -- index, fill bits -- arrives in mapped host memory
     the commit kernel writes (mdns.h, mdns_joint_fetch), the likelihood row stays on the device;
