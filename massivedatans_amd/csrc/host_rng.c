@@ -82,9 +82,55 @@ static inline __attribute__((always_inline)) void mt_refill(mdns_mt19937 *s)
  * rejected: 9 ns per draw with a branch, 3 with one branch-free loop, under 2 split in three).  A run of draws is never longer than the number of points still to be drawn, so
  * the generator stops exactly where numpy's one-at-a-time loop stops. */
 #if defined(__x86_64__) && defined(__GNUC__)
-#define MDNS_CLONES __attribute__((target_clones("avx2", "default")))      /* wider tempering loops where the CPU has them */
+#define MDNS_CLONES __attribute__((target_clones("avx512f", "avx2", "default")))      /* wider tempering loops where the CPU has them */
 #else
 #define MDNS_CLONES
+#endif
+
+/* Tempering of n state words and the accepted values (<= top after masking with `cover`) packed
+ * together, in draw order: returns how many.  AVX-512: sixteen words per step, the accepted ones
+ * compressed to the front of a register (the scalar form spends a store and an add per word on it). */
+#if defined(__x86_64__) && defined(__GNUC__)
+#include <immintrin.h>
+#include <stdlib.h>
+__attribute__((target("avx512f")))
+static int64_t temper_pack_avx512(const uint32_t *key, int64_t n, uint32_t cover, uint32_t top, uint32_t *taken)
+{
+	const __m512i c1 = _mm512_set1_epi32((int) 0x9d2c5680u), c2 = _mm512_set1_epi32((int) 0xefc60000u);
+	const __m512i vcover = _mm512_set1_epi32((int) cover), vtop = _mm512_set1_epi32((int) top);
+	int64_t got = 0;
+	for (int64_t i = 0; i < n; i += 16) {
+		const __mmask16 live = n - i >= 16 ? (__mmask16) 0xffff : (__mmask16) ((1u << (n - i)) - 1u);
+		__m512i y = _mm512_maskz_loadu_epi32(live, key + i);
+		y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 11));
+		y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 7), c1));
+		y = _mm512_xor_si512(y, _mm512_and_si512(_mm512_slli_epi32(y, 15), c2));
+		y = _mm512_xor_si512(y, _mm512_srli_epi32(y, 18));
+		y = _mm512_and_si512(y, vcover);
+		const __mmask16 ok = _mm512_mask_cmple_epu32_mask(live, y, vtop);
+		/* (compress in a register + one full store: the store form of vpcompressd is microcoded on
+		 * Zen 4/5; `taken` has sixteen words of slack) */
+		_mm512_storeu_si512((void *) (taken + got), _mm512_maskz_compress_epi32(ok, y));
+		got += __builtin_popcount((unsigned) ok);
+	}
+	return got;
+}
+static int have_avx512(void)
+{
+	static int known = -1;
+	if (known < 0) {
+		const char *off = getenv("MDNS_HOST_NO_AVX512");                 /* tests compare the two forms */
+		known = (off && off[0] == '1') ? 0 : (__builtin_cpu_supports("avx512f") ? 1 : 0);
+	}
+	return known;
+}
+#else
+static int have_avx512(void) { return 0; }
+static int64_t temper_pack_avx512(const uint32_t *key, int64_t n, uint32_t cover, uint32_t top, uint32_t *taken)
+{
+	(void) key; (void) n; (void) cover; (void) top; (void) taken;
+	return 0;
+}
 #endif
 
 /* The same draws WITHOUT the choice: the stream is left where mdns_host_bootstrap_masks_mt would
@@ -139,7 +185,8 @@ int mdns_host_bootstrap_masks_mt(void *state, int64_t K, int rounds, uint32_t *m
 	const uint32_t top = (uint32_t) top64;
 	uint32_t cover = top;
 	cover |= cover >> 1; cover |= cover >> 2; cover |= cover >> 4; cover |= cover >> 8; cover |= cover >> 16;
-	uint32_t vals[624], taken[625];
+	uint32_t vals[624], taken[624 + 16];
+	const int wide = have_avx512();
 	for (int b = 0; b < rounds; b++) {
 		const uint32_t bit = 1u << b;
 		int64_t need = K;
@@ -150,18 +197,21 @@ int mdns_host_bootstrap_masks_mt(void *state, int64_t K, int rounds, uint32_t *m
 			const uint32_t *key = s->key + s->pos;
 			/* three short loops instead of one: tempering (vectorised by the compiler), the
 			 * accepted values packed together without a branch, then the scatter */
-			for (int64_t i = 0; i < n; i++) {
-				uint32_t y = key[i];
-				y ^= (y >> 11);
-				y ^= (y << 7) & 0x9d2c5680u;
-				y ^= (y << 15) & 0xefc60000u;
-				y ^= (y >> 18);
-				vals[i] = y & cover;
-			}
 			int64_t got = 0;
-			for (int64_t i = 0; i < n; i++) {
-				taken[got] = vals[i];
-				got += vals[i] <= top;
+			if (wide) got = temper_pack_avx512(key, n, cover, top, taken);
+			else {
+				for (int64_t i = 0; i < n; i++) {
+					uint32_t y = key[i];
+					y ^= (y >> 11);
+					y ^= (y << 7) & 0x9d2c5680u;
+					y ^= (y << 15) & 0xefc60000u;
+					y ^= (y >> 18);
+					vals[i] = y & cover;
+				}
+				for (int64_t i = 0; i < n; i++) {
+					taken[got] = vals[i];
+					got += vals[i] <= top;
+				}
 			}
 			for (int64_t i = 0; i < got; i++) masks[taken[i]] |= bit;
 			s->pos += (int) n;

@@ -225,6 +225,20 @@ def test_bootstrap_choice_consumes_the_rng_like_the_reference():
             assert np.array_equal(unpack_bootstrap_masks(masks, B), want)
 
 
+def test_bootstrap_choice_without_avx512():
+    """The same check with the AVX-512 form of the tempering / packing loop switched off (the
+    library decides once per process: a child process with MDNS_HOST_NO_AVX512=1), so that both
+    forms are compared with numpy wherever the tests run."""
+    import os, subprocess, sys
+    if os.environ.get("MDNS_HOST_NO_AVX512") == "1":
+        pytest.skip("already the scalar form")
+    env = dict(os.environ, MDNS_HOST_NO_AVX512="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "not gpu",
+                          __file__ + "::test_bootstrap_choice_consumes_the_rng_like_the_reference"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
 def test_incremental_grouping_walk_on_shrinking_selections():
     """The passes of one iteration ask for the groups of smaller and smaller selections of the
     same id matrix: the incremental native walk (one holder index per iteration, counts kept up
