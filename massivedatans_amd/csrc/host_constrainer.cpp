@@ -242,7 +242,9 @@ struct Counters {
 };
 
 struct Region {
-	std::vector<double> members;          // [K, ndim], the metric's coordinates
+	std::shared_ptr<const std::vector<double>> points;   // [K, ndim], the metric's coordinates (shared: the regions a
+	                                                     // cluster() call makes of the same live points hold ONE copy)
+	const double *members = nullptr;      // = points->data()
 	int K = 0, ndim = 0;
 	bool has_radius = false;
 	double radius = 0;
@@ -264,7 +266,7 @@ struct Region {
 	{
 		if (has_radius || started || !be->region_begin || !be->region_radius) return true;
 		const long long t0 = now_ns();
-		handle = be->region_begin(be->user, members.data(), K, ndim, masks.data(), nbootstraps);
+		handle = be->region_begin(be->user, members, K, ndim, masks.data(), nbootstraps);
 		if (stat) stat->add(T_REGION, now_ns() - t0);
 		if (!handle) { set_error("region_begin (K6) failed for %d points", K); return false; }
 		started = true;
@@ -278,7 +280,7 @@ struct Region {
 			const long long t0 = now_ns();
 			if (started) {
 				if (be->region_radius(be->user, handle, &r) != 0) { set_error("region_radius (K6) failed for %d points", K); return false; }
-			} else handle = be->region_create(be->user, members.data(), K, ndim, masks.data(), nbootstraps, &r);
+			} else handle = be->region_create(be->user, members, K, ndim, masks.data(), nbootstraps, &r);
 			if (stat) stat->add(T_REGION, now_ns() - t0);
 			if (!handle) { set_error("region_create (K6) failed for %d points", K); return false; }
 			radius = r;
@@ -295,7 +297,7 @@ struct Region {
 		if (!maxdistance(&r)) return false;
 		if (!handle) {
 			const long long t0 = now_ns();
-			handle = be->region_create(be->user, members.data(), K, ndim, nullptr, 0, &r);
+			handle = be->region_create(be->user, members, K, ndim, nullptr, 0, &r);
 			if (stat) stat->add(T_REGION, now_ns() - t0);
 			if (!handle) { set_error("region_create failed for %d points", K); return false; }
 		}
@@ -397,10 +399,13 @@ struct Env {
 // `discarded`: the caller replaces this region before anybody can ask it for anything -- its
 // bootstrap choice is drawn from the stream (the position of the draws is part of the results) but
 // not kept
-RegionRef new_region(Env &e, const double *members, int K, bool given, double maxdistance, bool discarded = false)
+typedef std::shared_ptr<const std::vector<double>> Points;
+
+RegionRef new_region(Env &e, const Points &members, int K, bool given, double maxdistance, bool discarded = false)
 {
 	RegionRef r = std::make_shared<Region>();
-	r->members.assign(members, members + (size_t) K * e.c->ndim);
+	r->points = members;
+	r->members = members->data();
 	r->K = K;
 	r->ndim = e.c->ndim;
 	r->be = e.be;
@@ -441,7 +446,7 @@ bool prev_value(mdns_constrainer *c)
 	return true;
 }
 
-RegionRef never_grow(Env &e, RegionRef region, const double *members_old_metric, int K)
+RegionRef never_grow(Env &e, RegionRef region, const Points &members_old_metric, int K)
 {
 	mdns_constrainer *c = e.c;
 	if (!c->force_shrink) return region;
@@ -460,14 +465,15 @@ bool cluster(Env &e, const double *u, int K, bool keepMetric)
 {
 	mdns_constrainer *c = e.c;
 	const int ndim = c->ndim;
-	std::vector<double> w_old((size_t) K * ndim);
-	c->metric.transform(u, K, ndim, w_old.data());
+	auto w_old_store = std::make_shared<std::vector<double>>((size_t) K * ndim);
+	c->metric.transform(u, K, ndim, w_old_store->data());
+	const Points w_old = w_old_store;
 	RegionRef region;
 	if (keepMetric) {
 		// (with force_shrink and no previous radius never_grow replaces it at once, hiermetriclearn.py:53-54)
-		region = new_region(e, w_old.data(), K, false, 0, c->force_shrink && !c->has_prev);
+		region = new_region(e, w_old, K, false, 0, c->force_shrink && !c->has_prev);
 		if (!region) return false;
-		region = never_grow(e, region, w_old.data(), K);
+		region = never_grow(e, region, w_old, K);
 		if (!region) return false;
 	} else {
 		bool changed = false;
@@ -489,13 +495,13 @@ bool cluster(Env &e, const double *u, int K, bool keepMetric)
 			}
 			c->metric = m;
 		}
-		std::vector<double> w_new((size_t) K * ndim);
-		c->metric.transform(u, K, ndim, w_new.data());
-		region = new_region(e, w_new.data(), K, false, 0);
+		auto w_new = std::make_shared<std::vector<double>>((size_t) K * ndim);
+		c->metric.transform(u, K, ndim, w_new->data());
+		region = new_region(e, Points(w_new), K, false, 0);
 		if (!region) return false;
 		// only a region in the SAME metric is comparable with the previous radius
 		if (!changed && c->has_prev) {
-			region = never_grow(e, region, w_old.data(), K);
+			region = never_grow(e, region, w_old, K);
 			if (!region) return false;
 		}
 	}
@@ -512,16 +518,21 @@ bool cluster(Env &e, const double *u, int K, bool keepMetric)
 void reset_buffer(mdns_constrainer *c) { c->has_buf = false; c->buf_n = 0; c->buf_pos = 0; c->buf_ntotal = 0; }
 
 // rebuild(u, keepMetric) (hiermetriclearn.py:139-150)
-bool rebuild(Env &e, const double *u, int K, bool keepMetric)
+// (`points` is given up when a new region is built -- it becomes `last_cluster_points` without
+// another copy -- and `*taken` says so: a later rebuild of the same draw with the same points
+// would find them identical and do nothing, hiermetriclearn.py:141-143)
+bool rebuild(Env &e, std::vector<double> &points, int K, bool keepMetric, bool *taken)
 {
 	mdns_constrainer *c = e.c;
+	const double *u = points.data();
 	const size_t n = (size_t) K * c->ndim;
 	if (c->has_last && c->last_K == K && memcmp(c->last_cluster_points.data(), u, n * sizeof(double)) == 0) {
 		// (memcmp equality is numpy's element-wise == for the finite unit-cube points of a pile)
 		return true;                        // identical live points: keep region AND generator
 	}
 	if (!cluster(e, u, K, keepMetric)) return false;
-	c->last_cluster_points.assign(u, u + n);
+	c->last_cluster_points.swap(points);
+	*taken = true;
 	c->last_K = K;
 	c->has_last = true;
 	c->has_generator = true;
@@ -876,8 +887,9 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 	const bool region_due = !c->region || c->ndraws_since_rebuild > c->rebuild_every;
 	const bool metric_due = c->iter_since_metric_rebuild > c->metric_rebuild_every;
 	bool region_rebuilt = false, metric_rebuilt = false;
+	bool u_taken = false;                  // `u` went into the constrainer (the points of its current region)
 	if (region_due) {
-		if (!rebuild(e, u.data(), K, !metric_due)) return 1;
+		if (!rebuild(e, u, K, !metric_due, &u_taken)) return 1;
 		c->ndraws_since_rebuild = 0;
 		if (metric_due) c->iter_since_metric_rebuild = 0;
 		region_rebuilt = true;
@@ -971,11 +983,11 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 		// (hiermetriclearn.py:198-211); the candidate stream restarts from the new region
 		if (!region_rebuilt && c->ndraws_since_rebuild > c->rebuild_every) {
 			region_rebuilt = true;
-			if (!rebuild(e, u.data(), K, true)) return 1;
+			if (!u_taken && !rebuild(e, u, K, true, &u_taken)) return 1;
 			c->ndraws_since_rebuild = 0;
 		} else if (!metric_rebuilt && tries > 200) {
 			metric_rebuilt = true;
-			if (!rebuild(e, u.data(), K, false)) return 1;
+			if (!u_taken && !rebuild(e, u, K, false, &u_taken)) return 1;
 			c->iter_since_metric_rebuild = 0;
 		}
 	}
