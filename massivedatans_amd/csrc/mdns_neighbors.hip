@@ -572,7 +572,11 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	if (tile_n <= 0) { set_error("ndim=%d too large for the member tile", ndim); return false; }
 	// few candidates: 16 per workgroup and 16 member slices (latency shape)
 	const bool small = (M + 63) / 64 < 2 * c->num_cus;
-	const int pts = small ? 16 : 64;
+	// with a mailbox the members are not split between workgroups (no partial counts): 4 points per
+	// workgroup and 64 member slices instead, so that the ~1000 proposals of a membership call
+	// still make 250 workgroups (16 points x 16 slices: 63 workgroups, 20 us per call in a real run)
+	const bool fine = mail != nullptr && small;
+	const int pts = fine ? 4 : (small ? 16 : 64);
 	const int gx = (M + pts - 1) / pts;
 	// split the members between workgroups until the grid covers the chip about twice
 	int want = (2 * c->num_cus + gx - 1) / gx;
@@ -589,7 +593,9 @@ bool launch_count_within(const double *d_members, int K, int ndim, double thresh
 	const size_t lds = (size_t) tile_n * ndim * sizeof(double) + fixed;
 	dim3 grid(gx, gy);
 	ProfileScope prof(2);
-#define COUNT_LAUNCH(D) do { if (small) hipLaunchKernelGGL((k_count_within<D, 4>), grid, dim3(kBlock), lds, c->stream, \
+#define COUNT_LAUNCH(D) do { if (fine) hipLaunchKernelGGL((k_count_within<D, 16>), grid, dim3(kBlock), lds, c->stream, \
+		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate, post); \
+	else if (small) hipLaunchKernelGGL((k_count_within<D, 4>), grid, dim3(kBlock), lds, c->stream, \
 		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate, post); \
 	else hipLaunchKernelGGL((k_count_within<D, 1>), grid, dim3(kBlock), lds, c->stream, \
 		d_members, K, ndim, thresh_sq, d_res, d_cands, M, d_counts, kchunk, tile_n, accumulate, post); } while (0)
