@@ -379,6 +379,10 @@ int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M, long long
  * which numbers them by their first vertex); point_labels int32[npoints] = the label of the
  * component holding live point q, -1 when no selected data set holds it.  Either may be NULL. */
 int mdns_groups_labels(mdns_groups *g, int32_t *labels, int32_t *point_labels);
+/* The same for the ids the last mdns_groups_components listed only: id_labels int32[ndistinct], in the
+ * order of that list (a full mdns_groups_labels copies one label per id of the PILE, megabytes late in
+ * a run, of which the caller looks at the listed ones). */
+int mdns_groups_id_labels(mdns_groups *g, int32_t *labels, int32_t *id_labels, long long ndistinct);
 /* rounds of label propagation per mdns_groups_components call so far, on average */
 double mdns_groups_mean_rounds(const mdns_groups *g);
 

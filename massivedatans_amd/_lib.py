@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "mdns_joint_result_dev", "mdns_joint_result_bytes", "mdns_joint_fetch", "mdns_joint_prepare_dev", "mdns_joint_advance_dev",
     "mdns_joint_restore_live_dev", "mdns_joint_undo_advance_dev", "mdns_joint_live_dev",
     "mdns_groups_create", "mdns_groups_destroy", "mdns_groups_set_ids", "mdns_groups_get_ids",
-    "mdns_groups_replace", "mdns_groups_components", "mdns_groups_labels", "mdns_groups_mean_rounds",
+    "mdns_groups_replace", "mdns_groups_components", "mdns_groups_labels", "mdns_groups_id_labels", "mdns_groups_mean_rounds",
     "mdns_backend_region_create", "mdns_backend_region_destroy", "mdns_backend_region_count",
     "mdns_backend_draw_begin", "mdns_backend_draw_chunk", "mdns_backend_chunk_size",
     "mdns_backend_region_begin", "mdns_backend_region_radius",
@@ -153,6 +153,7 @@ def _declare(lib):
         "mdns_groups_replace": (i, [vp, vp, vp, vp, i]),
         "mdns_groups_components": (i, [vp, vp, i, C.c_longlong, vp, vp, vp, C.c_longlong, vp]),
         "mdns_groups_labels": (i, [vp, vp, vp]),
+        "mdns_groups_id_labels": (i, [vp, vp, vp, C.c_longlong]),
         "mdns_groups_mean_rounds": (d, [vp]),
         "mdns_backend_region_create": (vp, [vp, vp, i, i, vp, i, vp]),
         "mdns_backend_region_destroy": (None, [vp, vp]),

@@ -252,6 +252,16 @@ __global__ __launch_bounds__(kBlock) void k_groups_point_labels(const PLabel *__
 	point_labels[q] = (int) (w >> 32) == call ? (int) (unsigned) w : -1;
 }
 
+// labels of the ids a components call listed (its ascending list is still in `list`), in that order
+__global__ __launch_bounds__(kBlock) void k_groups_id_labels(const PLabel *__restrict__ plabel, const int *list, long long n,
+                                                             int call, int *out)
+{
+	const long long e = (long long) blockIdx.x * kBlock + threadIdx.x;
+	if (e >= n) return;
+	const PLabel w = plabel[list[e]];
+	out[e] = (int) (w >> 32) == call ? (int) (unsigned) w : -1;
+}
+
 __global__ __launch_bounds__(kBlock) void k_groups_replace(int *__restrict__ idsT, int ndata, int nlive,
                                                            const int *__restrict__ rows, const int *__restrict__ slots,
                                                            const int *__restrict__ new_ids, int n, int *__restrict__ status)
@@ -281,7 +291,7 @@ struct mdns_groups {
 	GroupsBox *h_box = nullptr, *h_box_dev = nullptr;  long long box_cap = 0;   // room for box_cap ids
 	unsigned long long box_seq = 0;
 	bool have_ids = false;
-	int last_M = -1;  long long last_npoints = 0;      // of the last components call (-1: ids changed since)
+	int last_M = -1;  long long last_npoints = 0, last_ndistinct = 0;      // of the last components call (-1: ids changed since)
 	int rounds_hint = 4;                               // rounds the next call launches before it looks
 	int call = 0;                                      // number of the current components call (stamps)
 	int label_call = 0;                                // the stamp the point labels of the last call carry
@@ -532,7 +542,7 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		if (!MDNS_HIP(hipMemcpyAsync(touched, touched_of(g), nw * 8, hipMemcpyDeviceToHost, c->stream)) ||
 		    !MDNS_HIP(hipStreamSynchronize(c->stream))) return 1;
 	}
-	g->last_M = M; g->last_npoints = npoints;
+	g->last_M = M; g->last_npoints = npoints; g->last_ndistinct = nd;
 	g->label_call = call;
 	return 0;
 }
@@ -543,6 +553,27 @@ extern "C" double mdns_groups_mean_rounds(const mdns_groups *g)
 	return g && g->calls_total ? (double) g->rounds_total / (double) g->calls_total : 0.0;
 }
 
+extern "C" int mdns_groups_id_labels(mdns_groups *g, int32_t *labels, int32_t *id_labels, long long ndistinct)
+{
+	Context *c = ctx();
+	if (!c || !g) return 1;
+	if (g->last_M <= 0) { set_error("mdns_groups_id_labels: no components computed since the ids last changed"); return 1; }
+	if (ndistinct != g->last_ndistinct) { set_error("mdns_groups_id_labels: %lld ids asked for, the last call listed %lld", ndistinct, g->last_ndistinct); return 1; }
+	const int M = g->last_M;
+	// the list of the last call is still in the compaction's scratch; every entry is replaced by its
+	// label in place (a thread reads its own entry, then writes it), so this works once per call
+	int *list = pout_of(g), *out = pout_of(g);
+	if (id_labels && ndistinct > 0) {
+		g->last_ndistinct = -1;
+		hipLaunchKernelGGL(k_groups_id_labels, dim3((unsigned) ((ndistinct + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
+		                   plabel_of(g), (const int *) list, ndistinct, g->label_call, out);
+		if (!MDNS_HIP(hipGetLastError())) return 1;
+	}
+	if (labels && !MDNS_HIP(hipMemcpyAsync(labels, g->d_labels, (size_t) M * 4, hipMemcpyDeviceToHost, c->stream))) return 1;
+	if (id_labels && ndistinct > 0 && !MDNS_HIP(hipMemcpyAsync(id_labels, out, (size_t) ndistinct * 4, hipMemcpyDeviceToHost, c->stream))) return 1;
+	return MDNS_HIP(hipStreamSynchronize(c->stream)) ? 0 : 1;
+}
+
 extern "C" int mdns_groups_labels(mdns_groups *g, int32_t *labels, int32_t *point_labels)
 {
 	Context *c = ctx();
@@ -550,6 +581,7 @@ extern "C" int mdns_groups_labels(mdns_groups *g, int32_t *labels, int32_t *poin
 	if (g->last_M <= 0) { set_error("mdns_groups_labels: no components computed since the ids last changed"); return 1; }
 	const int M = g->last_M;
 	const long long np = g->last_npoints;
+	if (point_labels) g->last_ndistinct = -1;                          // (the labels overwrite the list of the last call)
 	if (point_labels)
 		hipLaunchKernelGGL(k_groups_point_labels, dim3((unsigned) ((np + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream,
 		                   plabel_of(g), np, g->label_call, pout_of(g));

@@ -107,6 +107,17 @@ class DeviceGroups(object):
         _lib.check(self._lib.mdns_groups_labels(self._h, _lib.ptr(labels), _lib.ptr(point_labels)), "mdns_groups_labels")
         return labels, point_labels
 
+    def labels_of_ids(self, ndistinct):
+        """Of the last :meth:`components`: (label of every selected data set, label of every id IT
+        LISTED, in the order of that list) -- a few thousand numbers instead of one per id of the
+        pile; once per components call."""
+        M = self.ndata if self._rows is None else len(self._rows)
+        labels = np.empty(M, dtype=np.int32)
+        id_labels = np.empty(int(ndistinct), dtype=np.int32)
+        _lib.check(self._lib.mdns_groups_id_labels(self._h, _lib.ptr(labels), _lib.ptr(id_labels), int(ndistinct)),
+                   "mdns_groups_id_labels")
+        return labels, id_labels
+
     def groups(self, rows, npoints):
         """[(original indices of the member data sets, ascending; their distinct ids, ascending)],
         components in order of their lowest data set (igraph numbers clusters by their first
@@ -115,6 +126,5 @@ class DeviceGroups(object):
         every = np.arange(self.ndata) if rows is None else np.asarray(rows)
         if ncomp == 1:
             return [(every, ids)]
-        labels, point_labels = self.labels()
-        of_id = point_labels[ids]
+        labels, of_id = self.labels_of_ids(len(ids))
         return [(every[labels == root], ids[of_id == root]) for root in np.unique(labels)]

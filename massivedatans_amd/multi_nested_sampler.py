@@ -582,7 +582,7 @@ class MultiNestedSampler(object):
                 self._last_selection = (data_mask, selected, real_rows)      # for _fill_shelves
                 yield data_mask, ids
                 return
-            labels, point_labels = dg.labels()
+            labels, of_id = dg.labels_of_ids(len(ids))
             # components in ascending order of their label (= their lowest data set: igraph's cluster
             # order), members and ids ascending inside: two stable sorts instead of one pass over all
             # data sets and ids per component (a selection can fall into dozens of components)
@@ -591,7 +591,7 @@ class MultiNestedSampler(object):
             labels = labels.astype(narrow)
             order = numpy.argsort(labels, kind='stable')
             cuts = numpy.flatnonzero(numpy.diff(labels[order])) + 1
-            of_id = point_labels[ids].astype(narrow)
+            of_id = of_id.astype(narrow)
             id_order = numpy.argsort(of_id, kind='stable')
             id_cuts = numpy.flatnonzero(numpy.diff(of_id[id_order])) + 1
             members = numpy.split(selected[order], cuts)
