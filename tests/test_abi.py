@@ -60,9 +60,8 @@ def test_no_cpu_fallback(built):
     with pytest.raises(_lib.MdnsError):
         neighbors.count_within_distance_of(np.zeros((3, 2)), 0.1, np.zeros((2, 2)))
     # the raw ABI reports failure instead of computing
-    out = np.zeros(2)
-    rc = built.mdns_count_within_distance_of(_lib.ptr(np.zeros((3, 2))), 3, 2, 0.1,
-                                             _lib.ptr(np.zeros((2, 2))), 2, _lib.ptr(out), 0)
+    out, members, points = np.zeros(2), np.zeros((3, 2)), np.zeros((2, 2))       # (alive across the call)
+    rc = built.mdns_count_within_distance_of(_lib.ptr(members), 3, 2, 0.1, _lib.ptr(points), 2, _lib.ptr(out), 0)
     assert rc != 0 and b"no HIP device" in built.mdns_last_error()
 
 

@@ -28,7 +28,8 @@ for name, bright in (("nobody accepts", True), ("random candidates", False)):
     else:
         # candidates as a sampler draws them (narrow lines: template values down to denormals), against
         # thresholds nobody beats
-        _lib.check(lib.mdns_joint_set_live(js._h, _lib.ptr(np.full((nlive, ndata), 1e300))), "set_live")
+        high = np.full((nlive, ndata), 1e300)                   # (kept alive across the call)
+        _lib.check(lib.mdns_joint_set_live(js._h, _lib.ptr(high)), "set_live")
         js.prepare()
     xs = sample.priortransform_batch(cube)
     for _ in range(10):
