@@ -305,6 +305,8 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_filter(
 			if (i + 1 < kSteps) { \
 				_Pragma("unroll") for (int t = 0; t < NB; t++) b[(i + 1) & 1][t] = cur[((i + 1) * 4 + kq) * SPEC + jq + 16 * t]; \
 			} \
+			/* (k-steps past the last channel -- 24 of the 224 channel slots at 200 channels -- multiply \
+			   zeros; skipping them with a branch per k-step measured SLOWER: 37.0 against 34.6 us) */ \
 			_Pragma("unroll") for (int t = 0; t < NB; t++) \
 				acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[R][i], PROBE == 3 ? a[R][(i + t + 1) % kSteps] : b[i & 1][t], acc[t], 0, 0, 0); \
 		} \
@@ -555,7 +557,8 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 		// at 10 000 x 256 (rocprofv3, us): 64 spectra x 40 channels 30.3-32.4; 32 x 32 29-32; two chunks
 		// ahead 36.9 (132 VGPRs: three waves per SIMD instead of four or five -- this kernel wants
 		// independent workgroups around its barriers more than it wants distance to its loads; with the
-		// L2s flushed between launches it takes the same 31); 16-channel chunks 30-31.
+		// L2s flushed between launches it takes the same 31); 16-channel chunks 30-31; 48-channel chunks
+		// (five barriers instead of seven, 128 VGPRs) 37.0 against 34.7 on the same box.
 		// MDNS_FILTER_PROBE (experiments; results are wrong): 1 no MFMAs 12.8, 2 no loads after the first
 		// chunk 26.5, 3 MFMAs on registers only 23.5 -- against 14.8 for the 502 400 MFMAs at the rate the
 		// instruction sustains alone (69.7 TFLOP/s) on perfectly balanced SIMDs.

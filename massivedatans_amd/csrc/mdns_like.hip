@@ -514,59 +514,6 @@ __device__ __forceinline__ void cols_accumulate_deep(const double *__restrict__ 
 	}
 }
 
-// cols_accumulate with NB - 1 stages of spectra in flight instead of one, templates still scalar
-// operands from global memory (wave-uniform address).  With one stage of look-ahead a wave waits a
-// full memory round trip (~1.5 us) for every 8 channels: five waves per SIMD x 26 stages x 0.3 us =
-// 39 us whatever the arithmetic costs -- which is what both the add + fma kernel (31 us of issue)
-// and the FMA-only filter (16 us of issue) measured.  Same operations in the same order per
-// (candidate, spectrum): same bits.
-template <int BT, int NB, bool DOT>
-__device__ __forceinline__ void cols_accumulate_ring(const double *__restrict__ YT, int nxp,
-                                                     const double *mp,
-                                                     const int *__restrict__ rows, int M, int tile, int lane,
-                                                     int &k, double (&acc)[BT])
-{
-	constexpr int CH = 8;
-	k = tile * 64 + lane;
-	int col = k;
-	if (rows) col = rows[k < M ? k : M - 1];
-	else if (col >= ((M + 63) & ~63)) col = M - 1;
-	const double *yp = YT + ((size_t) (col >> 6) * nxp << 6) + (col & 63);
-#pragma unroll
-	for (int b = 0; b < BT; b++) acc[b] = 0.0;
-	const int nst = nxp / CH;
-	double y[NB][CH];
-#pragma unroll
-	for (int i = 0; i < NB - 1; i++) {
-		const double *p = yp + (size_t) min(i, nst - 1) * CH * 64;
-#pragma unroll
-		for (int c = 0; c < CH; c++) y[i][c] = p[c * 64];
-	}
-#pragma unroll 1
-	for (int s0 = 0; s0 < nst; s0 += NB) {
-#pragma unroll
-		for (int i = 0; i < NB; i++) {
-			const int s = s0 + i;                                // wave-uniform
-			if (s < nst) {
-				const double *p = yp + (size_t) min(s + NB - 1, nst - 1) * CH * 64;
-#pragma unroll
-				for (int c = 0; c < CH; c++) y[(i + NB - 1) % NB][c] = p[c * 64];
-				const double *m = mp + (size_t) s * CH * BT;
-#pragma unroll
-				for (int c = 0; c < CH; c++)
-#pragma unroll
-					for (int b = 0; b < BT; b++) {
-						if constexpr (DOT) acc[b] = fma(m[c * BT + b], y[i][c], acc[b]);
-						else {
-							const double d = m[c * BT + b] - y[i][c];
-							acc[b] = fma(d, d, acc[b]);
-						}
-					}
-			}
-		}
-	}
-}
-
 // copies n template values from global memory (stride `stride` doubles apart) into LDS, all of a
 // thread's loads in flight at once; ends with the workgroup barrier
 __device__ __forceinline__ void stage_templates(double *__restrict__ dst, const double *__restrict__ src, int n, int stride)
