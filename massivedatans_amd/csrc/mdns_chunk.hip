@@ -241,9 +241,9 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_filter(
 {
 	constexpr int NB = SPEC / 16;                                         // 16-spectrum blocks per wave: MFMAs per k-step
 	constexpr int kRow2 = SPEC / 2;                                       // 16-byte pieces per channel row
-	constexpr int kPieces = CHUNK * kRow2 / 256;                          // per thread and chunk
+	constexpr int kPieces = (CHUNK * kRow2 + 255) / 256;                  // per thread and chunk (the last one may be partial)
+	constexpr bool kWhole = (CHUNK * kRow2) % 256 == 0;                   // ... or not
 	constexpr int kRowsPerPass = 256 / kRow2;
-	static_assert(kPieces * 256 == CHUNK * kRow2, "chunk");
 	constexpr int kSteps = CHUNK / 4;
 	__shared__ __attribute__((aligned(16))) double stage[DEPTH + 1][CHUNK * SPEC];
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -278,7 +278,8 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_filter(
 #define FILTER_FETCH(SET, CHUNK_NO) { \
 	const int cn_ = (CHUNK_NO) < nchunks ? (CHUNK_NO) : nchunks - 1; \
 	_Pragma("unroll") for (int i = 0; i < kPieces; i++) { \
-		const int ch = cn_ * CHUNK + prow + i * kRowsPerPass; \
+		const int row = kWhole || prow + i * kRowsPerPass < CHUNK ? prow + i * kRowsPerPass : CHUNK - 1; \
+		const int ch = cn_ * CHUNK + row; \
 		piece[SET][i] = src[(size_t) ((ch < nxp ? ch : nxp - 1) - prow) * 32]; \
 	} \
 	_Pragma("unroll") for (int i = 0; i < kSteps; i++) { \
@@ -288,10 +289,11 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_filter(
 #define FILTER_STAGE(SET, CHUNK_NO) { \
 	const int cn_ = (CHUNK_NO) < nchunks ? (CHUNK_NO) : nchunks - 1; \
 	_Pragma("unroll") for (int i = 0; i < kPieces; i++) { \
-		const bool inside = cn_ * CHUNK + prow + i * kRowsPerPass < nxp; \
+		const int row = prow + i * kRowsPerPass; \
+		const bool inside = cn_ * CHUNK + row < nxp; \
 		double2 v = piece[SET][i]; \
 		v.x = inside ? v.x : 0.0; v.y = inside ? v.y : 0.0; \
-		reinterpret_cast<double2 *>(stage[SET])[i * 256 + threadIdx.x] = v; \
+		if (kWhole || row < CHUNK) reinterpret_cast<double2 *>(stage[SET])[i * 256 + threadIdx.x] = v; \
 	} }
 	// the B operands of a k-step are read from LDS one k-step ahead of the MFMAs that use them
 #define FILTER_BODY(R, R1, RF, CHUNK_NO) { \
@@ -572,11 +574,18 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 #define MFMA_LAUNCH(D, P) hipLaunchKernelGGL((k_gauss_mfma_filter<32, 32, D, P>), dim3(blocks), dim3(256), 0, c->stream, \
 		                   d_yT, nxp, s->nx, d_model_t, d_msq, B, scale, d_thr_rows, M, nspec, nbt, ngroups, d_higher, \
 		                   (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest)
-		switch (pr) {
+		// chunks of 40 channels where they leave fewer padded channels than chunks of 32 (200 channels:
+		// none against 24 -- the padded k-steps multiply zeros: 34.1 against 38.9 us on the same box)
+		const bool forty = pr == 0 && (nxp + 39) / 40 * 40 < (nxp + 31) / 32 * 32;
+		if (forty) hipLaunchKernelGGL((k_gauss_mfma_filter<32, 40, 1, 0>), dim3(blocks), dim3(256), 0, c->stream,
+		                              d_yT, nxp, s->nx, d_model_t, d_msq, B, scale, d_thr_rows, M, nspec, nbt, ngroups, d_higher,
+		                              (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest);
+		else switch (pr) {
 		case 1: MFMA_LAUNCH(1, 1); break;
 		case 2: MFMA_LAUNCH(1, 2); break;
 		case 3: MFMA_LAUNCH(1, 3); break;
 		case 4: MFMA_LAUNCH(2, 0); break;       // two chunks ahead (correct results)
+		case 5: MFMA_LAUNCH(1, 0); break;       // 32-channel chunks whatever the padding
 		default: MFMA_LAUNCH(1, 0); break;
 		}
 #undef MFMA_LAUNCH
