@@ -77,6 +77,13 @@ def test_components_against_scipy_small_and_ragged():
             got = dg.groups(rows, npoints)
             same(got, want)
             multi += len(want) > 1
+            # the labels of the listed ids (one call's worth) are those of the full label array
+            ncomp, ids = dg.components(rows, npoints)
+            labels_a, of_ids = dg.labels_of_ids(len(ids))
+            ncomp2, ids2 = dg.components(rows, npoints)
+            labels_b, of_points = dg.labels()
+            assert ncomp == ncomp2 == len(want) and np.array_equal(ids, ids2)
+            assert np.array_equal(labels_a, labels_b) and np.array_equal(of_ids, of_points[ids])
         dg.close()
     assert multi > 10
 
