@@ -34,6 +34,8 @@ log = logging.getLogger("massivedatans_amd")
 
 from . import _host
 
+_DEBUG_SHELVES = __import__("os").environ.get("MDNS_DEBUG_SHELVES") == "1"
+
 
 def _host_lib():
     """``libmdns_host.so`` (csrc/host_groups.c, plain C): the grouping walk as native host code.
@@ -277,7 +279,25 @@ class MultiNestedSampler(object):
 
     @property
     def shelves(self):
+        """The reference's ``self.shelves`` (lists of ``(pj, uj, xj, Lj)``).  With a joint state the
+        likelihoods of the waiting points live THERE (the host queues carry the point ids only,
+        and NaN where the reference has Lj): asking for them here is refused instead of answered
+        with NaNs."""
+        waiting = numpy.arange(self._shelves.L.shape[1])[None, :] < self._shelves.n[:, None]
+        if self.joint is not None and numpy.isnan(self._shelves.L[waiting]).any():
+            raise RuntimeError("the shelves' likelihoods are kept by the joint state (fetch_rows=False): "
+                               "ask joint.thresholds() / use fetch_rows=True")
         return self._shelves.as_lists(self.pointpile, self.pointpilex)
+
+    def _check_shelves_in_step(self):
+        """MDNS_DEBUG_SHELVES=1: once per iteration, the shelf sizes of the joint state against the host
+        queues of point ids (they are kept in step by two different pieces of code)."""
+        _, n_dev = self.joint.thresholds()
+        running = self._running_indices()
+        if not numpy.array_equal(numpy.asarray(n_dev)[running], self._shelves.n):
+            bad = numpy.flatnonzero(numpy.asarray(n_dev)[running] != self._shelves.n)
+            raise AssertionError("iteration %d: shelf sizes differ between the joint state and the host queues for data sets %s"
+                                 % (self.global_iter, running[bad][:10]))
 
     @property
     def live_pointsL(self):
@@ -827,6 +847,8 @@ class MultiNestedSampler(object):
     def __next__(self):
         allu, allp, _, Lmins, Lmini = self.prepare()
         self._fill_shelves(Lmins, allu, allp)
+        if self.joint is not None and _DEBUG_SHELVES:
+            self._check_shelves_in_step()
 
         # every data set gives up its worst live point and takes the head of its shelf
         self.global_iter += 1

@@ -273,7 +273,7 @@ def test_geometry_full_size_properties(nb):
 # ---------------------------------------------------------------- end to end ---------------
 @pytest.mark.parametrize("fused", [False, True])
 @pytest.mark.parametrize("case", ["nothing4", "horns3", "horns12", "horns100", "nothing4_graph", "horns12_graph", "horns100_graph"])
-def test_end_to_end_against_reference_trace(case, fused):
+def test_end_to_end_against_reference_trace(case, fused, monkeypatch):
     """The whole analysis on the GPU (HIP likelihood + HIP geometry + host orchestration) against
     the trace recorded from the reference's Python + C.  Geometry is bit-exact and likelihoods
     agree to ~1e-15, so the integer bookkeeping is expected to coincide (a last-bit tie in an
@@ -284,9 +284,11 @@ def test_end_to_end_against_reference_trace(case, fused):
     (and 1e-9 absolute).  ``fused``: live-point likelihoods, shelves, thresholds, accept test and
     shelf fill on the device (mdns_joint_*).  ``*_graph``: the reference's default grouping
     (USE_GRAPH=1) -- with ``fused`` its components come from the device (csrc/mdns_groups.hip)."""
-    from massivedatans_amd import sample
+    from massivedatans_amd import multi_nested_sampler, sample
     from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
     from tracing import Recorder, check_bookkeeping, check_floats, load_trace
+    # (every iteration also compares the device's shelf sizes with the host's queues of point ids)
+    monkeypatch.setattr(multi_nested_sampler, "_DEBUG_SHELVES", True)
     g = load_trace(case)
     ndata, nlive = int(g["ndata"]), int(g["nlive"])
     use_graph = bool(g.get("use_graph", 0))
