@@ -33,9 +33,15 @@ def integrate_remainder(sampler, logwidth, logVolremaining, logZ, H, globalLmax)
     """Evidence still held by the live points, which all share the shell width ``logwidth``
     (multi_nested_integrator.py:26-59).  Returns per running data set: remainder log-evidence,
     its bracketing error, total log-evidence, total error (twice, as the reference does)."""
-    live = list(sampler.remainder())                     # ascending likelihood, per data set
+    # ascending likelihood, per data set: only the likelihoods are looked at here, and those are the
+    # sorted columns of the live matrix (the reference's `remainder()` also gathers the coordinates
+    # of every point: 200 gathers over all data sets per call)
+    if hasattr(sampler, 'remainder_likelihoods'):
+        live_L = sampler.remainder_likelihoods()
+    else:
+        live_L = numpy.array([Li for _, _, Li in sampler.remainder()])
     ref = globalLmax                                     # likelihoods are taken relative to this
-    rel = numpy.exp([Li - ref for _, _, Li in live])     # [nlive, nrunning]
+    rel = numpy.exp(live_L - ref)                        # [nlive, nrunning]
     # upper / lower Riemann sums: every point takes its upper (resp. lower) neighbour's value
     rel_top = rel.copy()
     rel_top[-1] = numpy.exp(globalLmax - ref)
@@ -50,7 +56,7 @@ def integrate_remainder(sampler, logwidth, logVolremaining, logZ, H, globalLmax)
     assert numpy.isfinite(bracket).all(), bracket
 
     # information if the run stopped here: absorb the live points one by one
-    for _, _, Li in live:
+    for Li in live_L:
         logZ, H = _absorb(logZ, H, logwidth, Li)
         H[H < 0] = 0
 

@@ -108,9 +108,10 @@ class _Shelves(object):
         """Head (id, L) of every queue; every queue must be non-empty."""
         assert (self.n > 0).all()
         pid, L = self.p[:, 0].copy(), self.L[:, 0].copy()
-        self.p[:, :-1] = self.p[:, 1:]
-        self.L[:, :-1] = self.L[:, 1:]
-        self.L[:, -1] = numpy.inf
+        m = int(self.n.max())                           # nothing waits beyond column m - 1
+        self.p[:, :m - 1] = self.p[:, 1:m]
+        self.L[:, :m - 1] = self.L[:, 1:m]
+        self.L[:, m - 1] = numpy.inf
         self.n -= 1
         return pid, L
 
@@ -893,6 +894,10 @@ class MultiNestedSampler(object):
         order = numpy.argsort(self.live_pointsL[:, d])
         p = self.live_pointsp[order, d]
         return self.pointpile[p], self.pointpilex[p], self.live_pointsL[order, d]
+
+    def remainder_likelihoods(self):
+        """The likelihoods of ``remainder()`` alone: [nlive, running data sets], every column ascending."""
+        return numpy.sort(self.live_pointsL, axis=0)
 
     def remainder(self, d=None):
         """Live points in order of increasing likelihood: per data set ``d``, or for all data
