@@ -896,8 +896,10 @@ class MultiNestedSampler(object):
         return self.pointpile[p], self.pointpilex[p], self.live_pointsL[order, d]
 
     def remainder_likelihoods(self):
-        """The likelihoods of ``remainder()`` alone: [nlive, running data sets], every column ascending."""
-        return numpy.sort(self.live_pointsL, axis=0)
+        """The likelihoods of ``remainder()`` alone: [nlive, running data sets], every column ascending.
+        C-contiguous like the array the integrator used to build from the rows: numpy adds up an
+        axis in another order when it is the contiguous one, and the evidence errors are sums."""
+        return numpy.ascontiguousarray(numpy.sort(numpy.asarray(self.live_pointsL), axis=0))
 
     def remainder(self, d=None):
         """Live points in order of increasing likelihood: per data set ``d``, or for all data
