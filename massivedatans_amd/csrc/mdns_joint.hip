@@ -138,6 +138,9 @@ __global__ __launch_bounds__(kBlock) void k_joint_prepare(JointArrays st, const 
 	}
 	if (real && sl == 0) st.shelfn[d] = w;
 	if (w_held < 0) w_held = w;
+	// (shelves longer than the registers hold: the selection below reads entries the purge above has
+	// just moved -- stores of other lanes of this wave -- from memory: make them visible first)
+	if (n0 > kSlices * kHeld) __threadfence();
 	// The (w+1)-th smallest of live + shelf (find_nsmallest, :44-47) by quickselect on counts: the
 	// answer is the smallest value x with at least w + 1 values at or below it.  It is known to lie
 	// in (lo, hi]; a round takes a pivot strictly inside -- every lane proposes the middle one, in
