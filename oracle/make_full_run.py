@@ -7,7 +7,10 @@ oracle is pinned bit for bit against the reference on the small traces; this fix
 path be compared with it over a complete run at full size.  Test infrastructure: writes
 tests/golden/full_c3.npz (nothing) or full_c2.npz (horns).
 
-    python oracle/make_full_run.py [nothing|horns]
+    python oracle/make_full_run.py [nothing|horns] [graph]
+
+`graph`: the reference's default grouping (USE_GRAPH=1: connected components, host implementation)
+instead of the discovery-order walk -> full_c3_graph.npz / full_c2_graph.npz.
 """
 import hashlib
 import os
@@ -34,14 +37,16 @@ def main():
     o = Oracle(kind="port-omp")
     oracle_backend.patch_neighbors(_Patch(), o)
     kind = sys.argv[1] if len(sys.argv) > 1 else "nothing"
+    graph = len(sys.argv) > 2 and sys.argv[2] == "graph"
     data = (gen.nothing if kind == "nothing" else gen.horns)(10000)
     backend = oracle_backend.OracleSpectra(o, data["x"], data["y"])
     t = time.time()
     with np.errstate(all="ignore"):
         results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=0,
-                                            use_graph=False, backend=backend)
+                                            use_graph=graph, backend=backend)
     digest = hashlib.sha256(np.ascontiguousarray(sampler.pointpile, dtype=np.float64).tobytes()).hexdigest()
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "full_c3.npz" if kind == "nothing" else "full_c2.npz"),
+    name = ("full_c3" if kind == "nothing" else "full_c2") + ("_graph" if graph else "") + ".npz"
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", name),
                         logZ=results["logZ"], logZerr=results["logZerr"], ndraws=sampler.ndraws,
                         npoints=len(sampler.pointpile), iterations=results["nsamples"],
                         pointpile_sha256=np.array(digest))

@@ -724,27 +724,32 @@ def test_c3_is_the_low_acceptance_stress_it_is_meant_to_be():
     print("RadFriends stress, first 400 iterations:", stats)
 
 
+@pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("kind", ["nothing", "horns"])
-def test_full_run_matches_the_cpu_path(kind):
+def test_full_run_matches_the_cpu_path(kind, graph):
     """BASELINE.json configs[2] (10 000 no-signal spectra) / configs[1] (horns), 100 live points,
     TO TERMINATION on the GPU against the same complete run on the CPU oracle backends
     (tests/golden/full_c3.npz / full_c2.npz from oracle/make_full_run.py): same iterations and
     draws, the pile of accepted points byte for byte, and the evidences of all 10 000 data sets
     within 1e-9 (relative bar of BASELINE.json: 1e-6).  The horns run takes a minute and a half
-    on the GPU (2.3 hours on the CPU path); MDNS_SKIP_LONG_TESTS=1 leaves it out."""
+    on the GPU (2.3 hours on the CPU path); MDNS_SKIP_LONG_TESTS=1 leaves it out.  ``graph``: the
+    reference's default grouping -- connected components, on the device here, by the host
+    implementation in the fixture's run (full_c3_graph.npz / full_c2_graph.npz)."""
     import hashlib
     from massivedatans_amd import sample
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "tests", "golden", "full_c3.npz" if kind == "nothing" else "full_c2.npz")
+    path = os.path.join(root, "tests", "golden", ("full_c3" if kind == "nothing" else "full_c2") + ("_graph" if graph else "") + ".npz")
     if not os.path.exists(path):
-        pytest.skip("fixture not generated (oracle/make_full_run.py %s)" % kind)
+        pytest.skip("fixture not generated (oracle/make_full_run.py %s%s)" % (kind, " graph" if graph else ""))
     if kind == "horns" and os.environ.get("MDNS_SKIP_LONG_TESTS") == "1":
         pytest.skip("MDNS_SKIP_LONG_TESTS=1")
     with np.load(path) as f:
         want = {k: f[k] for k in f.files}
     data = (gen.nothing if kind == "nothing" else gen.horns)(10000)
     with np.errstate(all="ignore"):
-        results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=0, use_graph=False)
+        results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=100, max_samples=0, use_graph=graph)
+    if graph:
+        assert sampler._dgroups is not None, "the components did not come from the device"
     assert results["nsamples"] == int(want["iterations"])
     assert sampler.ndraws == int(want["ndraws"])
     assert len(sampler.pointpile) == int(want["npoints"])
