@@ -282,6 +282,10 @@ def setup_dist(args):
         import torch.distributed as dist
         device_index = local_rank % max(1, torch.cuda.device_count())
         torch.cuda.set_device(device_index)
+        if world == 1:
+            # (the single-rank rehearsal started by hand: what torchrun would have put there)
+            for key, value in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29611")):
+                os.environ.setdefault(key, value)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
     else:
         device_index = local_rank
