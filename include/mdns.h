@@ -165,8 +165,9 @@ double mdns_region_radius(mdns_region *r);
 int mdns_region_count(mdns_region *r, const double *points, int M, int *counts);
 int mdns_region_count_dev(mdns_region *r, const double *d_points, int M, int *d_counts);
 /* mdns_region_count with the shortest round trip (what a native constrainer calls once per 1000
- * proposals): points through a pinned block, counts exported by a kernel into host memory mapped
- * into the device, polled -- no pageable copies, no stream synchronisation. */
+ * proposals): ONE kernel, which reads the points from and stores the counts to a pinned block
+ * mapped into the device and raises a sequence number the host polls for -- no copies, no stream
+ * synchronisation. */
 int mdns_region_count_polled(mdns_region *r, const double *points, int M, int *counts);
 
 /* ------------------------------------------------------------------------------------ */
