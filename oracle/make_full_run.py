@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2] (gennothing) or configs[1] (horns), 10 000 spectra and 100 live points,
 run TO TERMINATION by our host orchestration on the CPU oracle backends: evidences of all data
-sets, draw count and a SHA-256 of the pile of accepted points.  gennothing: 2.5 minutes on 8
-cores; horns: hours (its regions hold thousands of points for several hundred iterations).  The pair orchestration +
+sets, draw count and a SHA-256 of the pile of accepted points.  gennothing: 2 minutes on 8
+cores; horns: an hour or two (its regions hold thousands of points for several hundred iterations).  The pair orchestration +
 oracle is pinned bit for bit against the reference on the small traces; this fixture lets the GPU
 path be compared with it over a complete run at full size.  Test infrastructure: writes
 tests/golden/full_c3.npz (nothing) or full_c2.npz (horns).
