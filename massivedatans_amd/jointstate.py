@@ -129,6 +129,11 @@ class HostJointState(object):
     # (parallel.ShardedJointState) in between
     def score(self, xs, rows):
         """Accept flag of every candidate of the chunk against the selected data sets."""
+        return self.score_params(self.to_kernel_params(xs) if len(xs) else numpy.zeros((0, self.nparams)), rows)
+
+    def score_params(self, params, rows):
+        """``score`` for candidates given as kernel parameter rows."""
+        xs = params
         rows = numpy.arange(self.ndata) if rows is None else numpy.asarray(rows, dtype=int)
         self._scored_rows = rows
         if len(rows) == 0 or len(xs) == 0:
@@ -136,7 +141,7 @@ class HostJointState(object):
             return numpy.zeros(len(xs), dtype=numpy.int32)
         mask = numpy.zeros(self.ndata, dtype=bool)
         mask[rows] = True
-        self._scored_L = self.scorer.loglike_batch(self.to_kernel_params(xs), mask)
+        self._scored_L = self.scorer.loglike_batch(params, mask)
         self.nevals_scored += self._scored_L.size
         self.ncalls += 1
         return (self._scored_L > self.higher[rows]).any(axis=1).astype(numpy.int32)
@@ -330,6 +335,11 @@ class GaussJointState(object):
     def score(self, xs, rows):
         """Scores the chunk; the accept flags stay on the device (``flags`` / ``set_flags`` /
         ``flags_address`` reach them)."""
+        return self.score_params(self.to_kernel_params(xs) if len(xs) else numpy.zeros((0, 3)), rows)
+
+    def score_params(self, params, rows):
+        """``score`` for candidates given as kernel parameter rows (A, mu, sig)."""
+        xs = params
         B = len(xs)
         if B > _lib.JOINT_MAX_BATCH:
             raise ValueError("at most %d candidates per chunk" % _lib.JOINT_MAX_BATCH)
@@ -337,7 +347,7 @@ class GaussJointState(object):
             rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
         M = self.ndata if rows is None else len(rows)
         self._reserve_for(rows)
-        params = _lib.as_f64(self.to_kernel_params(xs)) if B else numpy.zeros((0, 3))
+        params = _lib.as_f64(params) if B else numpy.zeros((0, 3))
         self._scored_rows, self._scored_B = rows, B
         self._check(self._lib.mdns_joint_score(self._h, _lib.ptr(params), B, self.noise_level,
                                                _lib.ptr(rows) if rows is not None and M else None, M), "mdns_joint_score")

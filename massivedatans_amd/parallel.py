@@ -271,11 +271,27 @@ class ShardedJointState(object):
             self.local.set_flags(flags)
         return flags
 
+    @property
+    def nparams(self):
+        return getattr(self.local, "nparams", 3)
+
+    def took(self, rows, beats):
+        """(a native constrainer's draw ended in this state's ``draw_params``: nothing to add)"""
+
     def draw(self, xs, rows):
+        return self.draw_params(self.local.to_kernel_params(xs), rows)
+
+    def draw_params(self, params, rows, jitter=None):
+        """``draw`` for candidates given as kernel parameter rows: what a native constrainer hands over
+        (``constrainer.python_backend``); every rank runs the same constrainer on the same random
+        stream and meets the others here."""
+        if jitter is not None:
+            raise ValueError("likelihood jitter is not part of the sharded Gaussian-line state")
         torch, dist = _dist()
         mine, counts = self._mine(rows)
+        xs = params
         B = len(xs)
-        self._local_flags = self.local.score(xs, mine)
+        self._local_flags = self.local.score_params(params, mine)
         if self._local_flags is None and not self._device_flags:
             self._local_flags = self.local.flags()
         self.ncalls += 1

@@ -125,14 +125,16 @@ class GaussLineProblem(object):
 
 def native_context(joint, prior, ndata):
     """The shared part of the native constrainers (massivedatans_amd.constrainer) for a joint
-    state, or None where they cannot run (library not built, data sets sharded over ranks)."""
-    from . import constrainer
+    state, or None where they cannot run (library not built).  With the data sets sharded over
+    ranks every rank runs the same constrainer on the same random stream; its chunks go through
+    ``ShardedJointState.draw_params``, where the ranks exchange their accept flags."""
+    from . import constrainer, parallel
     from .jointstate import GaussJointState, HostJointState
     if not constrainer.available():
         return None
     if isinstance(joint, GaussJointState):
         backend = constrainer.hip_backend(joint)
-    elif isinstance(joint, HostJointState):
+    elif isinstance(joint, (HostJointState, parallel.ShardedJointState)):
         backend = constrainer.python_backend(joint)
     else:
         return None

@@ -71,6 +71,7 @@ def _worker(rank, world, port, q):
         sampler = sample.build_sampler(problem, nlive_points=int(g["nlive"]), nsuperset_draws=int(g["nsuperset_draws"]),
                                        use_graph=False, seed=1, batched=True, fused=True)
         ok &= type(sampler.joint).__name__ == "ShardedJointState"
+        ok &= sampler.native is not None                  # one native call per draw on every rank, chunks meet in draw_params
         rec = Recorder(sampler)
         with np.errstate(all="ignore"):
             res = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0,
