@@ -560,7 +560,11 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 		// ahead 36.9 (132 VGPRs: three waves per SIMD instead of four or five -- this kernel wants
 		// independent workgroups around its barriers more than it wants distance to its loads; with the
 		// L2s flushed between launches it takes the same 31); 16-channel chunks 30-31; 48-channel chunks
-		// (five barriers instead of seven, 128 VGPRs) 37.0 against 34.7 on the same box.
+		// (five barriers instead of seven, 128 VGPRs) 37.0 against 34.7 on the same box.  The reads of
+		// the B operands out of LDS forced ahead of the MFMAs that use them (scheduling barriers; left alone
+		// the scheduler puts every read right in front of its use): a pair of k-steps ahead, still 128
+		// VGPRs: 33.8 against 33.9 -- the LDS latency is not what the waves wait for; a whole chunk ahead
+		// (152 VGPRs, three waves per SIMD): 35.8.
 		// MDNS_FILTER_PROBE (experiments; results are wrong): 1 no MFMAs 12.8, 2 no loads after the first
 		// chunk 26.5, 3 MFMAs on registers only 23.5 -- against 14.8 for the 502 400 MFMAs at the rate the
 		// instruction sustains alone (69.7 TFLOP/s) on perfectly balanced SIMDs.
