@@ -525,6 +525,79 @@ int mdns_backend_chunk_size(void *joint, int offered, int M, int hint);
 void *mdns_backend_region_begin(void *joint, const double *members, int K, int ndim, const unsigned *packed, int nbootstraps);
 int mdns_backend_region_radius(void *joint, void *region, double *radius);
 
+/* ------------------------------------------------------------------------------------------
+ * Part 6 -- one native call per nested-sampling ITERATION (libmdns_host.so, csrc/host_sampler.cpp).
+ *
+ * The integer side of MultiNestedSampler between `prepare` and the replacement of the dead points
+ * (multi_nested_sampler.py:365-534): the passes over the data sets whose shelf is empty, the grouping
+ * of the data sets that share live points (:204-355), the constrainer that serves each group
+ * (cachedconstrainer.py:19-116: four-generation cache, "similar to the last call" shortcut, one
+ * constrainer per single data set), the constrained draws (mdns_constrainer_draw) and the shelves'
+ * queues of point ids (:474-489), the pile of accepted points, the superpoints.  The floating-point
+ * side stays where it is: the joint state behind `mdns_draw_backend`.  Python keeps the reference's
+ * class (massivedatans_amd.core.NativeCoreSampler: same constructor, iterator protocol, attributes).
+ * ------------------------------------------------------------------------------------------ */
+/* Connected components of big selections on the device: user = an mdns_groups handle, the three
+ * functions = mdns_groups_components / mdns_groups_id_labels / mdns_groups_replace (Part 4).  Optional:
+ * without it (and for selections of few (data set, live point) pairs) a union-find on the host gives
+ * the same partition, component order and ascending id lists. */
+typedef struct mdns_group_backend {
+	void *user;
+	int (*components)(void *user, const int32_t *rows, int M, long long npoints, int *ncomponents,
+	                  long long *ndistinct, int32_t *distinct, long long cap, unsigned long long *touched);
+	int (*id_labels)(void *user, int32_t *labels, int32_t *id_labels, long long ndistinct);
+	int (*replace)(void *user, const int32_t *rows, const int32_t *slots, const int32_t *new_ids, int n);
+} mdns_group_backend;
+
+typedef struct mdns_core mdns_core;
+
+/* MultiNestedSampler(...) (multi_nested_sampler.py:58-119) with the constrainer settings of the
+ * reference's driver (sample.py:133-137).  be / prior / np / mt19937_state as in mdns_constrainer_draw
+ * (borrowed for the life of the object); gb may be NULL; shelf_mirror (int64[ndata], may be NULL) is
+ * incremented at the ORIGINAL index of every data set that shelves a point (the joint state's mirror of
+ * its shelf sizes; the joint state itself takes entries off in its `advance`); constrainer_totals as in
+ * mdns_constrainer_share_stats (may be NULL). */
+mdns_core *mdns_core_create(int nlive, int ndata, int ndim, int nsuperset_draws, int use_graph,
+                            int metriclearner, int rebuild_every, int metric_rebuild_every, int force_shrink,
+                            const mdns_draw_backend *be, const mdns_prior *prior, const mdns_numpy_ops *np,
+                            void *mt19937_state, const mdns_group_backend *gb, long long *shelf_mirror,
+                            long long *constrainer_totals);
+void mdns_core_destroy(mdns_core *c);
+const char *mdns_core_last_error(void);
+/* selections of at most this many (data set, live point) pairs are grouped on the host even when a
+ * device backend is there (default 32768) */
+void mdns_core_set_host_edges(mdns_core *c, long long edges);
+/* the nlive prior draws every data set starts from (:88-103): u, x f64[nlive][ndim] */
+int mdns_core_set_initial(mdns_core *c, const double *u, const double *x);
+/* `prepare` (:137-138): keep uint8[nrunning][width]; entry e of the r-th running data set's shelf stays
+ * when e < width and keep[r][e] */
+int mdns_core_purge(mdns_core *c, const unsigned char *keep, int width);
+/* :365-491: constrained draws until no running data set has an empty shelf */
+int mdns_core_fill(mdns_core *c);
+/* :494-534: the r-th running data set gives up the live point in slot argmin[r] and takes the head of
+ * its shelf; dead_u, dead_x f64[nrunning][ndim] / dead_ids, new_ids int32[nrunning] may be NULL */
+int mdns_core_advance(mdns_core *c, const int32_t *argmin, double *dead_u, double *dead_x,
+                      int32_t *dead_ids, int32_t *new_ids);
+/* cut_down (:148-173): surviving uint8[nrunning] */
+int mdns_core_cut_down(mdns_core *c, const unsigned char *surviving);
+long long mdns_core_npoints(const mdns_core *c);
+int mdns_core_nrunning(const mdns_core *c);
+/* the pile of accepted points f64[npoints][ndim] (valid until the next mdns_core_fill) */
+const double *mdns_core_pile_u(const mdns_core *c);
+const double *mdns_core_pile_x(const mdns_core *c);
+/* live_pointsp int32[nlive][nrunning] (:108) */
+int mdns_core_get_ids(const mdns_core *c, int32_t *out);
+/* shelf sizes int32[nrunning] and (ids != NULL) the waiting ids, queue after queue; returns their number */
+long long mdns_core_get_shelves(const mdns_core *c, int32_t *sizes, int32_t *ids, long long cap);
+int mdns_core_get_superpoints(const mdns_core *c, int32_t *out, int cap);
+/* out int64[MDNS_CORE_COUNTERS]: [0] ndraws (likelihood calls of the reference), [1] constrained draws,
+ * [2] useful (candidate, data set) evaluations, [3] points in the pile, [4] iterations, [5] running data
+ * sets, [6] superpoints, [7] passes, [8] groupings, of which [9] on the host, [10] on the device, [11] walks,
+ * [12] constrainers created, nanoseconds in [13] mdns_constrainer_draw, [14] grouping, [15] mdns_core_fill,
+ * [16] draws served by the "similar to the last call" shortcut */
+#define MDNS_CORE_COUNTERS 17
+void mdns_core_stats(const mdns_core *c, long long *out);
+
 #ifdef __cplusplus
 }
 #endif

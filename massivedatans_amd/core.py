@@ -1,0 +1,377 @@
+"""One native call per nested-sampling iteration.
+
+``NativeCoreSampler`` is :class:`massivedatans_amd.multi_nested_sampler.MultiNestedSampler` -- the
+reference's ``MultiNestedSampler`` (multi_nested_sampler.py:49-570): same constructor, iterator
+protocol, ``cut_down`` / ``remainder`` methods and attributes -- with the integer side of an
+iteration behind ``mdns_core_*`` (include/mdns.h Part 6, csrc/host_sampler.cpp): the passes over
+the data sets whose shelf is empty, the grouping of data sets that share live points, the choice
+of a constrainer per group (``cachedconstrainer.py``), the constrained draws themselves
+(``mdns_constrainer_draw``), the shelves' id queues, the pile of accepted points, the
+superpoints.  Python makes three native calls per iteration: ``joint.prepare()``, ``fill``,
+``advance``.
+
+The floating-point side stays with the joint state (:mod:`massivedatans_amd.jointstate`), the
+random numbers with numpy's global legacy stream (stepped in place by the constrainers), so the
+results are those of the Python orchestration bit for bit (tests/test_orchestration.py, mode
+"core", against traces of the reference's own code).
+"""
+import ctypes as C
+import os
+import time
+
+import numpy
+
+from . import constrainer as _constrainer
+from .multi_nested_sampler import MultiNestedSampler
+
+#: mdns_core_stats (include/mdns.h)
+COUNTERS = ("ndraws", "ndraw_calls", "nevals", "npoints", "iterations", "nrunning", "nsuperpoints", "passes",
+            "groupings", "groupings_host", "groupings_device", "groupings_walk", "constrainers",
+            "ns_draw", "ns_group", "ns_fill", "similar")
+
+_COMPONENTS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
+                          C.c_longlong, C.c_void_p)
+_ID_LABELS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong)
+_REPLACE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int)
+
+
+class GroupBackend(C.Structure):           # mdns_group_backend
+    _fields_ = [("user", C.c_void_p), ("components", _COMPONENTS), ("id_labels", _ID_LABELS), ("replace", _REPLACE)]
+
+
+_DECLARED = False
+
+
+def _declare(L):
+    global _DECLARED
+    if _DECLARED:
+        return
+    L.mdns_core_create.restype = C.c_void_p
+    L.mdns_core_create.argtypes = [C.c_int] * 9 + [C.c_void_p] * 7
+    L.mdns_core_destroy.restype = None
+    L.mdns_core_destroy.argtypes = [C.c_void_p]
+    L.mdns_core_last_error.restype = C.c_char_p
+    L.mdns_core_last_error.argtypes = []
+    L.mdns_core_set_host_edges.restype = None
+    L.mdns_core_set_host_edges.argtypes = [C.c_void_p, C.c_longlong]
+    L.mdns_core_set_initial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mdns_core_purge.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.mdns_core_fill.argtypes = [C.c_void_p]
+    L.mdns_core_advance.argtypes = [C.c_void_p] * 6
+    L.mdns_core_cut_down.argtypes = [C.c_void_p, C.c_void_p]
+    L.mdns_core_npoints.restype = C.c_longlong
+    L.mdns_core_npoints.argtypes = [C.c_void_p]
+    L.mdns_core_nrunning.argtypes = [C.c_void_p]
+    L.mdns_core_pile_u.restype = C.c_void_p
+    L.mdns_core_pile_u.argtypes = [C.c_void_p]
+    L.mdns_core_pile_x.restype = C.c_void_p
+    L.mdns_core_pile_x.argtypes = [C.c_void_p]
+    L.mdns_core_get_ids.argtypes = [C.c_void_p, C.c_void_p]
+    L.mdns_core_get_shelves.restype = C.c_longlong
+    L.mdns_core_get_shelves.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_longlong]
+    L.mdns_core_get_superpoints.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.mdns_core_stats.restype = None
+    L.mdns_core_stats.argtypes = [C.c_void_p, C.c_void_p]
+    _DECLARED = True
+
+
+def available():
+    """libmdns_host.so carries the core (built from csrc/host_sampler.cpp)."""
+    L = _constrainer.host_lib()
+    return L is not None and hasattr(L, "mdns_core_fill") and _constrainer.available()
+
+
+def device_group_backend(groups):
+    """mdns_group_backend over a :class:`massivedatans_amd.grouping.DeviceGroups` (libmdns_hip.so)."""
+    from . import _lib
+    lib = _lib.require_device()
+    gb = GroupBackend()
+    gb.user = groups._h
+    gb.components = C.cast(lib.mdns_groups_components, _COMPONENTS)
+    gb.id_labels = C.cast(lib.mdns_groups_id_labels, _ID_LABELS)
+    gb.replace = C.cast(lib.mdns_groups_replace, _REPLACE)
+    gb._keep = groups
+    return gb
+
+
+class _ShelfView(object):
+    """What the host code looks at of the shelves: their sizes."""
+
+    def __init__(self, n):
+        self.n = n
+
+
+class NativeCoreSampler(MultiNestedSampler):
+    """``MultiNestedSampler`` with a joint state and a native context (``native=...``), the integer
+    bookkeeping in the library.  The constructor takes the base class's arguments; the three
+    ``*_draw_constrained`` callables are not used (the constrainers are the library's, with
+    ``constrainer_settings`` = (metriclearner, rebuild_every, metric_rebuild_every, force_shrink),
+    default: the reference driver's, sample.py:133-137)."""
+
+    def __init__(self, *args, **kwargs):
+        self._core = None
+        settings = kwargs.pop("constrainer_settings", ("truncatedscaling", 1000, 20, True))
+        kwargs.setdefault("superset_draw_constrained", None)
+        kwargs.setdefault("individual_draw_constrained", None)
+        kwargs.setdefault("draw_constrained", None)
+        want_device_groups = bool(kwargs.get("device_groups", False))
+        super(NativeCoreSampler, self).__init__(*args, **kwargs)
+        if self.native is None or self.joint is None:
+            raise ValueError("NativeCoreSampler needs joint_state=... and native=... (constrainer.NativeContext)")
+        L = _constrainer.host_lib()
+        if L is None or not hasattr(L, "mdns_core_fill"):
+            raise RuntimeError("libmdns_host.so lacks the sampler core (make -C massivedatans_amd/csrc)")
+        _declare(L)
+        self._L = L
+        ctx = self.native
+        ndata = int(self.__dict__.pop("_init_ndata"))
+        self._ndata = ndata
+        self._ndata_total = ndata
+        us = numpy.ascontiguousarray(self.__dict__.pop("_init_pointpile"), dtype=numpy.float64)
+        xs = numpy.ascontiguousarray(self.__dict__.pop("_init_pointpilex"), dtype=numpy.float64)
+        self.__dict__.pop("_init_live_pointsp", None)
+        self._gb = None
+        if self.use_graph and want_device_groups:
+            from .grouping import DeviceGroups
+            full = numpy.repeat(numpy.arange(self.nlive_points, dtype=numpy.int32)[:, None], ndata, axis=1)
+            self._dgroups = DeviceGroups(full)
+            self._gb = device_group_backend(self._dgroups)
+        mirror = getattr(self.joint, "shelf_n", None)
+        if mirror is not None and not (isinstance(mirror, numpy.ndarray) and mirror.dtype == numpy.int64
+                                       and mirror.flags.c_contiguous and len(mirror) == ndata):
+            mirror = None
+        self._mirror = mirror
+        metric, rebuild_every, metric_rebuild_every, force_shrink = settings
+        self._core = L.mdns_core_create(
+            self.nlive_points, ndata, self.ndim, int(self.nsuperset_draws), 1 if self.use_graph else 0,
+            _constrainer.METRICS[metric], int(rebuild_every), int(metric_rebuild_every), 1 if force_shrink else 0,
+            ctx._be, ctx._prior, ctx._ops, ctx.mt, C.addressof(self._gb) if self._gb is not None else None,
+            mirror.ctypes.data if mirror is not None else None, ctx.totals.ctypes.data)
+        if not self._core:
+            raise RuntimeError("mdns_core_create: " + L.mdns_core_last_error().decode())
+        edges = os.environ.get("MDNS_CORE_HOST_EDGES")
+        if edges:
+            L.mdns_core_set_host_edges(self._core, int(edges))
+        self._check(L.mdns_core_set_initial(self._core, us.ctypes.data, xs.ctypes.data), "mdns_core_set_initial")
+        self._stats = numpy.zeros(len(COUNTERS), dtype=numpy.int64)
+        self._lp_cache = None
+        self.fill_seconds = 0.0
+
+    def __del__(self):
+        try:
+            if getattr(self, "_core", None):
+                self._L.mdns_core_destroy(self._core)
+                self._core = None
+            if self._dgroups is not None:
+                self._dgroups.close()
+                self._dgroups = None
+        except Exception:       # noqa: BLE001
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            from . import _lib
+            raise RuntimeError("%s failed: %s | %s | %s" % (
+                what, self._L.mdns_core_last_error().decode(), self._L.mdns_host_last_error().decode(),
+                _lib.last_error() if _lib._lib is not None else ""))
+
+    # ---- the base class's attributes, now views of the library's state ----------------------
+    def core_stats(self):
+        self._L.mdns_core_stats(self._core, self._stats.ctypes.data)
+        return dict(zip(COUNTERS, self._stats.tolist()))
+
+    def _stat(self, k):
+        self._L.mdns_core_stats(self._core, self._stats.ctypes.data)
+        return int(self._stats[k])
+
+    def _pile(self, getter):
+        n = int(self._L.mdns_core_npoints(self._core))
+        ptr = getter(self._core)
+        return numpy.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (n, self.ndim)).copy()
+
+    @property
+    def pointpile(self):
+        if self._core is None:
+            return self.__dict__["_init_pointpile"]
+        return self._pile(self._L.mdns_core_pile_u)
+
+    @pointpile.setter
+    def pointpile(self, value):
+        if self._core is None:
+            self.__dict__["_init_pointpile"] = value
+
+    @property
+    def pointpilex(self):
+        if self._core is None:
+            return self.__dict__["_init_pointpilex"]
+        return self._pile(self._L.mdns_core_pile_x)
+
+    @pointpilex.setter
+    def pointpilex(self, value):
+        if self._core is None:
+            self.__dict__["_init_pointpilex"] = value
+
+    @property
+    def live_pointsp(self):
+        if self._core is None:
+            return self.__dict__["_init_live_pointsp"]
+        if self._lp_cache is None:
+            out = numpy.empty((self.nlive_points, self._ndata), dtype=numpy.int32)
+            self._check(self._L.mdns_core_get_ids(self._core, out.ctypes.data), "mdns_core_get_ids")
+            self._lp_cache = out.astype(int)
+        return self._lp_cache
+
+    @live_pointsp.setter
+    def live_pointsp(self, value):
+        if self._core is None:
+            self.__dict__["_init_live_pointsp"] = value
+
+    @property
+    def ndata(self):
+        return self._ndata if self._core is not None else self.__dict__["_init_ndata"]
+
+    @ndata.setter
+    def ndata(self, value):
+        if self._core is None:
+            self.__dict__["_init_ndata"] = value
+
+    @property
+    def ndraws(self):
+        return self._stat(0) if self._core is not None else self.__dict__.get("_init_ndraws", 0)
+
+    @ndraws.setter
+    def ndraws(self, value):
+        if self._core is None:
+            self.__dict__["_init_ndraws"] = value
+
+    @property
+    def ndraw_calls(self):
+        return self._stat(1) if self._core is not None else 0
+
+    @ndraw_calls.setter
+    def ndraw_calls(self, value):
+        pass
+
+    @property
+    def nevals(self):
+        return self._stat(2) if self._core is not None else self.__dict__.get("_init_nevals", 0)
+
+    @nevals.setter
+    def nevals(self, value):
+        if self._core is None:
+            self.__dict__["_init_nevals"] = value
+
+    @property
+    def global_iter(self):
+        return self._stat(4) if self._core is not None else 0
+
+    @global_iter.setter
+    def global_iter(self, value):
+        pass
+
+    @property
+    def draw_seconds(self):
+        return self._stat(13) * 1e-9 if self._core is not None else 0.0
+
+    @draw_seconds.setter
+    def draw_seconds(self, value):
+        pass
+
+    @property
+    def superpoints(self):
+        if self._core is None:
+            return self.__dict__.get("_init_superpoints", set())
+        out = numpy.empty(max(1, self._L.mdns_core_get_superpoints(self._core, None, 0)), dtype=numpy.int32)
+        n = self._L.mdns_core_get_superpoints(self._core, out.ctypes.data, len(out))
+        return set(out[:n].tolist())
+
+    @superpoints.setter
+    def superpoints(self, value):
+        if self._core is None:
+            self.__dict__["_init_superpoints"] = value
+
+    @property
+    def _shelves(self):
+        if self._core is None:
+            return self.__dict__.get("_init_shelves")
+        n = numpy.empty(self._ndata, dtype=numpy.int32)
+        self._L.mdns_core_get_shelves(self._core, n.ctypes.data, None, 0)
+        return _ShelfView(n.astype(int))
+
+    @_shelves.setter
+    def _shelves(self, value):
+        if self._core is None:
+            self.__dict__["_init_shelves"] = value
+
+    @property
+    def shelves(self):
+        """The point ids waiting on every running data set's shelf (their likelihoods live in the
+        joint state): lists of ``(id, u, x, nan)`` like the reference's ``self.shelves``."""
+        n = numpy.empty(self._ndata, dtype=numpy.int32)
+        total = int(self._L.mdns_core_get_shelves(self._core, n.ctypes.data, None, 0))
+        ids = numpy.empty(max(1, total), dtype=numpy.int32)
+        self._L.mdns_core_get_shelves(self._core, n.ctypes.data, ids.ctypes.data, len(ids))
+        pile, pilex = self.pointpile, self.pointpilex
+        out, at = [], 0
+        for k in n:
+            out.append([(int(p), pile[p], pilex[p], numpy.nan) for p in ids[at:at + k]])
+            at += k
+        return out
+
+    # ---- the iteration ------------------------------------------------------------------------
+    def prepare(self):
+        Lmins, Lmini, kept = self.joint.prepare()
+        if kept is not None:
+            kept = numpy.ascontiguousarray(kept, dtype=numpy.uint8)
+            self._check(self._L.mdns_core_purge(self._core, kept.ctypes.data, kept.shape[1]), "mdns_core_purge")
+        return None, None, Lmins.min() if len(Lmins) else numpy.nan, Lmins, Lmini
+
+    def _fill_shelves(self, Lmins=None, allu=None, allp=None):
+        t0 = time.perf_counter()
+        rc = self._L.mdns_core_fill(self._core)
+        self.fill_seconds += time.perf_counter() - t0
+        self._check(rc, "mdns_core_fill")
+
+    def __next__(self):
+        ctx = self.native
+        ctx.sync_gauss_from_numpy()
+        _, _, _, Lmins, Lmini = self.prepare()
+        try:
+            self._fill_shelves()
+        finally:
+            ctx.sync_gauss_to_numpy()
+        if os.environ.get("MDNS_DEBUG_SHELVES") == "1":
+            self._check_shelves_in_step()
+        nrun = self._ndata
+        uis = numpy.empty((nrun, self.ndim))
+        xis = numpy.empty((nrun, self.ndim))
+        slots = numpy.ascontiguousarray(Lmini, dtype=numpy.int32)
+        self._check(self._L.mdns_core_advance(self._core, slots.ctypes.data, uis.ctypes.data, xis.ctypes.data, None, None),
+                    "mdns_core_advance")
+        self.joint.advance()
+        self._live_cache = None
+        self._lp_cache = None
+        return uis, xis, numpy.asarray(Lmins)
+
+    next = __next__
+
+    def cut_down(self, surviving):
+        surviving = numpy.asarray(surviving, dtype=bool)
+        if len(surviving) != self._ndata:
+            raise ValueError("cut_down: %d flags for %d running data sets" % (len(surviving), self._ndata))
+        flags = numpy.ascontiguousarray(surviving, dtype=numpy.uint8)
+        self._check(self._L.mdns_core_cut_down(self._core, flags.ctypes.data), "mdns_core_cut_down")
+        self._ndata = int(surviving.sum())
+        self.data_mask_all = numpy.ones(self._ndata) == 1
+        self.real_data_mask_all[self.real_data_mask_all] = surviving
+        self._real_indices = None
+        self._live_cache = None
+        self._lp_cache = None
+        self.joint.set_running(numpy.flatnonzero(self.real_data_mask_all))
+        self.point_data_map = None
+
+    # (the grouping lives in the library; the base class's generators work from live_pointsp and
+    # stay usable for inspection)
+
+
+__all__ = ['NativeCoreSampler', 'available', 'device_group_backend', 'COUNTERS']

@@ -142,12 +142,15 @@ def native_context(joint, prior, ndata):
 
 
 def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False, seed=1, batched=True,
-                  fused=False, native=None):
+                  fused=False, native=None, core=None):
     """Constrainers + sampler wired as sample.py:131-194 (CONSTRAINER=MLFRIENDS).  ``fused``: the
     likelihood matrix, the shelves' likelihoods and the thresholds live in a joint state
     (``problem.joint_state``) and whole chunks of candidates are scored and decided there.
     ``native`` (default with ``fused``: on, MDNS_NATIVE_CONSTRAINER=0 turns it off): the
-    constrainers are ``constrainer.NativeConstrainer`` objects -- one native call per draw."""
+    constrainers are ``constrainer.NativeConstrainer`` objects -- one native call per draw.
+    ``core`` (default with ``native``: on, MDNS_NATIVE_CORE=0 turns it off): the sampler is a
+    ``core.NativeCoreSampler`` -- the whole integer side of an iteration (passes, grouping,
+    constrainer cache, draws, shelves) behind one native call."""
     numpy.random.seed(seed)                                      # sample.py:162
     joint = problem.joint_state(nlive_points) if fused else None
     if native is None:
@@ -175,6 +178,21 @@ def build_sampler(problem, nlive_points=400, nsuperset_draws=10, use_graph=False
     from .jointstate import GaussJointState
     on_device = isinstance(joint, GaussJointState) or isinstance(getattr(joint, 'local', None), GaussJointState)
     device_groups = use_graph and on_device and os.environ.get('MDNS_DEVICE_GROUPS', '1') != '0'
+    if core is None:
+        core = context is not None and os.environ.get('MDNS_NATIVE_CORE', '1') != '0'
+    if core:
+        from . import core as core_module
+        if context is None or not core_module.available():
+            raise RuntimeError("the native sampler core needs the native constrainer (libmdns_host.so)")
+        # the constrainers live in the library, with the reference driver's settings (sample.py:133-137)
+        return core_module.NativeCoreSampler(
+            nlive_points=nlive_points, priortransform=prior_fn,
+            multi_loglikelihood=problem.multi_loglikelihood, ndim=ndim, ndata=problem.ndata,
+            nsuperset_draws=nsuperset_draws, use_graph=use_graph,
+            multi_loglikelihood_batch=getattr(problem, 'multi_loglikelihood_batch', None) if batched else None,
+            joint_state=joint, priortransform_batch=prior_batch if fused else None,
+            device_groups=device_groups, native=context,
+            constrainer_settings=('truncatedscaling', 1000, 20, True))
     sampler = MultiNestedSampler(
         nlive_points=nlive_points, priortransform=prior_fn,
         multi_loglikelihood=problem.multi_loglikelihood, ndim=ndim, ndata=problem.ndata,

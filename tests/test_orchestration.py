@@ -23,7 +23,7 @@ CASES = ["nothing4", "horns3", "horns12", "horns6", "horns100",
          "nothing4_graph", "horns12_graph", "horns100_graph"]
 
 
-def run_case(g, oracle, batched, fused=False, native=False):
+def run_case(g, oracle, batched, fused=False, native=False, core=False):
     from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
     ndata, nlive = int(g["ndata"]), int(g["nlive"])
     name = "horns" if "horns" in g["_name"] else "nothing"
@@ -31,8 +31,9 @@ def run_case(g, oracle, batched, fused=False, native=False):
     problem = sample.GaussLineProblem(data["x"], data["y"], backend=OracleSpectra(oracle, data["x"], data["y"]))
     sampler = sample.build_sampler(problem, nlive_points=nlive, nsuperset_draws=int(g["nsuperset_draws"]),
                                    use_graph=bool(g.get("use_graph", 0)), seed=1, batched=batched, fused=fused,
-                                   native=native)
+                                   native=native, core=core)
     assert (sampler.native is not None) == native
+    assert (type(sampler).__name__ == "NativeCoreSampler") == core
     rec = Recorder(sampler)
     results = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0,
                                       max_samples=int(g["max_samples"]))
@@ -46,22 +47,24 @@ def run_case(g, oracle, batched, fused=False, native=False):
 # "native": the same with every constrainer a constrainer.NativeConstrainer -- region, proposals
 # (numpy's own Mersenne Twister stepped in C), prior transform and accept loop of a draw in ONE call
 # of csrc/host_constrainer.cpp, the oracle behind its backend table
-@pytest.mark.parametrize("mode", ["single", "fused", "native"])
+# "core": the whole integer side of an iteration -- passes, grouping, constrainer cache, draws, shelves --
+# behind mdns_core_fill (csrc/host_sampler.cpp), the constrainers inside it
+@pytest.mark.parametrize("mode", ["single", "fused", "native", "core"])
 def test_trace_bit_exact(case, mode, oracle, monkeypatch):
     g = load_trace(case)
     batched = mode != "single"
-    if mode == "native":
+    if mode in ("native", "core"):
         from massivedatans_amd import constrainer
         if not constrainer.available():
             pytest.skip("libmdns_host.so not built")
-    if case == "horns6" and mode not in ("single", "native"):
-        pytest.skip("242k draws: run one candidate at a time and native")
+    if case == "horns6" and mode not in ("single", "native", "core"):
+        pytest.skip("242k draws: run one candidate at a time, native and core")
     if case.startswith("horns100") and mode == "single":
         pytest.skip("44k draws: run fused and native")
     patch_neighbors(monkeypatch, oracle)
     with np.errstate(all="ignore"):
-        results, sampler, rec, rng_probe = run_case(g, oracle, batched, fused=(mode in ("fused", "native")),
-                                                    native=(mode == "native"))
+        results, sampler, rec, rng_probe = run_case(g, oracle, batched, fused=(mode in ("fused", "native", "core")),
+                                                    native=(mode in ("native", "core")), core=(mode == "core"))
     check_bookkeeping(g, sampler, rec, results)        # integers: ids, draw counts, accepted points
     check_floats(g, rec, results, rtol=0)              # floats: the same bits
     # the global legacy RNG stream was consumed call for call
