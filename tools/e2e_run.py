@@ -61,5 +61,7 @@ print(json.dumps({"workload": "%s %d x 200, nlive %d, cap %d" % (kind, ndata, nl
                   "draw_constrained_wall_s": sampler.draw_seconds,
                   "grouping": ("graph (components on the device, %d calls)" % sampler._dgroups.ncalls) if sampler._dgroups is not None
                   else ("graph (host)" if sampler.use_graph else "walk (host)"),
+                  "core": sampler.core_stats() if hasattr(sampler, "core_stats") else None,
+                  "fill_wall_s": getattr(sampler, "fill_seconds", None),
                   "useful_evals_per_s": sampler.nevals / duration,
                   "logZ_first3": results["logZ"][:3].tolist()}))
