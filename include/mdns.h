@@ -403,6 +403,7 @@ double mdns_groups_mean_rounds(const mdns_groups *g);
  * ------------------------------------------------------------------------------------------ */
 #define MDNS_MAX_DIM 16
 
+struct mdns_chain_request;
 /* Device work of a draw.  `user` is passed back as the first argument of every function. */
 typedef struct mdns_draw_backend {
 	void *user;
@@ -435,7 +436,30 @@ typedef struct mdns_draw_backend {
 	 * region per backend is between the two calls at any time. */
 	void *(*region_begin)(void *user, const double *members, int K, int ndim, const unsigned *packed, int nbootstraps);
 	int (*region_radius)(void *user, void *region, double *radius);
+	/* Optional (NULL: not offered).  The first batch of box proposals of a region between region_begin
+	 * and region_radius WITHOUT a host look in between (radfriendsregion.py:135-141 + hiermetriclearn.py:
+	 * 111-119,181-196): chain_begin queues, behind K6, the proposals lo + (hi - lo) u, their membership
+	 * counts and -- when it can; limit > 0 asks for it -- the first chunk of the draw begun with
+	 * draw_begin: the first min(kept, limit) proposals that are inside the region and, after the metric's
+	 * inverse transform, inside the unit cube, prior-transformed, scored, accepted and committed like a
+	 * draw_chunk.  chain_end waits for all of it: counts int32[n]; *nkept (-1: the chunk did not ride
+	 * along), *B (its size), *accepted, fillbits, params f64[B][nparams] the device scored with (may be
+	 * NULL).  The caller then asks region_radius as usual. */
+	int (*chain_begin)(void *user, void *region, const struct mdns_chain_request *rq);
+	int (*chain_end)(void *user, void *region, int *counts, int *nkept, int *B, int *accepted,
+	                 unsigned long long *fillbits, double *params);
 } mdns_draw_backend;
+
+struct mdns_prior;
+typedef struct mdns_chain_request {
+	int n, ndim;                    /* proposals, dimensions */
+	const double *u;                /* f64[n][ndim]: numpy's raw doubles of uniform(lo, hi, size=(n, ndim)) */
+	const double *mn, *mx;          /* f64[ndim]: members.min(axis=0), members.max(axis=0) (radfriendsregion.py:69-70) */
+	int identity;                   /* the metric is the identity; else x = y * scale + mean (sdml.py) */
+	const double *mean, *scale;
+	const struct mdns_prior *prior;
+	int limit;                      /* candidates of the first chunk at most; 0: stop after the counts */
+} mdns_chain_request;
 
 /* The prior transform of the problem (sample.py:52-58) and the kernel's parameters (sample.py:103),
  * per dimension:  x[k] = a[k] * u[k] + b[k]  (the addition skipped when b[k] == 0), then
@@ -496,11 +520,14 @@ int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, cons
  * [6] membership calls (K3), [7] raw proposals, [8] proposals the region kept, [9] tries (the
  * reference's likelihood calls); nanoseconds spent in [10] the bootstrap choices, [11] region_create
  * (K6 + upload), [12] region_count (K3), [13] proposal random numbers + arithmetic, [14] the prior
- * transform, [15] draw_chunk, [16] mdns_constrainer_draw as a whole, [17] the likelihood jitter.
+ * transform, [15] draw_chunk, [16] mdns_constrainer_draw as a whole, [17] the likelihood jitter;
+ * [18] first batches chained on the device together with their chunk (chain_begin / chain_end), [19] with
+ * their membership counts only, [20] accepted candidates of chained chunks whose device parameters were
+ * not bit for bit the host's (10**v), [21] nanoseconds between chain_begin and chain_end.
  * mdns_constrainer_share_stats:
  * every increment is also added to totals int64[MDNS_CONSTRAINER_COUNTERS] (the caller's: the sum
  * over a sampler's constrainers). */
-#define MDNS_CONSTRAINER_COUNTERS 18
+#define MDNS_CONSTRAINER_COUNTERS 22
 void mdns_constrainer_stats(const mdns_constrainer *c, long long *out);
 void mdns_constrainer_share_stats(mdns_constrainer *c, long long *totals);
 const char *mdns_host_last_error(void);
@@ -524,6 +551,9 @@ int mdns_backend_draw_chunk(void *joint, const double *params, int B, const doub
 int mdns_backend_chunk_size(void *joint, int offered, int M, int hint);
 void *mdns_backend_region_begin(void *joint, const double *members, int K, int ndim, const unsigned *packed, int nbootstraps);
 int mdns_backend_region_radius(void *joint, void *region, double *radius);
+int mdns_backend_chain_begin(void *joint, void *region, const mdns_chain_request *rq);
+int mdns_backend_chain_end(void *joint, void *region, int *counts, int *nkept, int *B, int *accepted,
+                           unsigned long long *fillbits, double *params);
 
 /* ------------------------------------------------------------------------------------------
  * Part 6 -- one native call per nested-sampling ITERATION (libmdns_host.so, csrc/host_sampler.cpp).
@@ -594,8 +624,9 @@ int mdns_core_get_superpoints(const mdns_core *c, int32_t *out, int cap);
  * [2] useful (candidate, data set) evaluations, [3] points in the pile, [4] iterations, [5] running data
  * sets, [6] superpoints, [7] passes, [8] groupings, of which [9] on the host, [10] on the device, [11] walks,
  * [12] constrainers created, nanoseconds in [13] mdns_constrainer_draw, [14] grouping, [15] mdns_core_fill,
- * [16] draws served by the "similar to the last call" shortcut */
-#define MDNS_CORE_COUNTERS 17
+ * [16] draws served by the "similar to the last call" shortcut, [17..24] groupings by selection size
+ * (fewer than 2, 8, 32, 128, 512, 2048, 8192 data sets, more) and [25..32] the nanoseconds they took */
+#define MDNS_CORE_COUNTERS 33
 void mdns_core_stats(const mdns_core *c, long long *out);
 
 #ifdef __cplusplus

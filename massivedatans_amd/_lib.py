@@ -40,7 +40,7 @@ ABI_SYMBOLS = (
     "mdns_groups_replace", "mdns_groups_components", "mdns_groups_labels", "mdns_groups_id_labels", "mdns_groups_mean_rounds",
     "mdns_backend_region_create", "mdns_backend_region_destroy", "mdns_backend_region_count",
     "mdns_backend_draw_begin", "mdns_backend_draw_chunk", "mdns_backend_chunk_size",
-    "mdns_backend_region_begin", "mdns_backend_region_radius",
+    "mdns_backend_region_begin", "mdns_backend_region_radius", "mdns_backend_chain_begin", "mdns_backend_chain_end",
 )
 
 #: the symbols of include/mdns.h Part 5 that live in libmdns_host.so (plain host code, no GPU)

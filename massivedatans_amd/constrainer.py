@@ -35,6 +35,9 @@ _DRAW_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C
 _CHUNK_SIZE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 _REGION_BEGIN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int)
 _REGION_RADIUS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double))
+_CHAIN_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
+_CHAIN_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                         C.POINTER(C.c_ulonglong), C.POINTER(C.c_double))
 _CUSTOM_PRIOR = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double))
 _VEC_POW = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_double)
 _FIT_METRIC = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int, C.c_int,
@@ -46,7 +49,9 @@ class DrawBackend(C.Structure):            # mdns_draw_backend
                 ("region_count", _REGION_COUNT), ("draw_begin", _DRAW_BEGIN), ("draw_chunk", _DRAW_CHUNK),
                 ("chunk_size", _CHUNK_SIZE),
                 # optional halves of region_create (NULL: not offered): K6 launched / its radius awaited
-                ("region_begin", _REGION_BEGIN), ("region_radius", _REGION_RADIUS)]
+                ("region_begin", _REGION_BEGIN), ("region_radius", _REGION_RADIUS),
+                # optional: the first batch of a region without a host look in between (mdns.h Part 5)
+                ("chain_begin", _CHAIN_BEGIN), ("chain_end", _CHAIN_END)]
 
 
 class Prior(C.Structure):                  # mdns_prior
@@ -62,7 +67,8 @@ class NumpyOps(C.Structure):               # mdns_numpy_ops
 METRICS = {'none': 0, 'simplescaling': 1, 'truncatedscaling': 2}
 #: mdns_constrainer_stats (include/mdns.h)
 COUNTERS = ("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals", "inside", "tries",
-            "ns_bootstrap", "ns_region", "ns_count", "ns_propose", "ns_transform", "ns_chunk", "ns_draw", "ns_jitter")
+            "ns_bootstrap", "ns_region", "ns_count", "ns_propose", "ns_transform", "ns_chunk", "ns_draw", "ns_jitter",
+            "chains", "chain_counts", "param_mismatch", "ns_chain")
 
 _HOST = None
 
@@ -154,6 +160,11 @@ def _numpy_ops():
     return ops
 
 
+def joint_kind_gauss(joint):
+    """The Gaussian-line joint state (the chained first batch scores with the K1 chunk kernels)."""
+    return getattr(joint, "nparams", 3) == 3
+
+
 def hip_backend(joint):
     """The device entry points of libmdns_hip.so for a :class:`jointstate.GaussJointState`."""
     lib = _lib.require_device()
@@ -168,6 +179,9 @@ def hip_backend(joint):
                                ("region_begin", _REGION_BEGIN, "mdns_backend_region_begin"),
                                ("region_radius", _REGION_RADIUS, "mdns_backend_region_radius")):
         setattr(be, field, C.cast(getattr(lib, name), proto))
+    if os.environ.get("MDNS_CHAIN", "1") != "0" and joint_kind_gauss(joint):
+        be.chain_begin = C.cast(lib.mdns_backend_chain_begin, _CHAIN_BEGIN)
+        be.chain_end = C.cast(lib.mdns_backend_chain_end, _CHAIN_END)
     be._keep = joint
     return be
 

@@ -27,7 +27,9 @@ from .multi_nested_sampler import MultiNestedSampler
 #: mdns_core_stats (include/mdns.h)
 COUNTERS = ("ndraws", "ndraw_calls", "nevals", "npoints", "iterations", "nrunning", "nsuperpoints", "passes",
             "groupings", "groupings_host", "groupings_device", "groupings_walk", "constrainers",
-            "ns_draw", "ns_group", "ns_fill", "similar")
+            "ns_draw", "ns_group", "ns_fill", "similar") + \
+    tuple("groupings_lt%s" % b for b in ("2", "8", "32", "128", "512", "2048", "8192", "inf")) + \
+    tuple("ns_group_lt%s" % b for b in ("2", "8", "32", "128", "512", "2048", "8192", "inf"))
 
 _COMPONENTS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_longlong, C.c_void_p)
@@ -331,6 +333,8 @@ class NativeCoreSampler(MultiNestedSampler):
         rc = self._L.mdns_core_fill(self._core)
         self.fill_seconds += time.perf_counter() - t0
         self._check(rc, "mdns_core_fill")
+        if self._dgroups is not None:
+            self._dgroups.ncalls = self._stat(10)           # groupings the library sent to the device
 
     def __next__(self):
         ctx = self.native

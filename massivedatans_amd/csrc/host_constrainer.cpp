@@ -222,7 +222,10 @@ struct Metric {
 enum { N_DRAWS, N_CHUNKS, N_CANDIDATES, N_PAIRS, N_REGIONS, N_RADII, N_COUNTS, N_PROPOSALS, N_INSIDE, N_TRIES,
        // nanoseconds spent in: the bootstrap choice, region_create (K6 + upload), region_count (K3),
        // proposal arithmetic + random numbers, prior transform, draw_chunk, the whole draw call
-       T_BOOTSTRAP, T_REGION, T_COUNT, T_PROPOSE, T_TRANSFORM, T_CHUNK, T_DRAW, T_JITTER, N_COUNTERS };
+       T_BOOTSTRAP, T_REGION, T_COUNT, T_PROPOSE, T_TRANSFORM, T_CHUNK, T_DRAW, T_JITTER,
+       // first batches chained on the device: with their chunk / counts only; accepted candidates whose device
+       // parameters were not bit for bit the host's (10**v: mdns_pow10.h); nanoseconds from chain_begin to chain_end
+       N_CHAINS, N_CHAIN_COUNTS, N_PARAM_MISMATCH, T_CHAIN, N_COUNTERS };
 
 inline long long now_ns()
 {
@@ -375,6 +378,17 @@ struct mdns_constrainer {
 	std::vector<double> us, ws, dir, rad, coin, xs, params, wtmp;
 	std::vector<int32_t> idx;
 	std::vector<int> counts;
+	// the draw in progress (what the chained first batch needs to know of the accept loop's state)
+	long long cur_tries = 0;
+	bool cur_region_rebuilt = false, cur_metric_rebuilt = false;
+	int cur_M = 0;
+	bool in_draw = false;
+	// outcome of a first chunk that rode along with the region's first batch (chain_begin / chain_end)
+	bool chain_valid = false;
+	int chain_B = 0, chain_accepted = -1;
+	std::vector<unsigned long long> chain_bits;
+	std::vector<double> chain_params;
+	int chain_nkept = -1;
 	// likelihood jitter of a chunk and the stream's state after each candidate's share of it
 	struct Snapshot { MT mt; int has_gauss; double gauss; };
 	std::vector<double> jitter;
@@ -575,6 +589,31 @@ bool deliver(Env &e, const double *ws, int n, long long nspent)
 	return true;
 }
 
+// how many candidates the next chunk of the draw in progress may hold when `room` are on offer: never
+// past the candidate after which the reference would rebuild its region (hiermetriclearn.py:198-211)
+int chunk_room(Env &e, long long room)
+{
+	mdns_constrainer *c = e.c;
+	if (!c->cur_region_rebuilt) {
+		long long lim = c->rebuild_every - c->ndraws_since_rebuild + 1;
+		if (lim < 1) lim = 1;
+		if (room > lim) room = lim;
+	}
+	if (!c->cur_metric_rebuilt) {
+		long long lim = 201 - c->cur_tries;
+		if (lim < 1) lim = 1;
+		if (room > lim) room = lim;
+	}
+	int B = (int) (room > 0x3fffffff ? 0x3fffffff : room);
+	if (e.be->chunk_size) {
+		const long long hint = c->last_ntoaccept > 1 ? c->last_ntoaccept : 1;
+		const int got = e.be->chunk_size(e.be->user, B, c->cur_M, (int) (hint > 0x3fffffff ? 0x3fffffff : hint));
+		if (got < 1 || got > B) return -1;
+		B = got;
+	}
+	return B;
+}
+
 // next(self.generator): fills the buffer with the next batch of candidates (consumes RNG, exactly
 // on demand)
 bool next_batch_inner(Env &e);
@@ -613,9 +652,56 @@ bool next_batch_inner(Env &e)
 			// numbers from the stream in between, and a generator that starts always proposes:
 			// `proposed` is 0)
 			const bool starting = !c->gen_started;
+			bool chained = false;
 			if (starting) {
 				c->us.resize((size_t) N * ndim);
 				mt_fill_doubles(e.mt, c->us.data(), (size_t) N * ndim);
+				// K6 of this region is running and the backend can carry on by itself: the proposals
+				// from these doubles, their membership counts and -- inside a draw -- the first chunk are
+				// queued behind it and the host waits ONCE (mdns.h, chain_begin / chain_end)
+				if (r->started && !r->has_radius && r->handle && e.be->chain_begin && e.be->chain_end && !e.prior->custom &&
+				    ndim <= 5 && N <= 1024) {
+					double mn[MDNS_MAX_DIM], mx[MDNS_MAX_DIM];
+					for (int k = 0; k < ndim; k++) { mn[k] = r->members[k]; mx[k] = r->members[k]; }
+					for (int i = 1; i < r->K; i++)
+						for (int k = 0; k < ndim; k++) {
+							const double v = r->members[(size_t) i * ndim + k];
+							if (v < mn[k]) mn[k] = v;
+							if (v > mx[k]) mx[k] = v;
+						}
+					int limit = 0;
+					if (c->in_draw) {
+						limit = chunk_room(e, N);
+						if (limit < 0) { set_error("chunk_size failed"); return false; }
+					}
+					mdns_chain_request rq;
+					rq.n = N; rq.ndim = ndim; rq.u = c->us.data(); rq.mn = mn; rq.mx = mx;
+					rq.identity = c->metric.identity ? 1 : 0;
+					rq.mean = c->metric.identity ? nullptr : c->metric.mean.data();
+					rq.scale = c->metric.identity ? nullptr : c->metric.scale.data();
+					rq.prior = e.prior; rq.limit = limit;
+					const long long t0 = now_ns();
+					if (e.be->chain_begin(e.be->user, r->handle, &rq) != 0) { set_error("chain_begin failed"); return false; }
+					c->counts.resize(N);
+					c->chain_bits.resize((size_t) (c->cur_M + 63) / 64 + 1);
+					c->chain_params.resize((size_t) 1024 * 3);
+					int nkept = -1, B = 0, accepted = -1;
+					if (e.be->chain_end(e.be->user, r->handle, c->counts.data(), &nkept, &B, &accepted, c->chain_bits.data(),
+					                    c->chain_params.data()) != 0) { set_error("chain_end failed"); return false; }
+					c->stat.add(T_CHAIN, now_ns() - t0);
+					chained = true;
+					c->stat.add(N_COUNTS, 1);
+					if (nkept >= 0) {
+						c->stat.add(N_CHAINS, 1);
+						c->chain_valid = B > 0;
+						c->chain_B = B;
+						c->chain_accepted = accepted;
+						c->chain_nkept = nkept;          // (checked against the host's own count below)
+					} else {
+						c->stat.add(N_CHAIN_COUNTS, 1);
+						c->chain_nkept = -1;
+					}
+				}
 				// like the reference, the ball proposals keep the members and the radius the generator
 				// started with (radfriendsregion.py:118-120)
 				if (!r->maxdistance(&c->gen_maxdistance)) return false;
@@ -642,8 +728,10 @@ bool next_batch_inner(Env &e)
 					const double t = range[k] * c->us[(size_t) i * ndim + k];
 					c->us[(size_t) i * ndim + k] = r->lo[k] + t;
 				}
-			c->counts.resize(N);
-			if (!r->count(c->us.data(), N, c->counts.data())) return false;
+			if (!chained) {
+				c->counts.resize(N);
+				if (!r->count(c->us.data(), N, c->counts.data())) return false;
+			}
 			c->phase = mdns_constrainer::BALL;
 			c->ws.clear();
 			int n = 0;
@@ -653,11 +741,18 @@ bool next_batch_inner(Env &e)
 					n++;
 				}
 			c->stat.add(N_INSIDE, n);
+			bool got = false;
 			if (n) {
 				const long long sp = c->spent;
 				c->spent = 0;
-				if (deliver(e, c->ws.data(), n, sp)) return true;
+				got = deliver(e, c->ws.data(), n, sp);
 			}
+			if (chained && c->chain_nkept >= 0 && (got ? c->buf_n : 0) != c->chain_nkept) {
+				set_error("chain: the device kept %d of the proposals, the host %d", c->chain_nkept, got ? c->buf_n : 0);
+				return false;
+			}
+			if (got) return true;
+			c->chain_valid = false;
 			break;
 		}
 		case mdns_constrainer::BALL: {
@@ -897,32 +992,26 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 	}
 	if (!c->has_generator) { set_error("mdns_constrainer_draw: no generator"); return 1; }
 	if (be->draw_begin && be->draw_begin(be->user, rows, M) != 0) { set_error("draw_begin failed"); return 1; }
+	struct InDraw { mdns_constrainer *c; ~InDraw() { c->in_draw = false; c->chain_valid = false; } } in_draw_guard = {c};
+	c->in_draw = true;
+	c->chain_valid = false;
+	c->cur_M = M;
 	// the accept loop of hiermetriclearn.py:181-211 with the candidates handed over in chunks: a
 	// chunk never reaches past the candidate after which the reference would rebuild its region
 	// (:198-211), so regions, RNG draws and results are those of the one-candidate-at-a-time loop
 	long long tries = 0;
 	for (;;) {
+		c->cur_tries = tries;
+		c->cur_region_rebuilt = region_rebuilt;
+		c->cur_metric_rebuilt = metric_rebuilt;
 		if (!c->has_buf || c->buf_pos >= c->buf_n) {
+			c->chain_valid = false;
 			if (!next_batch(e)) return 1;
 			if (c->buf_ntotal > 100000) c->direct_draws_efficient = false;
-		}
-		long long room = c->buf_n - c->buf_pos;
-		if (!region_rebuilt) {
-			long long lim = c->rebuild_every - c->ndraws_since_rebuild + 1;
-			if (lim < 1) lim = 1;
-			if (room > lim) room = lim;
-		}
-		if (!metric_rebuilt) {
-			long long lim = 201 - tries;
-			if (lim < 1) lim = 1;
-			if (room > lim) room = lim;
-		}
-		int B = (int) room;
-		if (be->chunk_size) {
-			const long long hint = c->last_ntoaccept > 1 ? c->last_ntoaccept : 1;
-			B = be->chunk_size(be->user, B, M, (int) (hint > 0x3fffffff ? 0x3fffffff : hint));
-			if (B < 1 || B > room) { set_error("chunk_size returned %d of %lld", B, room); return 1; }
-		}
+		} else c->chain_valid = false;
+		const long long room = c->buf_n - c->buf_pos;
+		const int B = chunk_room(e, room);
+		if (B < 1 || B > room) { set_error("chunk_size returned %d of %lld", B, room); return 1; }
 		const double *chunk = &c->buf[(size_t) c->buf_pos * ndim];
 		c->xs.resize((size_t) B * ndim);
 		c->params.resize((size_t) B * prior->nparams);
@@ -950,7 +1039,19 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 		}
 		const long long t2 = now_ns();
 		int accepted = -1, nscored = B;
-		const int rc_chunk = be->draw_chunk(be->user, c->params.data(), B, jitter, &accepted, fillbits, &nscored);
+		int rc_chunk = 0;
+		if (c->chain_valid) {
+			// this chunk rode along with the region's first batch: scored and committed already
+			c->chain_valid = false;
+			if (c->chain_B != B || c->buf_pos != 0) { set_error("chain: a chunk of %d was scored, the host's is %d (position %d)", c->chain_B, B, c->buf_pos); return 1; }
+			accepted = c->chain_accepted;
+			if (accepted >= 0) {
+				memcpy(fillbits, c->chain_bits.data(), (size_t) ((M + 63) / 64) * sizeof(unsigned long long));
+				// the parameters the device scored the accepted candidate with against the host's own
+				if (memcmp(&c->chain_params[(size_t) accepted * 3], &c->params[(size_t) accepted * prior->nparams], 3 * sizeof(double)) != 0)
+					c->stat.add(N_PARAM_MISMATCH, 1);
+			}
+		} else rc_chunk = be->draw_chunk(be->user, c->params.data(), B, jitter, &accepted, fillbits, &nscored);
 		if (jitter && rc_chunk == 0) {
 			// the reference evaluated exactly the candidates up to the accepted one (or all `nscored`)
 			const int last = accepted >= 0 ? accepted : nscored - 1;

@@ -76,7 +76,9 @@ typedef std::shared_ptr<Cons> ConsRef;
 
 // index of a counter in mdns_core_stats' output
 enum { C_NDRAWS, C_NDRAW_CALLS, C_NEVALS, C_NPOINTS, C_ITER, C_NRUN, C_NSUPER, C_PASSES, C_GROUPINGS, C_GROUPINGS_HOST,
-       C_GROUPINGS_DEVICE, C_GROUPINGS_WALK, C_CONSTRAINERS, C_NS_DRAW, C_NS_GROUP, C_NS_FILL, C_SIMILAR, C_COUNTERS };
+       C_GROUPINGS_DEVICE, C_GROUPINGS_WALK, C_CONSTRAINERS, C_NS_DRAW, C_NS_GROUP, C_NS_FILL, C_SIMILAR,
+       // groupings by selection size (< 2, 8, 32, 128, 512, 2048, 8192, more): calls and nanoseconds
+       C_SIZE_CALLS, C_SIZE_NS = C_SIZE_CALLS + 8, C_COUNTERS = C_SIZE_NS + 8 };
 
 }  // namespace
 
@@ -618,7 +620,15 @@ extern "C" int mdns_core_fill(mdns_core *c)
 			const long long t0 = now_ns();
 			c->stat[C_GROUPINGS]++;
 			const bool ok = c->use_graph ? groups_graph(c, *sel, dst) : groups_walk(c, *sel, dst);
-			c->stat[C_NS_GROUP] += now_ns() - t0;
+			const long long dt = now_ns() - t0;
+			c->stat[C_NS_GROUP] += dt;
+			{
+				static const size_t edges[8] = {2, 8, 32, 128, 512, 2048, 8192, (size_t) -1};
+				int bucket = 0;
+				while (sel->size() >= edges[bucket]) bucket++;
+				c->stat[C_SIZE_CALLS + bucket]++;
+				c->stat[C_SIZE_NS + bucket] += dt;
+			}
 			if (!ok) return 1;
 			if (!focussed) have_superset = true;
 			groups = &dst;

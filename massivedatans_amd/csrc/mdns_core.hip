@@ -1016,6 +1016,15 @@ mdns_region *mdns::region_begin_bootstrapped(const double *members, int K, int n
 	return create_bootstrapped(members, K, ndim, packed, nbootstraps, nullptr, false);
 }
 
+// what the chain kernels (mdns_chain.hip) need of a region whose radius is being computed or known on
+// the device
+bool mdns::region_view(mdns_region *r, RegionView *out)
+{
+	if (!r || !out || !r->on_device) return false;
+	out->d_members = r->d_members; out->K = r->K; out->ndim = r->ndim; out->d_res = r->d_res;
+	return true;
+}
+
 extern "C" mdns_region *mdns_region_wrap_dev(const double *d_members, int K, int ndim)
 {
 	if (!ctx()) return nullptr;

@@ -192,6 +192,40 @@ bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const uns
                              int nbootstraps, double *d_round_sq, const BootstrapFinish *finish);
 bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out);
 
+// ---- the first batch of a region without a host look in between (mdns_chain.hip) --------
+// what the chain kernels need of a region whose radius computation has been launched (mdns_core.hip)
+struct RegionView { const double *d_members; int K, ndim; const RegionResult *d_res; };
+bool region_view(mdns_region *r, RegionView *out);
+static constexpr int kChainMost = 1024;        // proposals per batch at most (radfriendsregion.py:124 uses 1000)
+static constexpr int kChainDim = 8;            // dimensions at most
+// by-value description of what happens to a proposal between the membership test and the kernel:
+// the metric's inverse transform (sdml.py), the unit-cube test (hiermetriclearn.py:113-116), the prior
+// transform and the kernel's parameters (mdns_prior)
+struct ChainSpec {
+	int n, ndim, nparams, limit, identity;
+	double mn[kChainDim], mx[kChainDim];                   // extent of the members (radfriendsregion.py:69-70)
+	double mean[kChainDim], scale[kChainDim];              // y * scale + mean
+	double a[kChainDim], b[kChainDim];
+	int pow10[kChainDim], kernel_pow10[kChainDim];
+};
+// mapped host memory the chain kernels fill: {seq | nkept, B | counts | parameters of the candidates scored}
+struct ChainBox {
+	unsigned long long seq;
+	int nkept, B;
+	int counts[kChainMost];
+	double params[kChainMost][3];
+	double u[kChainMost * kChainDim];                      // in: the raw doubles of the proposals
+};
+// proposals lo + (hi - lo) u from the raw doubles in `box_dev->u`, radius and threshold from d_res;
+// counts to box_dev->counts and d_counts, proposals to d_props [n][ndim]; mail != nullptr: the last
+// workgroup raises box->seq (a chain that ends here)
+bool launch_box_count(const RegionView &rv, const ChainSpec &spec, ChainBox *box_dev, double *d_props, int *d_counts,
+                      const CountMail *mail);
+// k_chunk_accept with the candidates taken from the kept proposals (first min(kept, limit) of them)
+bool launch_chain_accept(const mdns_spectra *s, const ChainSpec &spec, const double *d_props, const int *d_counts,
+                         ChainBox *box_dev, double scale, const int *d_rows_in, int *d_rows_dev, int M,
+                         const double *d_higher, int *d_flags, int stamp, const JointTrail &trail, void *d_header);
+
 // optional per-launch event timing (mdns_profile); which: 0 gauss rows, 1 muse rows,
 // 2 count-within, 3 nearest-chosen.  Use as:  { ProfileScope ps(which); launch...; }
 struct ProfileScope {

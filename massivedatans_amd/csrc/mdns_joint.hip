@@ -398,6 +398,13 @@ struct mdns_joint {
 	// no shelf holds more than this many entries (set by prepare from the purge's keep bits, +1 per
 	// accepted chunk, -1 per advance): when it reaches the capacity the shelves are grown
 	int shelf_bound = 0;
+	// the first batch of a region without a host look in between (mdns_backend_chain_*, mdns_chain.hip)
+	ChainBox *h_chain = nullptr, *h_chain_dev = nullptr;   // mapped
+	double *d_chain_props = nullptr;
+	int *d_chain_counts = nullptr, *d_chain_ticket = nullptr;
+	unsigned long long chain_seq = 0;
+	int chain_state = 0;               // 0 none, 1 counts only (poll h_chain->seq), 2 full (poll the commit's mailbox)
+	int chain_n = 0;
 };
 
 static size_t result_bytes(int M) { return sizeof(JointHeader) + (size_t) ((M + 63) / 64) * 8 + (size_t) M * 8; }
@@ -420,6 +427,10 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	if (j->d_filter_scratch) (void) hipFree(j->d_filter_scratch);
 	if (j->d_jitter) (void) hipFree(j->d_jitter);
 	if (j->h_in) (void) hipHostFree(j->h_in);
+	if (j->h_chain) (void) hipHostFree(j->h_chain);
+	if (j->d_chain_props) (void) hipFree(j->d_chain_props);
+	if (j->d_chain_counts) (void) hipFree(j->d_chain_counts);
+	if (j->d_chain_ticket) (void) hipFree(j->d_chain_ticket);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
 	for (void *b : trail) if (b) (void) hipFree(b);
 	if (j->h_box) (void) hipHostFree(j->h_box);
@@ -1203,4 +1214,136 @@ extern "C" int mdns_backend_chunk_size(void *joint, int offered, int M, int hint
 	if (budget > want) budget = want;
 	if (budget > MDNS_JOINT_MAX_BATCH) budget = MDNS_JOINT_MAX_BATCH;
 	return offered < budget ? offered : (int) budget;
+}
+
+// ---------------------------------------------------------------------------------------
+// the first batch of a fresh region without a host look in between (mdns.h Part 5, chain_begin /
+// chain_end; kernels in mdns_chain.hip)
+// ---------------------------------------------------------------------------------------
+extern "C" int mdns_backend_chain_begin(void *joint, void *region, const mdns_chain_request *rq)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !j || !region || !rq || !rq->u || !rq->mn || !rq->mx || !rq->prior) { set_error("mdns_backend_chain_begin: null argument"); return 1; }
+	if (!j->sel_open) { set_error("mdns_backend_chain_begin: no draw begun"); return 1; }
+	if (j->chain_state != 0) { set_error("mdns_backend_chain_begin: a chain is in flight"); return 1; }
+	RegionView rv;
+	if (!region_view((mdns_region *) region, &rv)) { set_error("mdns_backend_chain_begin: the region's radius is not on the device"); return 1; }
+	const mdns_prior *prior = rq->prior;
+	if (rq->n <= 0 || rq->n > kChainMost || rq->ndim != rv.ndim || rv.ndim > 5 || prior->ndim != rq->ndim) {
+		set_error("mdns_backend_chain_begin: %d proposals, %d dimensions (region: %d)", rq->n, rq->ndim, rv.ndim);
+		return 1;
+	}
+	if (!j->h_chain) {
+		if (!MDNS_HIP(hipHostMalloc((void **) &j->h_chain, sizeof(ChainBox), hipHostMallocMapped)) ||
+		    !MDNS_HIP(hipHostGetDevicePointer((void **) &j->h_chain_dev, j->h_chain, 0)) ||
+		    !MDNS_HIP(hipMalloc((void **) &j->d_chain_props, (size_t) kChainMost * kChainDim * sizeof(double))) ||
+		    !MDNS_HIP(hipMalloc((void **) &j->d_chain_counts, (size_t) kChainMost * sizeof(int))) ||
+		    !MDNS_HIP(hipMalloc((void **) &j->d_chain_ticket, sizeof(int))) ||
+		    !MDNS_HIP(hipMemsetAsync(j->d_chain_ticket, 0, sizeof(int), c->stream))) return 1;
+		memset(j->h_chain, 0, sizeof(ChainBox));
+	}
+	const int M = j->sel_M;
+	// the chunk rides along when the problem is the Gaussian line with the library's own prior
+	// transform and the chunk would take the two-launch path anyway
+	int limit = rq->limit;
+	if (limit > MDNS_JOINT_MAX_BATCH) limit = MDNS_JOINT_MAX_BATCH;
+	const bool full = limit > 0 && j->kind == 0 && !prior->custom && prior->nparams == 3 && prior->jitter_sigma == 0 && M > 0 &&
+	                  chunk_fits(j->s, M, limit);
+	ChainSpec spec;
+	memset(&spec, 0, sizeof spec);
+	spec.n = rq->n; spec.ndim = rq->ndim; spec.nparams = 3; spec.limit = full ? limit : 0;
+	spec.identity = rq->identity || !rq->mean || !rq->scale;
+	for (int k = 0; k < rq->ndim; k++) {
+		spec.mn[k] = rq->mn[k]; spec.mx[k] = rq->mx[k];
+		spec.mean[k] = spec.identity ? 0.0 : rq->mean[k];
+		spec.scale[k] = spec.identity ? 1.0 : rq->scale[k];
+		spec.a[k] = prior->a[k]; spec.b[k] = prior->b[k];
+		spec.pow10[k] = prior->pow10[k]; spec.kernel_pow10[k] = prior->kernel_pow10[k];
+	}
+	memcpy(j->h_chain->u, rq->u, (size_t) rq->n * rq->ndim * sizeof(double));
+	j->h_chain->nkept = -1; j->h_chain->B = -1;
+	j->chain_n = rq->n;
+	if (!full) {
+		const CountMail mail = {j->d_chain_ticket, &j->h_chain_dev->seq, ++j->chain_seq};
+		if (!launch_box_count(rv, spec, j->h_chain_dev, j->d_chain_props, j->d_chain_counts, &mail)) return 1;
+		j->chain_state = 1;
+		return 0;
+	}
+	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
+	if (!launch_box_count(rv, spec, j->h_chain_dev, j->d_chain_props, j->d_chain_counts, nullptr)) return 1;
+	JointTrail trail;
+	if (!joint_trail(j, limit, M, &trail)) return 1;
+	const int *rows_in = nullptr;
+	int *rows_out = nullptr;
+	if (j->sel_rows) {
+		if (j->sel_on_device) rows_in = j->d_sel_rows;
+		else { rows_in = (const int *) (j->h_in_dev + kInParams); rows_out = j->d_sel_rows; }
+	}
+	const double scale = -0.5 / (j->noise_level * j->noise_level);
+	if (j->chunk_seq == 0x7fffffff) {
+		if (!MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kFlagInts * sizeof(int), c->stream))) return 1;
+		j->chunk_seq = 1;
+	}
+	const int flag = ++j->chunk_seq;
+	char *base = j->d_result;
+	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
+	if (!launch_chain_accept(j->s, spec, j->d_chain_props, j->d_chain_counts, j->h_chain_dev, scale, rows_in, rows_out, M,
+	                         j->st.higher, j->d_flags, flag, trail, base)) return 1;
+	if (j->sel_rows) j->sel_on_device = true;
+	const int *thr_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+	if (M <= 128) {
+		if (!launch_chunk_commit(thr_rows, M, limit, j->d_flags, flag, trail, j->st, base, bits, j->h_box_dev, ++j->box_seq)) return 1;
+	} else {
+		if (!launch_joint_commit_trail(thr_rows, M, limit, j->d_flags, trail, j->st, base, bits, flag)) return 1;
+		hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
+		                   j->h_box_dev, ++j->box_seq);
+		if (!MDNS_HIP(hipGetLastError())) return 1;
+	}
+	j->box_pending = true;
+	j->trail_valid = false;
+	j->last_B = 0;
+	j->chain_state = 2;
+	return 0;
+}
+
+extern "C" int mdns_backend_chain_end(void *joint, void *region, int *counts, int *nkept, int *B, int *accepted,
+                                      unsigned long long *fillbits, double *params)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	(void) region;
+	if (!c || !j || !counts || !nkept || !B || !accepted) { set_error("mdns_backend_chain_end: null argument"); return 1; }
+	const int state = j->chain_state;
+	j->chain_state = 0;
+	*accepted = -1; *nkept = -1; *B = 0;
+	if (state == 1) {
+		volatile unsigned long long *at = &j->h_chain->seq;
+		for (unsigned spin = 0; *at != j->chain_seq; spin++) {
+			if ((spin & 1023) != 1023) continue;
+			const hipError_t e = hipStreamQuery(c->stream);
+			if (e == hipErrorNotReady) continue;
+			if (e != hipSuccess) { set_error("chain: the membership count failed: %s", hipGetErrorString(e)); return 1; }
+			if (*at != j->chain_seq) {
+				(void) hipMemsetAsync(j->d_chain_ticket, 0, sizeof(int), c->stream);
+				set_error("chain: the membership count finished without a result");
+				return 1;
+			}
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
+		memcpy(counts, (const void *) j->h_chain->counts, (size_t) j->chain_n * sizeof(int));
+		return 0;
+	}
+	if (state != 2) { set_error("mdns_backend_chain_end: no chain in flight"); return 1; }
+	if (mdns_joint_fetch(j, j->sel_M, accepted, fillbits) != 0) return 1;
+	memcpy(counts, (const void *) j->h_chain->counts, (size_t) j->chain_n * sizeof(int));
+	*nkept = j->h_chain->nkept;
+	*B = j->h_chain->B;
+	if (*B < 0 || *B > MDNS_JOINT_MAX_BATCH || *nkept < *B || *accepted >= *B) {
+		set_error("chain: the device reports %d kept proposals, a chunk of %d, accepted %d", *nkept, *B, *accepted);
+		return 1;
+	}
+	if (params && *B > 0) memcpy(params, (const void *) j->h_chain->params, (size_t) *B * 3 * sizeof(double));
+	if (*accepted >= 0) j->shelf_bound++;
+	return 0;
 }

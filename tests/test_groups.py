@@ -198,7 +198,7 @@ def test_bad_arguments_are_refused():
 
 
 @pytest.mark.parametrize("key", ["horns-graph_100_40_400", "nothing-graph_100_40_400", "horns-graph_300_40_300"])
-def test_graph_variant_on_the_gpu_matches_the_cpu_path(key):
+def test_graph_variant_on_the_gpu_matches_the_cpu_path(key, monkeypatch):
     """USE_GRAPH=1 (the reference's default grouping) end to end: the GPU run -- components and
     distinct ids from the device (csrc/mdns_groups.hip), draws decided on the device -- against
     the host orchestration on the CPU oracle backends, whose graph grouping is native host code
@@ -211,6 +211,8 @@ def test_graph_variant_on_the_gpu_matches_the_cpu_path(key):
     want = table[key]
     kind, ndata, nlive, cap = key.split("_")
     data = (gen.horns if kind.startswith("horns") else gen.nothing)(int(ndata))
+    # (the sampler core groups small selections on the host: here every selection goes to the device)
+    monkeypatch.setenv("MDNS_CORE_HOST_EDGES", "0")
     with np.errstate(all="ignore"):
         results, sampler, _, _ = sample.run(data["x"], data["y"], nlive_points=int(nlive), max_samples=int(cap), use_graph=True)
     assert sampler._dgroups is not None and sampler._dgroups.ncalls > 0
@@ -230,6 +232,7 @@ def test_device_grouping_equals_host_grouping_end_to_end(kind, ndata, nlive, cap
     from massivedatans_amd import sample
     data = (gen.horns if kind == "horns" else gen.nothing)(ndata)
     runs = []
+    monkeypatch.setenv("MDNS_CORE_HOST_EDGES", "0")     # with a device grouping, every selection goes there
     for device in ("1", "0"):
         monkeypatch.setenv("MDNS_DEVICE_GROUPS", device)
         with np.errstate(all="ignore"):

@@ -119,6 +119,7 @@ from massivedatans_amd import gen, parallel, sample
 from massivedatans_amd.like import GaussLineSpectra
 from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
 d = gen.horns(300)
+os.environ["MDNS_CORE_HOST_EDGES"] = "0"      # every grouping on the device
 backend = parallel.ShardedGaussLine(d["x"], d["y"], lambda x, y: GaussLineSpectra(x, y, noise_level=0.01))
 out = {}
 for name, fused, use_graph in (("classic", False, False), ("fused", True, False), ("graph", True, True)):
