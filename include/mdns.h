@@ -597,6 +597,10 @@ const char *mdns_core_last_error(void);
 /* selections of at most this many (data set, live point) pairs are grouped on the host even when a
  * device backend is there (default 32768) */
 void mdns_core_set_host_edges(mdns_core *c, long long edges);
+/* The focussed passes of an iteration select ever fewer data sets: their components are analysed once
+ * per iteration (selections of at most edges_max pairs; 0: never) and then kept up to date as data sets
+ * leave (csrc/host_sampler_inc.h); check != 0 compares every such result with a fresh computation. */
+void mdns_core_set_incremental(mdns_core *c, long long edges_max, int check);
 /* the nlive prior draws every data set starts from (:88-103): u, x f64[nlive][ndim] */
 int mdns_core_set_initial(mdns_core *c, const double *u, const double *x);
 /* `prepare` (:137-138): keep uint8[nrunning][width]; entry e of the r-th running data set's shelf stays
@@ -625,8 +629,9 @@ int mdns_core_get_superpoints(const mdns_core *c, int32_t *out, int cap);
  * sets, [6] superpoints, [7] passes, [8] groupings, of which [9] on the host, [10] on the device, [11] walks,
  * [12] constrainers created, nanoseconds in [13] mdns_constrainer_draw, [14] grouping, [15] mdns_core_fill,
  * [16] draws served by the "similar to the last call" shortcut, [17..24] groupings by selection size
- * (fewer than 2, 8, 32, 128, 512, 2048, 8192 data sets, more) and [25..32] the nanoseconds they took */
-#define MDNS_CORE_COUNTERS 33
+ * (fewer than 2, 8, 32, 128, 512, 2048, 8192 data sets, more) and [25..32] the nanoseconds they took;
+ * focussed groupings kept up to date: [33] analyses from scratch, [34] updates, [35] updates that split a component */
+#define MDNS_CORE_COUNTERS 36
 void mdns_core_stats(const mdns_core *c, long long *out);
 
 #ifdef __cplusplus

@@ -49,7 +49,8 @@ HOST_ABI_SYMBOLS = (
     "mdns_constrainer_draw", "mdns_constrainer_stats", "mdns_constrainer_share_stats", "mdns_host_last_error",
     "mdns_host_rng_get_gauss", "mdns_host_rng_set_gauss",
     # Part 6 (csrc/host_sampler.cpp)
-    "mdns_core_create", "mdns_core_destroy", "mdns_core_last_error", "mdns_core_set_host_edges", "mdns_core_set_initial",
+    "mdns_core_create", "mdns_core_destroy", "mdns_core_last_error", "mdns_core_set_host_edges", "mdns_core_set_incremental",
+    "mdns_core_set_initial",
     "mdns_core_purge", "mdns_core_fill", "mdns_core_advance", "mdns_core_cut_down", "mdns_core_npoints",
     "mdns_core_nrunning", "mdns_core_pile_u", "mdns_core_pile_x", "mdns_core_get_ids", "mdns_core_get_shelves",
     "mdns_core_get_superpoints", "mdns_core_stats",

@@ -29,7 +29,8 @@ COUNTERS = ("ndraws", "ndraw_calls", "nevals", "npoints", "iterations", "nrunnin
             "groupings", "groupings_host", "groupings_device", "groupings_walk", "constrainers",
             "ns_draw", "ns_group", "ns_fill", "similar") + \
     tuple("groupings_lt%s" % b for b in ("2", "8", "32", "128", "512", "2048", "8192", "inf")) + \
-    tuple("ns_group_lt%s" % b for b in ("2", "8", "32", "128", "512", "2048", "8192", "inf"))
+    tuple("ns_group_lt%s" % b for b in ("2", "8", "32", "128", "512", "2048", "8192", "inf")) + \
+    ("inc_builds", "inc_updates", "inc_splits")
 
 _COMPONENTS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_longlong, C.c_void_p, C.c_void_p, C.c_void_p,
                           C.c_longlong, C.c_void_p)
@@ -56,6 +57,8 @@ def _declare(L):
     L.mdns_core_last_error.argtypes = []
     L.mdns_core_set_host_edges.restype = None
     L.mdns_core_set_host_edges.argtypes = [C.c_void_p, C.c_longlong]
+    L.mdns_core_set_incremental.restype = None
+    L.mdns_core_set_incremental.argtypes = [C.c_void_p, C.c_longlong, C.c_int]
     L.mdns_core_set_initial.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mdns_core_purge.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.mdns_core_fill.argtypes = [C.c_void_p]
@@ -154,6 +157,12 @@ class NativeCoreSampler(MultiNestedSampler):
         edges = os.environ.get("MDNS_CORE_HOST_EDGES")
         if edges:
             L.mdns_core_set_host_edges(self._core, int(edges))
+        # MDNS_CORE_INCREMENTAL=0: every focussed pass computes its components afresh;
+        # MDNS_CORE_CHECK_GROUPS=1: the incremental result of every pass against a fresh one
+        inc_edges = int(os.environ.get("MDNS_CORE_INCREMENTAL_EDGES", "4000000"))
+        if os.environ.get("MDNS_CORE_INCREMENTAL", "1") == "0":
+            inc_edges = 0
+        L.mdns_core_set_incremental(self._core, inc_edges, 1 if os.environ.get("MDNS_CORE_CHECK_GROUPS") == "1" else 0)
         self._check(L.mdns_core_set_initial(self._core, us.ctypes.data, xs.ctypes.data), "mdns_core_set_initial")
         self._stats = numpy.zeros(len(COUNTERS), dtype=numpy.int64)
         self._lp_cache = None

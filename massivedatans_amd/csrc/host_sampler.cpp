@@ -78,7 +78,9 @@ typedef std::shared_ptr<Cons> ConsRef;
 enum { C_NDRAWS, C_NDRAW_CALLS, C_NEVALS, C_NPOINTS, C_ITER, C_NRUN, C_NSUPER, C_PASSES, C_GROUPINGS, C_GROUPINGS_HOST,
        C_GROUPINGS_DEVICE, C_GROUPINGS_WALK, C_CONSTRAINERS, C_NS_DRAW, C_NS_GROUP, C_NS_FILL, C_SIMILAR,
        // groupings by selection size (< 2, 8, 32, 128, 512, 2048, 8192, more): calls and nanoseconds
-       C_SIZE_CALLS, C_SIZE_NS = C_SIZE_CALLS + 8, C_COUNTERS = C_SIZE_NS + 8 };
+       C_SIZE_CALLS, C_SIZE_NS = C_SIZE_CALLS + 8,
+       // focussed groupings kept up to date (host_sampler_inc.h): analyses from scratch, updates, updates that split a component
+       C_INC_BUILDS = C_SIZE_NS + 8, C_INC_UPDATES, C_INC_SPLITS, C_COUNTERS };
 
 }  // namespace
 
@@ -130,11 +132,16 @@ struct mdns_core {
 	std::vector<int32_t> group_of, walk_points;
 	std::vector<int64_t> walk_offsets;
 	std::vector<int32_t> empty_list;
+	// the components of the focussed passes of the current iteration, kept up to date (host_sampler_inc.h)
+	void *inc = nullptr;
+	void (*inc_free)(void *) = nullptr;
+	long long inc_edges_max = 4000000;         // first focussed selections beyond this many pairs are not analysed here
+	bool check_groups = false;                 // MDNS_CORE_CHECK_GROUPS=1: every incremental result against a fresh one
 	// draw outputs
 	std::vector<double> u_out, x_out;
 	std::vector<unsigned long long> bits;
 
-	~mdns_core() { if (walk) mdns_host_walk_destroy(walk); }
+	~mdns_core() { if (walk) mdns_host_walk_destroy(walk); if (inc && inc_free) inc_free(inc); }
 	int shelf_n(int pos) const { return (int) shelf[pos].size() - head[pos]; }
 };
 
@@ -267,6 +274,13 @@ bool groups_graph(mdns_core *c, const std::vector<int32_t> &sel, std::vector<Gro
 	// than 2 nlive distinct ids, or superpoints known (which does not imply one component: see
 	// MultiNestedSampler.generate_subsets_graph in multi_nested_sampler.py of this package)
 	if (ncomp == 1 || nd < 2LL * c->nlive || !c->superpoints.empty()) {
+		{
+			static const char *log_path = getenv("MDNS_CORE_GROUP_LOG");
+			if (log_path) {
+				static FILE *f = fopen((std::string(log_path) + ".single").c_str(), "w");
+				if (f) fprintf(f, "%lld %d %lld %d %zu\n", c->global_iter, M, nd, ncomp, c->superpoints.size());
+			}
+		}
 		Group g;
 		g.members = sel;
 		g.ids = c->distinct_buf;
@@ -302,6 +316,21 @@ bool groups_graph(mdns_core *c, const std::vector<int32_t> &sel, std::vector<Gro
 		}
 		out[table[L]].members.push_back(sel[k]);
 	}
+	{
+		// MDNS_CORE_GROUP_LOG=<file>: M, distinct ids, components, the three largest (analysis only)
+		static const char *log_path = getenv("MDNS_CORE_GROUP_LOG");
+		if (log_path) {
+			static FILE *f = fopen(log_path, "w");
+			if (f) {
+				size_t top[3] = {0, 0, 0};
+				for (const Group &g : out) {
+					size_t v = g.members.size();
+					for (int t = 0; t < 3; t++) if (v > top[t]) { const size_t w = top[t]; top[t] = v; v = w; }
+				}
+				fprintf(f, "%lld %d %lld %d %zu %zu %zu\n", c->global_iter, M, nd, ncomp, top[0], top[1], top[2]);
+			}
+		}
+	}
 	for (long long t = 0; t < nd; t++) {
 		const int32_t L = idlabels[t];
 		if (L < 0 || (size_t) L >= nlabel || table[L] < 0 || table[L] >= (int32_t) out.size()) {
@@ -309,6 +338,53 @@ bool groups_graph(mdns_core *c, const std::vector<int32_t> &sel, std::vector<Gro
 			return false;
 		}
 		out[table[L]].ids.push_back(c->distinct_buf[t]);
+	}
+	return true;
+}
+
+}  // namespace
+
+#include <algorithm>
+#include "host_sampler_inc.h"
+
+namespace {
+
+Incremental &inc_state(mdns_core *c)
+{
+	if (!c->inc) {
+		c->inc = new Incremental();
+		c->inc_free = [](void *p) { delete (Incremental *) p; };
+	}
+	return *(Incremental *) c->inc;
+}
+
+// generate_subsets_graph for the focussed passes: the first one of an iteration analyses its
+// selection, the later ones update that analysis (host_sampler_inc.h)
+bool groups_focussed(mdns_core *c, const std::vector<int32_t> &sel, std::vector<Group> &out)
+{
+	Incremental &I = inc_state(c);
+	if (sel.size() == 1) return groups_graph(c, sel, out);          // (its own live points, in slot order)
+	if (!I.valid) {
+		if ((long long) sel.size() * c->nlive > c->inc_edges_max) return groups_graph(c, sel, out);
+		inc_build(c, I, sel);
+		c->stat[C_INC_BUILDS]++;
+	} else {
+		const long long before = I.splits;
+		inc_update(c, I, sel);
+		c->stat[C_INC_UPDATES]++;
+		c->stat[C_INC_SPLITS] += I.splits - before;
+	}
+	inc_emit(c, I, sel, out);
+	if (c->check_groups) {
+		std::vector<Group> fresh;
+		if (!groups_graph(c, sel, fresh)) return false;
+		bool same = fresh.size() == out.size();
+		for (size_t g = 0; same && g < fresh.size(); g++) same = fresh[g].members == out[g].members && fresh[g].ids == out[g].ids;
+		if (!same) {
+			core_error("incremental grouping differs from a fresh one (iteration %lld, %zu data sets: %zu groups against %zu)",
+			           c->global_iter, sel.size(), out.size(), fresh.size());
+			return false;
+		}
 	}
 	return true;
 }
@@ -544,6 +620,12 @@ extern "C" mdns_core *mdns_core_create(int nlive, int ndata, int ndim, int nsupe
 extern "C" void mdns_core_destroy(mdns_core *c) { delete c; }
 
 extern "C" void mdns_core_set_host_edges(mdns_core *c, long long edges) { if (c) c->host_edges_max = edges; }
+extern "C" void mdns_core_set_incremental(mdns_core *c, long long edges_max, int check)
+{
+	if (!c) return;
+	c->inc_edges_max = edges_max;
+	c->check_groups = check != 0;
+}
 
 // the nlive prior draws every data set starts from (multi_nested_sampler.py:88-103)
 extern "C" int mdns_core_set_initial(mdns_core *c, const double *u, const double *x)
@@ -590,6 +672,7 @@ extern "C" int mdns_core_fill(mdns_core *c)
 	const long long t_fill = now_ns();
 	std::vector<Group> superset_groups, tmp;
 	bool have_superset = false;
+	if (c->inc) ((Incremental *) c->inc)->valid = false;       // the id matrix changed since the last iteration
 	std::vector<int32_t> everybody;
 	long long passes = 0;
 	bool first_list = true;
@@ -619,7 +702,8 @@ extern "C" int mdns_core_fill(mdns_core *c)
 			std::vector<Group> &dst = focussed ? tmp : superset_groups;
 			const long long t0 = now_ns();
 			c->stat[C_GROUPINGS]++;
-			const bool ok = c->use_graph ? groups_graph(c, *sel, dst) : groups_walk(c, *sel, dst);
+			const bool ok = !c->use_graph ? groups_walk(c, *sel, dst)
+			                : (focussed && c->inc_edges_max > 0 ? groups_focussed(c, *sel, dst) : groups_graph(c, *sel, dst));
 			const long long dt = now_ns() - t0;
 			c->stat[C_NS_GROUP] += dt;
 			{
@@ -769,4 +853,51 @@ extern "C" void mdns_core_stats(const mdns_core *c, long long *out)
 	out[C_ITER] = c->global_iter;
 	out[C_NRUN] = c->nrun;
 	out[C_NSUPER] = (long long) c->superpoints.size();
+}
+
+// ---- test entry points (tests/test_core.py): the grouping on a planted id matrix ----
+// ids int32[nlive][nrunning] (the reference's orientation); every id below npoints
+extern "C" int mdns_core_debug_set_ids(mdns_core *c, const int32_t *ids, long long npoints, int nsuperpoints)
+{
+	if (!c || !ids || npoints <= 0) return 1;
+	for (int pos = 0; pos < c->nrun; pos++)
+		for (int p = 0; p < c->nlive; p++) {
+			const int32_t q = ids[(size_t) p * c->nrun + pos];
+			if (q < 0 || q >= npoints) { core_error("mdns_core_debug_set_ids: id %d", q); return 1; }
+			c->lp[(size_t) pos * c->nlive + p] = q;
+		}
+	c->npile = npoints;
+	c->pile_u.resize((size_t) npoints * c->ndim);
+	c->pile_x.resize((size_t) npoints * c->ndim);
+	c->superpoints.assign((size_t) (nsuperpoints > 0 ? nsuperpoints : 0), 0);
+	c->walk_stale = true;
+	if (c->inc) ((Incremental *) c->inc)->valid = false;
+	return 0;
+}
+
+// the groups of the selection sel int32[M] (positions, ascending): group_of int32[M] = group number of
+// every selected data set (groups in output order), ids = the groups' id lists one after the other,
+// offsets int64[ngroups + 1].  focussed: through the incremental path (a sequence of shrinking
+// selections; `restart` begins a new sequence).  Returns the number of groups, negative on failure.
+extern "C" int mdns_core_debug_groups(mdns_core *c, const int32_t *sel, int M, int focussed, int restart,
+                                      int32_t *group_of, int32_t *ids, long long cap, long long *offsets)
+{
+	if (!c || !sel || M <= 0 || !group_of || !ids || !offsets) return -1;
+	std::vector<int32_t> s(sel, sel + M);
+	std::vector<Group> out;
+	if (restart && c->inc) ((Incremental *) c->inc)->valid = false;
+	const bool ok = !c->use_graph ? groups_walk(c, s, out) : (focussed ? groups_focussed(c, s, out) : groups_graph(c, s, out));
+	if (!ok) return -1;
+	std::vector<int32_t> at((size_t) c->nrun, -1);
+	for (int k = 0; k < M; k++) at[s[k]] = k;
+	long long n = 0;
+	offsets[0] = 0;
+	for (size_t g = 0; g < out.size(); g++) {
+		for (int32_t pos : out[g].members) group_of[at[pos]] = (int32_t) g;
+		if (n + (long long) out[g].ids.size() > cap) return -2;
+		memcpy(ids + n, out[g].ids.data(), out[g].ids.size() * sizeof(int32_t));
+		n += (long long) out[g].ids.size();
+		offsets[g + 1] = n;
+	}
+	return (int) out.size();
 }

@@ -32,7 +32,7 @@ def sanitized(tmp_path_factory):
     inc = ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
     objs = []
     for src, cc, std in (("host_groups.c", "gcc", "-std=c99"), ("host_rng.c", "gcc", "-std=c99"),
-                         ("host_constrainer.cpp", "g++", "-std=c++17")):
+                         ("host_constrainer.cpp", "g++", "-std=c++17"), ("host_sampler.cpp", "g++", "-std=c++17")):
         obj = str(out / (src + ".o"))
         subprocess.run([cc, std, "-fPIC", "-ffp-contract=off", "-Wall"] + SAN + inc + ["-c", os.path.join(CSRC, src), "-o", obj], check=True)
         objs.append(obj)
@@ -68,3 +68,11 @@ def test_native_constrainer_traces_under_sanitizers(sanitized):
     """The native constrainer end to end (region builds, all proposal kinds, metric refits, the
     chunked accept loop) on the two reference traces that reach every branch quickly."""
     _replay(sanitized, ["tests/test_orchestration.py", "-k", "native and (nothing4 or horns3 or horns12)"])
+
+
+def test_sampler_core_under_sanitizers(sanitized):
+    """The sampler core (csrc/host_sampler.cpp: passes, grouping -- fresh and kept up to date --, constrainer
+    cache, shelves) on reference traces in both grouping modes, and the grouping stress test."""
+    env = dict(sanitized, MDNS_CORE_CHECK_GROUPS="1")
+    _replay(env, ["tests/test_orchestration.py", "tests/test_core.py", "-k",
+                  "test_fresh_and_incremental or (core and (nothing4 or horns3 or horns12))"])
