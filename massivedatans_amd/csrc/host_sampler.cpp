@@ -364,6 +364,7 @@ bool groups_focussed(mdns_core *c, const std::vector<int32_t> &sel, std::vector<
 {
 	Incremental &I = inc_state(c);
 	if (sel.size() == 1) return groups_graph(c, sel, out);          // (its own live points, in slot order)
+	const long long t_start = now_ns();
 	if (!I.valid) {
 		if ((long long) sel.size() * c->nlive > c->inc_edges_max) return groups_graph(c, sel, out);
 		inc_build(c, I, sel);
@@ -374,7 +375,17 @@ bool groups_focussed(mdns_core *c, const std::vector<int32_t> &sel, std::vector<
 		c->stat[C_INC_UPDATES]++;
 		c->stat[C_INC_SPLITS] += I.splits - before;
 	}
+	static long long t_upd = 0, t_emit = 0;
+	const long long tu = now_ns();
+	t_upd += tu - t_start;
 	inc_emit(c, I, sel, out);
+	t_emit += now_ns() - tu;
+	{
+		static const bool trace = getenv("MDNS_CORE_INC_TRACE") != nullptr;
+		if (trace)
+			fprintf(stderr, "inc: M %zu comps %zu orphans %lld chain %lld scanned %lld splits %lld update %lld us emit %lld us\n", sel.size(), I.comps.size(),
+			        I.orphans, I.chain_steps, I.scanned_ids, I.splits, t_upd / 1000, t_emit / 1000);
+	}
 	if (c->check_groups) {
 		std::vector<Group> fresh;
 		if (!groups_graph(c, sel, fresh)) return false;
@@ -700,6 +711,28 @@ extern "C" int mdns_core_fill(mdns_core *c)
 				sel = &everybody;
 			}
 			std::vector<Group> &dst = focussed ? tmp : superset_groups;
+			{
+				// MDNS_CORE_DUMP=<iteration>:<file>: the id matrix and the selections of that iteration's passes
+				// (analysis of the grouping off line: tools/groups_replay.py)
+				static const char *dump = getenv("MDNS_CORE_DUMP");
+				if (dump && atoll(dump) == c->global_iter && strchr(dump, ':')) {
+					static FILE *f = nullptr;
+					if (!f) {
+						f = fopen(strchr(dump, ':') + 1, "wb");
+						if (f) {
+							const long long head[3] = {c->nrun, c->nlive, c->npile};
+							fwrite(head, sizeof head, 1, f);
+							fwrite(c->lp.data(), sizeof(int32_t), c->lp.size(), f);
+						}
+					}
+					if (f) {
+						const long long rec[2] = {(long long) sel->size(), focussed ? 1 : 0};
+						fwrite(rec, sizeof rec, 1, f);
+						fwrite(sel->data(), sizeof(int32_t), sel->size(), f);
+						fflush(f);
+					}
+				}
+			}
 			const long long t0 = now_ns();
 			c->stat[C_GROUPINGS]++;
 			const bool ok = !c->use_graph ? groups_walk(c, *sel, dst)
