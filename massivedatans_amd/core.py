@@ -159,7 +159,7 @@ class NativeCoreSampler(MultiNestedSampler):
             L.mdns_core_set_host_edges(self._core, int(edges))
         # MDNS_CORE_INCREMENTAL=0: every focussed pass computes its components afresh;
         # MDNS_CORE_CHECK_GROUPS=1: the incremental result of every pass against a fresh one
-        inc_edges = int(os.environ.get("MDNS_CORE_INCREMENTAL_EDGES", "4000000"))
+        inc_edges = int(os.environ.get("MDNS_CORE_INCREMENTAL_EDGES", "150000"))
         if os.environ.get("MDNS_CORE_INCREMENTAL", "1") == "0":
             inc_edges = 0
         L.mdns_core_set_incremental(self._core, inc_edges, 1 if os.environ.get("MDNS_CORE_CHECK_GROUPS") == "1" else 0)

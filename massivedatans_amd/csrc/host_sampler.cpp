@@ -135,7 +135,7 @@ struct mdns_core {
 	// the components of the focussed passes of the current iteration, kept up to date (host_sampler_inc.h)
 	void *inc = nullptr;
 	void (*inc_free)(void *) = nullptr;
-	long long inc_edges_max = 4000000;         // first focussed selections beyond this many pairs are not analysed here
+	long long inc_edges_max = 150000;          // first focussed selections beyond this many pairs are not analysed here (the device is quicker)
 	bool check_groups = false;                 // MDNS_CORE_CHECK_GROUPS=1: every incremental result against a fresh one
 	// draw outputs
 	std::vector<double> u_out, x_out;
