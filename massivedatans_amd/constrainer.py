@@ -393,8 +393,15 @@ class NativeConstrainer(object):
         original indices; None = all ``M``).  Returns ``(u, x, tries, fill bits uint64[ceil(M/64)])``;
         u, x and the bits are views of buffers that the next draw overwrites."""
         ctx = self.context
-        if ids.dtype.itemsize not in (4, 8) or not ids.flags.c_contiguous:
+        ids = numpy.asarray(ids)
+        if ids.dtype.kind not in 'iu' or ids.dtype.itemsize not in (4, 8) or not ids.flags.c_contiguous:
             ids = numpy.ascontiguousarray(ids, dtype=numpy.int64)
+        if pile_u.dtype != numpy.float64 or not pile_u.flags.c_contiguous:
+            raise ValueError("pile_u must be a C-contiguous float64 array")
+        if len(ids) and (int(ids.min()) < 0 or int(ids.max()) >= len(pile_u)):
+            raise IndexError("live-point ids outside the pile of %d points" % len(pile_u))
+        if rows is not None and (rows.dtype != numpy.int32 or not rows.flags.c_contiguous):
+            rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
         rc = self._lib.mdns_constrainer_draw(self._h, ctx._be, ctx._prior, ctx._ops, ctx.mt, pile_u.ctypes.data,
                                              ids.ctypes.data, ids.dtype.itemsize, len(ids),
                                              rows.ctypes.data if rows is not None else None, M,

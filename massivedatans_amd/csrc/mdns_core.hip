@@ -1,6 +1,7 @@
 // libmdns_hip.so -- context, memory, resident spectra and the host-pointer entry points.
 // Kernels live in mdns_like.hip and mdns_neighbors.hip.
 #include "mdns_internal.h"
+#include <time.h>
 
 #include <atomic>
 #include <cmath>
@@ -930,6 +931,16 @@ static bool pool_fit(void **p, size_t *cap, size_t need)
 
 static bool region_fetch(mdns_region *r);
 
+bool mdns::poll_expired(long long *started_ns)
+{
+	static const double limit_s = [] { const char *v = getenv("MDNS_POLL_TIMEOUT_S"); const double t = v ? atof(v) : 120.0; return t > 0 ? t : 120.0; }();
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	const long long now = (long long) ts.tv_sec * 1000000000LL + ts.tv_nsec;
+	if (*started_ns == 0) { *started_ns = now; return false; }
+	return (double) (now - *started_ns) * 1e-9 > limit_s;
+}
+
 static mdns_region *region_new(const double *d_members, double *owned, int K, int ndim)
 {
 	mdns_region *r = new mdns_region();
@@ -1068,10 +1079,14 @@ static bool region_fetch(mdns_region *r)
 	// The result usually is there already (the caller has launched other work meanwhile).
 	// While polling, look at the stream now and then: once it has drained, everything the
 	// kernel wrote is visible, and a failed launch shows up as an error instead of a hang.
+	long long started = 0;
 	for (unsigned spin = 0; *seq != r->seq; spin++) {
 		if ((spin & 1023) != 1023) continue;
 		const hipError_t e = hipStreamQuery(c->stream);
-		if (e == hipErrorNotReady) continue;
+		if (e == hipErrorNotReady) {
+			if (poll_expired(&started)) { set_error("radius computation: no result within MDNS_POLL_TIMEOUT_S"); return false; }
+			continue;
+		}
 		if (e != hipSuccess) { set_error("radius computation failed: %s", hipGetErrorString(e)); return false; }
 		if (*seq != r->seq) { set_error("radius computation finished without a result"); return false; }
 	}
@@ -1195,10 +1210,14 @@ extern "C" int mdns_region_count_polled(mdns_region *r, const double *points, in
 	if (!launch_count_within(r->d_members, r->K, r->ndim, r->thresh_sq, r->on_device ? r->d_res : nullptr,
 	                         (const double *) (g_stage_dev + off_points), M, (int *) (g_stage_dev + off_counts), &mail)) return 1;
 	volatile unsigned long long *at = (volatile unsigned long long *) g_stage;
+	long long started = 0;
 	for (unsigned spin = 0; *at != seq; spin++) {
 		if ((spin & 1023) != 1023) continue;
 		const hipError_t e = hipStreamQuery(c->stream);
-		if (e == hipErrorNotReady) continue;
+		if (e == hipErrorNotReady) {
+			if (poll_expired(&started)) { set_error("membership count: no result within MDNS_POLL_TIMEOUT_S"); return 1; }
+			continue;
+		}
 		if (e != hipSuccess) { set_error("membership count failed: %s", hipGetErrorString(e)); return 1; }
 		if (*at != seq) {
 			// (the stream drained and the number is not there: the launch failed; the ticket counter

@@ -504,10 +504,14 @@ extern "C" int mdns_groups_components(mdns_groups *g, const int32_t *rows, int M
 		// counts, flags and the list arrive in mapped host memory: poll for `seq` (looking at the
 		// stream now and then: a failed launch shows up as an error instead of a hang)
 		volatile unsigned long long *seq = &g->h_box->seq;
+		long long started = 0;
 		for (unsigned spin = 0; *seq != g->box_seq; spin++) {
 			if ((spin & 1023) != 1023) continue;
 			const hipError_t e = hipStreamQuery(c->stream);
-			if (e == hipErrorNotReady) continue;
+			if (e == hipErrorNotReady) {
+				if (poll_expired(&started)) { set_error("mdns_groups_components: no result within MDNS_POLL_TIMEOUT_S"); return 1; }
+				continue;
+			}
 			if (e != hipSuccess) { set_error("mdns_groups_components: %s", hipGetErrorString(e)); return 1; }
 			if (*seq != g->box_seq) { set_error("mdns_groups_components: finished without a result"); return 1; }
 		}

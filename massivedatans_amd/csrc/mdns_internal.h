@@ -12,6 +12,11 @@ void set_error(const char *fmt, ...);
 bool hip_ok(hipError_t e, const char *what, const char *file, int line);
 #define MDNS_HIP(call) ::mdns::hip_ok((call), #call, __FILE__, __LINE__)
 
+// Busy polls of mapped mailboxes give up after MDNS_POLL_TIMEOUT_S seconds (default 120): a wedged
+// kernel or a lost mailbox store becomes an error the caller can act on instead of a core spinning
+// forever.  *started_ns: 0 before the first call of a wait.
+bool poll_expired(long long *started_ns);
+
 // ---- per-process context (one process drives one GPU) -----------------------------------
 struct Context {
 	int device = -1;

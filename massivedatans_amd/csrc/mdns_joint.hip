@@ -875,10 +875,14 @@ static bool joint_wait_box(mdns_joint *j, const char *who)
 	volatile unsigned long long *seq = &j->h_box->seq;
 	// While polling, look at the stream now and then: a failed launch shows up as an error
 	// instead of a hang.
+	long long started = 0;
 	for (unsigned spin = 0; *seq != j->box_seq; spin++) {
 		if ((spin & 1023) != 1023) continue;
 		const hipError_t e = hipStreamQuery(c->stream);
-		if (e == hipErrorNotReady) continue;
+		if (e == hipErrorNotReady) {
+			if (poll_expired(&started)) { set_error("%s: no outcome within MDNS_POLL_TIMEOUT_S", who); return false; }
+			continue;
+		}
 		if (e != hipSuccess) { set_error("%s: the commit failed: %s", who, hipGetErrorString(e)); return false; }
 		if (*seq != j->box_seq) { set_error("%s: the commit finished without an outcome", who); return false; }
 	}
@@ -1319,10 +1323,14 @@ extern "C" int mdns_backend_chain_end(void *joint, void *region, int *counts, in
 	*accepted = -1; *nkept = -1; *B = 0;
 	if (state == 1) {
 		volatile unsigned long long *at = &j->h_chain->seq;
+		long long started = 0;
 		for (unsigned spin = 0; *at != j->chain_seq; spin++) {
 			if ((spin & 1023) != 1023) continue;
 			const hipError_t e = hipStreamQuery(c->stream);
-			if (e == hipErrorNotReady) continue;
+			if (e == hipErrorNotReady) {
+				if (poll_expired(&started)) { set_error("chain: no membership counts within MDNS_POLL_TIMEOUT_S"); return 1; }
+				continue;
+			}
 			if (e != hipSuccess) { set_error("chain: the membership count failed: %s", hipGetErrorString(e)); return 1; }
 			if (*at != j->chain_seq) {
 				(void) hipMemsetAsync(j->d_chain_ticket, 0, sizeof(int), c->stream);

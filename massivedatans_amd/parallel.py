@@ -322,7 +322,8 @@ class ShardedJointState(object):
 
     def live_matrix(self):
         parts = self._gather_vectors(np.ascontiguousarray(self.local.live_matrix()).ravel())
-        return np.concatenate([p.reshape(self.nlive, -1) for p in parts], axis=1)
+        # (a rank that owns no running data set contributes an empty block: its width is stated, not inferred)
+        return np.concatenate([p.reshape(self.nlive, len(p) // self.nlive) for p in parts], axis=1)
 
     def thresholds(self):
         higher, n = self.local.thresholds()

@@ -219,6 +219,10 @@ def run(x, y, nlive_points=400, nsuperset_draws=10, use_graph=False, max_samples
     sampler = build_sampler(problem, nlive_points, nsuperset_draws, use_graph, seed, batched, fused)
     results = multi_nested_integrator(tolerance=tolerance, multi_sampler=sampler,
                                       min_samples=min_samples, max_samples=max_samples)
+    if sampler.native is not None:
+        # the cached second deviate of numpy's Gaussian generator travels with the stream the native
+        # constrainers stepped: Python code that draws after the run sees the reference's numbers
+        sampler.native.sync_gauss_to_numpy()
     return results, sampler, problem, time.time() - start
 
 

@@ -100,3 +100,33 @@ def test_graph_grouping_is_the_same_partition(oracle, monkeypatch):
                 assert a == b
                 checked += len(a) > 1
     assert checked > 0, "no split state was reached: the test would be vacuous"
+
+
+@pytest.mark.parametrize("core", [False, True])
+def test_cached_gaussian_deviate_goes_back_to_numpy(core, oracle, monkeypatch):
+    """numpy's legacy Gaussian generator caches the second deviate of a pair; the native constrainers
+    continue the stream with their own copy of that cache (csrc/host_constrainer.cpp).  After a run
+    numpy's own state must hold it again, so that Python code drawing afterwards stays on the
+    reference's stream."""
+    import ctypes as C
+    from massivedatans_amd import constrainer
+    if not constrainer.available():
+        pytest.skip("libmdns_host.so not built")
+    patch_neighbors(monkeypatch, oracle)
+    monkeypatch.setenv("MDNS_NATIVE_CORE", "1" if core else "0")
+    data = gen.horns(3)
+    with np.errstate(all="ignore"):
+        results, sampler, problem, _ = sample.run(data["x"], data["y"], nlive_points=20, max_samples=60,
+                                                  backend=OracleSpectra(oracle, data["x"], data["y"]), fused=True)
+    assert sampler.native is not None and (type(sampler).__name__ == "NativeCoreSampler") == core
+    has, val = C.c_int(0), C.c_double(0)
+    constrainer.host_lib().mdns_host_rng_get_gauss(C.addressof(has), C.addressof(val))
+    st = np.random.get_state(legacy=False)
+    assert int(st["has_gauss"]) == has.value
+    if has.value:
+        assert float(st["gauss"]) == val.value
+    # and a draw from numpy now continues the pair: the cached deviate comes first
+    expected = val.value if has.value else None
+    got = np.random.normal()
+    if expected is not None:
+        assert got == expected

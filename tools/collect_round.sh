@@ -3,8 +3,10 @@
 #   tools/collect_round.sh r03
 # (bench lines, complete analyses in both grouping modes + cProfile, rocprofv3 kernel stats of the
 # bench and of a real run, PMC passes, K6 sweep and counters, chunk round trips)
-set -x
-tag=$1
+set -euxo pipefail
+repo=$(cd "$(dirname "$0")/.." && pwd)
+cd "$repo"
+tag=${1:?usage: tools/collect_round.sh <tag>}
 out=gpurun_out/$tag
 mkdir -p "$out"
 python bench.py > "$out/bench.json" 2> "$out/bench.err"
@@ -21,7 +23,7 @@ python tools/k6_sweep.py > "$out/k6_sweep.json" 2> "$out/k6_sweep.err"
 MDNS_K6_PATH=classic python tools/k6_sweep.py > "$out/k6_sweep_classic.json" 2> "$out/k6_sweep_classic.err"
 python tools/chunk_bench.py > "$out/chunk_bench.log" 2>&1
 python tools/chunk_bench.py classic > "$out/chunk_bench_classic.log" 2>&1
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
 USE_GRAPH=1 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/e2e600_graph" -- python3 tools/e2e_run.py horns 10000 100 600 > "$out/e2e600_graph.log" 2>&1
 USE_GRAPH=0 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/e2e600" -- python3 tools/e2e_run.py horns 10000 100 600 > "$out/e2e600.log" 2>&1
 # (only 64 MiB travel back: the per-dispatch traces stay here, the --stats summaries go)
