@@ -131,8 +131,9 @@ class HostJointState(object):
         """Accept flag of every candidate of the chunk against the selected data sets."""
         return self.score_params(self.to_kernel_params(xs) if len(xs) else numpy.zeros((0, self.nparams)), rows)
 
-    def score_params(self, params, rows):
-        """``score`` for candidates given as kernel parameter rows."""
+    def score_params(self, params, rows, jitter=None):
+        """``score`` for candidates given as kernel parameter rows; ``jitter`` [B, M] is added to the
+        likelihoods before anything is compared or kept (musefuse.py:535)."""
         xs = params
         rows = numpy.arange(self.ndata) if rows is None else numpy.asarray(rows, dtype=int)
         self._scored_rows = rows
@@ -142,6 +143,8 @@ class HostJointState(object):
         mask = numpy.zeros(self.ndata, dtype=bool)
         mask[rows] = True
         self._scored_L = self.scorer.loglike_batch(params, mask)
+        if jitter is not None:
+            self._scored_L = self._scored_L + numpy.asarray(jitter)[:len(self._scored_L)]
         self.nevals_scored += self._scored_L.size
         self.ncalls += 1
         return (self._scored_L > self.higher[rows]).any(axis=1).astype(numpy.int32)

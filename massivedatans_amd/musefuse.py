@@ -106,12 +106,20 @@ class MuseProblem(object):
         return native_prior(self.jitter)
 
     def joint_state(self, nlive_points):
-        from . import jointstate
+        from . import jointstate, parallel
         from .like import MuseSpectra
-        if isinstance(self.backend, MuseSpectra):
-            js = jointstate.MuseJointState(self.backend, nlive_points)
+
+        def build(scorer, ndata):
+            if isinstance(scorer, MuseSpectra):
+                return jointstate.MuseJointState(scorer, nlive_points)
+            return jointstate.HostJointState(_LinesScorer(scorer), nlive_points, ndata, kernel_params, nparams=nparams)
+
+        if isinstance(self.backend, parallel.ShardedMuse):
+            # one process per GPU: every rank keeps the state of ITS block of data sets
+            b = self.backend
+            js = parallel.ShardedJointState(build(b.local, b.hi - b.lo), self.ndata, b.lo, b.hi)
         else:
-            js = jointstate.HostJointState(_LinesScorer(self.backend), nlive_points, self.ndata, kernel_params, nparams=nparams)
+            js = build(self.backend, self.ndata)
         js.jitter_sigma = JITTER_SIGMA if self.jitter else 0.0
         return js
 
@@ -139,6 +147,17 @@ def run(x, y, v, nlive_points=400, nsuperset_draws=10, use_graph=True, max_sampl
     return results, sampler, problem, time.time() - start
 
 
+def distributed_backend(x, y, v):
+    """One process per GPU (torchrun): this rank's block of spectra and variances on its GPU behind
+    :class:`parallel.ShardedMuse`; None in a single process (see sample.distributed_backend)."""
+    from . import sample
+    from .parallel import ShardedMuse
+    if sample.distributed_setup() is None:
+        return None
+    from .like import MuseSpectra
+    return ShardedMuse(x, y, v, lambda xs, ys, vs: MuseSpectra(xs, ys, vs))
+
+
 def main(argv=None):
     argv = sys.argv if argv is None else argv
     if len(argv) < 3:
@@ -147,9 +166,11 @@ def main(argv=None):
     data = gen.load(argv[1], ndata)
     nlive_points = int(os.environ.get('NLIVE_POINTS', '400'))
     results, sampler, problem, duration = run(
-        data['x'], data['y'], data['v'], nlive_points=nlive_points,
+        data['x'], data['y'], data['v'], nlive_points=nlive_points, backend=distributed_backend(data['x'], data['y'], data['v']),
         nsuperset_draws=int(os.environ.get('SUPERSET_DRAWS', '10')), use_graph=os.environ.get('USE_GRAPH', '1') == '1',
         max_samples=int(os.environ.get('MAXSAMPLES', 100000)), min_samples=int(os.environ.get('MINSAMPLES', 0)))
+    if int(os.environ.get('RANK', '0')) != 0:
+        return                                     # every rank holds the same results; rank 0 writes
     from .sample import save_results
     prefix = '%s_full_.out_%d' % (argv[1], ndata)
     save_results(prefix, results, sampler, duration, ndata)

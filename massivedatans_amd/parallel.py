@@ -144,6 +144,35 @@ class ShardedGaussLine(object):
         return allgather_columns(block, counts)
 
 
+class ShardedMuse(object):
+    """The MUSE-style scorer (``loglike_batch(ypred[B, nx], mask)``, ``loglike_batch_lines(params[B, 5],
+    mask)``: like.MuseSpectra) over all data sets, this rank scoring only its block of spectra and
+    variances.  ``backend_factory(x, y_block, v_block)`` builds the per-rank scorer."""
+
+    def __init__(self, x, y, v, backend_factory):
+        torch, dist = _dist()
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.ndata = y.shape[1]
+        self.lo, self.hi = shard_range(self.ndata, self.rank, self.world)
+        self.local = backend_factory(x, np.ascontiguousarray(y[:, self.lo:self.hi]), np.ascontiguousarray(v[:, self.lo:self.hi]))
+
+    def _sharded(self, call, rows_in, data_mask):
+        if data_mask is None:
+            data_mask = np.ones(self.ndata, dtype=bool)
+        data_mask = np.asarray(data_mask, dtype=bool)
+        mine = data_mask[self.lo:self.hi]
+        block = call(rows_in, mine) if mine.any() else np.zeros((len(rows_in), 0))
+        b = shard_bounds(self.ndata, self.world)
+        counts = [int(data_mask[b[r]:b[r + 1]].sum()) for r in range(self.world)]
+        return allgather_columns(block, counts)
+
+    def loglike_batch(self, ypred, data_mask=None):
+        return self._sharded(self.local.loglike_batch, np.atleast_2d(ypred), data_mask)
+
+    def loglike_batch_lines(self, params, data_mask=None):
+        return self._sharded(self.local.loglike_batch_lines, np.atleast_2d(params), data_mask)
+
+
 class _DeviceMemory(object):
     """Device memory owned by libmdns_hip, described through the CUDA array interface so that
     torch can wrap it without a copy (torch.as_tensor)."""
@@ -203,8 +232,14 @@ class ShardedJointState(object):
         a = int(np.searchsorted(rows, self.lo))
         return rows[a:a + counts[self.rank]] - self.lo, counts
 
-    def init(self, xs):
-        self.local.init(xs)
+    def init(self, xs, jitter=None):
+        """``jitter`` [nlive, ndata] (the MUSE-style likelihood's noise of the initial points,
+        musefuse.py:535): every rank drew the whole matrix from the common stream and keeps the
+        columns of its block."""
+        if jitter is not None:
+            self.local.init(xs, jitter=np.ascontiguousarray(np.asarray(jitter)[:, self.lo:self.hi]))
+        else:
+            self.local.init(xs)
         self.ncalls += 1
 
     def set_running(self, running):
@@ -285,13 +320,18 @@ class ShardedJointState(object):
         """``draw`` for candidates given as kernel parameter rows: what a native constrainer hands over
         (``constrainer.python_backend``); every rank runs the same constrainer on the same random
         stream and meets the others here."""
-        if jitter is not None:
-            raise ValueError("likelihood jitter is not part of the sharded Gaussian-line state")
         torch, dist = _dist()
         mine, counts = self._mine(rows)
         xs = params
         B = len(xs)
-        self._local_flags = self.local.score_params(params, mine)
+        if jitter is not None:
+            # every rank's constrainer drew the noise of ALL selected data sets from the common stream
+            # (candidate by candidate, musefuse.py:535): this rank adds the columns of its own
+            at = int(counts[:self.rank].sum())
+            mine_jitter = np.ascontiguousarray(np.asarray(jitter)[:, at:at + int(counts[self.rank])])
+            self._local_flags = self.local.score_params(params, mine, jitter=mine_jitter)
+        else:
+            self._local_flags = self.local.score_params(params, mine)
         if self._local_flags is None and not self._device_flags:
             self._local_flags = self.local.flags()
         self.ncalls += 1

@@ -244,11 +244,9 @@ def save_results(prefix, results, sampler, duration, ndata):
                        nevals=int(sampler.nevals)), f, indent=4)
 
 
-def distributed_backend(x, y):
-    """One process per GPU (torchrun): every rank runs the same host orchestration from the
-    same seed, scores only its contiguous block of spectra on its own GPU and all-gathers the
-    likelihood columns over RCCL, so all ranks take identical decisions (the 2-rank CPU test
-    reproduces the reference trace bit for bit this way).  Returns None in a single process."""
+def distributed_setup():
+    """The process group of a torchrun launch (one process per GPU) with the library's kernels and the
+    RCCL collectives on ONE stream; returns the backend name, or None in a single process."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world <= 1 and os.environ.get('MDNS_FORCE_DIST') != '1':
         return None
@@ -268,8 +266,6 @@ def distributed_backend(x, y):
             dist.init_process_group(backend=backend)
     os.environ.setdefault('MDNS_DEVICE', str(device))
     from . import _lib
-    from .like import GaussLineSpectra
-    from .parallel import ShardedGaussLine
     if backend == 'nccl':
         # kernels and RCCL collectives on ONE stream (torch's current one; its default is the null
         # stream, which the library reads as "my own"): the accept flags are reduced on the device
@@ -277,6 +273,18 @@ def distributed_backend(x, y):
         stream = torch.cuda.Stream()
         torch.cuda.set_stream(stream)
         _lib.check(_lib.require_device().mdns_set_stream(ctypes.c_void_p(stream.cuda_stream)), 'mdns_set_stream')
+    return backend
+
+
+def distributed_backend(x, y):
+    """One process per GPU (torchrun): every rank runs the same host orchestration from the
+    same seed, scores only its contiguous block of spectra on its own GPU and all-gathers the
+    likelihood columns over RCCL, so all ranks take identical decisions (the 2-rank CPU test
+    reproduces the reference trace bit for bit this way).  Returns None in a single process."""
+    if distributed_setup() is None:
+        return None
+    from .like import GaussLineSpectra
+    from .parallel import ShardedGaussLine
     return ShardedGaussLine(x, y, lambda xs, ys: GaussLineSpectra(xs, ys, noise_level=noise_level))
 
 

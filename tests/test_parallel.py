@@ -99,6 +99,69 @@ def test_two_rank_gloo():
     assert res == [(0, True, 0, 19), (1, True, 19, 37)]
 
 
+def _muse_worker(rank, world, port, q, cases=("muse6", "muse10_graph")):
+    """configs[4]'s problem with the data sets sharded: the MUSE-style likelihood + its jitter as
+    constrained draws over a ShardedJointState, every rank's native constrainer drawing the same
+    noise stream and adding the columns of its own block."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from massivedatans_amd import gen, musefuse, parallel, sample
+    from massivedatans_amd.multi_nested_integrator import multi_nested_integrator
+    from oracle.oracle import Oracle
+    import oracle_backend
+    from oracle_backend import OracleMuseSpectra
+    from tracing import Recorder, check_bookkeeping, check_floats, load_trace
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        orc = Oracle("port")
+
+        class _MP(object):
+            def setattr(self, obj, name, val):
+                setattr(obj, name, val)
+
+        oracle_backend.patch_neighbors(_MP(), orc)
+        ok = True
+        for case in cases:
+            g = load_trace(case)
+            data = gen.muse_like(int(g["ndata"]), int(g["nx"]))
+            backend = parallel.ShardedMuse(data["x"], data["y"], data["v"], lambda x, y, v: OracleMuseSpectra(orc, x, y, v))
+            problem = musefuse.MuseProblem(data["x"], data["y"], data["v"], backend=backend, jitter=True)
+            sampler = sample.build_sampler(problem, nlive_points=int(g["nlive"]), nsuperset_draws=int(g["nsuperset_draws"]),
+                                           use_graph=bool(g["use_graph"]), seed=1, batched=False, fused=True, native=True)
+            ok &= type(sampler.joint).__name__ == "ShardedJointState" and sampler.native is not None
+            rec = Recorder(sampler)
+            with np.errstate(all="ignore"):
+                res = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0, max_samples=int(g["max_samples"]))
+            sampler.native.sync_gauss_to_numpy()
+            ok &= np.random.uniform() == float(g["rng_probe"])
+            check_bookkeeping(g, sampler, rec, res)
+            check_floats(g, rec, res, rtol=0)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_muse_gloo(world):
+    """BASELINE configs[4] sharded: reference traces muse6 / muse10_graph bit for bit
+    -- integers, floats, position of the random stream -- with 2 and 3 ranks (ragged blocks)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000) + world
+    # (the longer trace, 100 s through gloo, with MDNS_LONG_TESTS=1: ragged blocks of 4 + 3 + 3 data sets)
+    cases = ("muse6", "muse10_graph") if os.environ.get("MDNS_LONG_TESTS") == "1" else ("muse6",)
+    procs = [ctx.Process(target=_muse_worker, args=(r, world, port, q, cases)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    res = sorted(q.get(timeout=5) for _ in range(world))
+    assert [p.exitcode for p in procs] == [0] * world
+    assert res == [(r, True) for r in range(world)]
+
+
 def test_shard_bounds():
     from massivedatans_amd import parallel
     assert parallel.shard_bounds(10, 3).tolist() == [0, 4, 7, 10]
