@@ -551,6 +551,18 @@ int mdns_backend_draw_chunk(void *joint, const double *params, int B, const doub
 int mdns_backend_chunk_size(void *joint, int offered, int M, int hint);
 void *mdns_backend_region_begin(void *joint, const double *members, int K, int ndim, const unsigned *packed, int nbootstraps);
 int mdns_backend_region_radius(void *joint, void *region, double *radius);
+/* mdns_backend_draw_chunk in two halves, for hosts that put something between them -- with the data sets
+ * sharded over ranks a MAX all-reduce of the candidates' votes: `score` (after draw_begin)
+ * stages and scores the chunk like draw_chunk and leaves one int32 0 / 1 vote per candidate in device
+ * memory (mdns_joint_votes_dev: int32[MDNS_JOINT_MAX_BATCH], asynchronous on the library stream);
+ * `commit` takes the first candidate that has a vote THEN as the accepted one and finishes like
+ * draw_chunk (shelves, thresholds, *accepted, fill bits of this handle's selected data sets).  Both
+ * kinds of joint state (Gaussian line; scale-marginalised likelihood with jitter f64[B, M]). */
+int mdns_backend_draw_score(void *joint, const double *params, int B, const double *jitter);
+int *mdns_joint_votes_dev(mdns_joint *j);
+int mdns_backend_draw_commit(void *joint, int *accepted, unsigned long long *fillbits);
+/* the HIP stream the library launches on (its own, or the one given to mdns_set_stream) */
+void *mdns_get_stream(void);
 int mdns_backend_chain_begin(void *joint, void *region, const mdns_chain_request *rq);
 int mdns_backend_chain_end(void *joint, void *region, int *counts, int *nkept, int *B, int *accepted,
                            unsigned long long *fillbits, double *params);

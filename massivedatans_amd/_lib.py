@@ -41,6 +41,7 @@ ABI_SYMBOLS = (
     "mdns_backend_region_create", "mdns_backend_region_destroy", "mdns_backend_region_count",
     "mdns_backend_draw_begin", "mdns_backend_draw_chunk", "mdns_backend_chunk_size",
     "mdns_backend_region_begin", "mdns_backend_region_radius", "mdns_backend_chain_begin", "mdns_backend_chain_end",
+    "mdns_backend_draw_score", "mdns_joint_votes_dev", "mdns_backend_draw_commit", "mdns_get_stream",
 )
 
 #: the symbols of include/mdns.h Part 5 that live in libmdns_host.so (plain host code, no GPU)
@@ -169,6 +170,10 @@ def _declare(lib):
         "mdns_backend_chunk_size": (i, [vp, i, i, i]),
         "mdns_backend_region_begin": (vp, [vp, vp, i, i, vp, i]),
         "mdns_backend_region_radius": (i, [vp, vp, vp]),
+        "mdns_backend_draw_score": (i, [vp, vp, i, vp]),
+        "mdns_joint_votes_dev": (vp, [vp]),
+        "mdns_backend_draw_commit": (i, [vp, vp, vp]),
+        "mdns_get_stream": (vp, []),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

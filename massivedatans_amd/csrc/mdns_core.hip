@@ -290,6 +290,11 @@ extern "C" int mdns_set_stream(void *hip_stream)
 	c->stream = hip_stream ? (hipStream_t) hip_stream : c->own_stream;
 	return 0;
 }
+extern "C" void *mdns_get_stream(void)
+{
+	Context *c = ctx();
+	return c ? (void *) c->stream : nullptr;
+}
 extern "C" void *mdns_event_create(void)
 {
 	if (!ctx()) return nullptr;

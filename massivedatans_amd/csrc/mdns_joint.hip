@@ -402,6 +402,10 @@ struct mdns_joint {
 	ChainBox *h_chain = nullptr, *h_chain_dev = nullptr;   // mapped
 	double *d_chain_props = nullptr;
 	int *d_chain_counts = nullptr, *d_chain_ticket = nullptr;
+	// a chunk in two halves (mdns_backend_draw_score / _commit): one 0 / 1 vote per candidate, what the ranks
+	// of a sharded run MAX-reduce in between
+	int *d_votes = nullptr;
+	int half_path = 0, half_B = 0, half_flag = 0;       // 0: none; 1: dense block (kind 1); 2: two launches; 3: lane kernels
 	unsigned long long chain_seq = 0;
 	int chain_state = 0;               // 0 none, 1 counts only (poll h_chain->seq), 2 full (poll the commit's mailbox)
 	int chain_n = 0;
@@ -431,6 +435,7 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	if (j->d_chain_props) (void) hipFree(j->d_chain_props);
 	if (j->d_chain_counts) (void) hipFree(j->d_chain_counts);
 	if (j->d_chain_ticket) (void) hipFree(j->d_chain_ticket);
+	if (j->d_votes) (void) hipFree(j->d_votes);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
 	for (void *b : trail) if (b) (void) hipFree(b);
 	if (j->h_box) (void) hipHostFree(j->h_box);
@@ -1067,7 +1072,7 @@ extern "C" int mdns_backend_draw_begin(void *joint, const int *rows, int M)
 			}
 			dst[k] = prev = r;
 		}
-	} else if (M != j->ndata) {
+	} else if (M != j->ndata && M != 0) {
 		set_error("mdns_backend_draw_begin: M=%d without rows (ndata=%d)", M, j->ndata);
 		return 1;
 	}
@@ -1352,6 +1357,144 @@ extern "C" int mdns_backend_chain_end(void *joint, void *region, int *counts, in
 		return 1;
 	}
 	if (params && *B > 0) memcpy(params, (const void *) j->h_chain->params, (size_t) *B * 3 * sizeof(double));
+	if (*accepted >= 0) j->shelf_bound++;
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// mdns_backend_draw_chunk in two halves, for hosts that put something between them: with the data sets
+// sharded over ranks, the MAX all-reduce of the candidates' votes (mdns_joint_votes_dev)
+// ---------------------------------------------------------------------------------------
+__global__ void k_flags_to_votes(const int *__restrict__ flags, int value, int *__restrict__ votes, int B)
+{
+	const int b = blockIdx.x * blockDim.x + threadIdx.x;
+	if (b < B) votes[b] = flags[b] == value ? 1 : 0;
+}
+
+extern "C" int *mdns_joint_votes_dev(mdns_joint *j) { return j ? j->d_votes : nullptr; }
+
+extern "C" int mdns_backend_draw_score(void *joint, const double *params, int B, const double *jitter)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !j || (!params && B > 0)) return 1;
+	if (!j->sel_open) { set_error("mdns_backend_draw_score: no draw begun"); return 1; }
+	const int M = j->sel_M;
+	if (!check_draw(j, B, M, "mdns_backend_draw_score")) return 1;
+	if (!j->d_votes && !MDNS_HIP(hipMalloc((void **) &j->d_votes, (size_t) MDNS_JOINT_MAX_BATCH * sizeof(int)))) return 1;
+	j->half_path = 0; j->half_B = B;
+	if (!MDNS_HIP(hipMemsetAsync(j->d_votes, 0, (size_t) MDNS_JOINT_MAX_BATCH * sizeof(int), c->stream))) return 1;
+	if (B == 0 || M == 0) { j->half_path = -1; return 0; }          // (nothing of this rank's is selected: no vote)
+	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
+	if (j->chunk_seq == 0x7fffffff) {
+		if (!MDNS_HIP(hipMemsetAsync(j->d_flags, 0, (size_t) kFlagInts * sizeof(int), c->stream))) return 1;
+		j->chunk_seq = 1;
+	}
+	char *base = j->d_result;
+	if (j->kind == 1) {
+		const size_t pbytes = (size_t) B * 5 * sizeof(double), n = (size_t) B * M;
+		char *pin = joint_pin(j, pbytes);
+		if (!pin) return 1;
+		memcpy(pin, params, pbytes);
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+		if (j->sel_rows && !j->sel_on_device) {
+			if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, j->h_in + kInParams, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
+			j->sel_on_device = true;
+		}
+		const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+		if (!joint_grow(&j->d_dense, &j->dense_cap, n)) return 1;
+		if (jitter) {
+			if (!joint_grow(&j->d_jitter, &j->jitter_cap, n)) return 1;
+			if (!MDNS_HIP(hipMemcpyAsync(j->d_jitter, jitter, n * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
+		}
+		if (mdns_muse3_loglike_batch_dev(j->s, j->d_params, B, d_rows, M, j->d_dense) != 0) return 1;
+		const int flag = ++j->chunk_seq;
+		hipLaunchKernelGGL(k_joint_accept_dense, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream,
+		                   j->d_dense, jitter ? (const double *) j->d_jitter : nullptr, B, M, d_rows, (const double *) j->st.higher,
+		                   j->d_flags, flag, (JointHeader *) base);
+		j->half_path = 1; j->half_flag = flag;
+	} else {
+		if (jitter) { set_error("mdns_backend_draw_score: likelihood jitter is not part of the Gaussian-line problem"); return 1; }
+		const size_t pbytes = (size_t) B * 24;
+		if (chunk_fits(j->s, M, B)) {
+			memcpy(j->h_in, params, pbytes);
+			JointTrail trail;
+			if (!joint_trail(j, B, M, &trail)) return 1;
+			const int *rows_in = nullptr;
+			int *rows_out = nullptr;
+			if (j->sel_rows) {
+				if (j->sel_on_device) rows_in = j->d_sel_rows;
+				else { rows_in = (const int *) (j->h_in_dev + kInParams); rows_out = j->d_sel_rows; }
+			}
+			const double scale = -0.5 / (j->noise_level * j->noise_level);
+			const int flag = ++j->chunk_seq;
+			if (!launch_chunk_accept(j->s, (const double *) j->h_in_dev, B, scale, rows_in, rows_out, M, j->st.higher,
+			                         j->d_flags, flag, trail, base)) return 1;
+			if (j->sel_rows) j->sel_on_device = true;
+			j->half_path = 2; j->half_flag = flag;
+		} else {
+			char *pin = joint_pin(j, pbytes);
+			if (!pin) return 1;
+			memcpy(pin, params, pbytes);
+			if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+			if (j->sel_rows && !j->sel_on_device) {
+				if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, j->h_in + kInParams, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
+				j->sel_on_device = true;
+			}
+			if (mdns_joint_score_dev(j, j->d_params, B, j->noise_level, j->sel_rows ? j->d_sel_rows : nullptr, M) != 0) return 1;
+			j->half_path = 3; j->half_flag = 1;
+		}
+	}
+	hipLaunchKernelGGL(k_flags_to_votes, dim3((B + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, (const int *) j->d_flags, j->half_flag, j->d_votes, B);
+	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
+}
+
+// second half: the first candidate with a vote (after whatever the caller did to the votes) is the
+// accepted one; *accepted and the fill bits of THIS handle's selected data sets as mdns_backend_draw_chunk
+extern "C" int mdns_backend_draw_commit(void *joint, int *accepted, unsigned long long *fillbits)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !j || !accepted) return 1;
+	*accepted = -1;
+	const int path = j->half_path, B = j->half_B, M = j->sel_M;
+	j->half_path = 0;
+	if (path == 0) { set_error("mdns_backend_draw_commit: no mdns_backend_draw_score precedes"); return 1; }
+	if (path < 0) {
+		// nothing of this handle's was scored: the accepted candidate is whoever the votes name
+		std::vector<int> votes((size_t) (B > 0 ? B : 1), 0);
+		if (B > 0 && (!MDNS_HIP(hipMemcpyAsync(votes.data(), j->d_votes, (size_t) B * sizeof(int), hipMemcpyDeviceToHost, c->stream)) || !joint_sync(c))) return 1;
+		for (int b = 0; b < B; b++) if (votes[b]) { *accepted = b; break; }
+		return 0;
+	}
+	char *base = j->d_result;
+	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
+	const int ntiles = (M + 63) / 64;
+	const int *thr_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+	if (path == 1) {
+		hipLaunchKernelGGL(k_joint_commit_dense, dim3((ntiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
+		                   (const double *) j->d_dense, thr_rows, M, B, ntiles, (const int *) j->d_votes, 1, j->st, (JointHeader *) base, bits);
+		hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, ntiles, j->h_box_dev, ++j->box_seq);
+		if (!MDNS_HIP(hipGetLastError())) return 1;
+		j->box_pending = true;
+	} else if (path == 2) {
+		const JointTrail trail = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L, j->trail_stamp};
+		if (M <= 128) {
+			if (!launch_chunk_commit(thr_rows, M, B, j->d_votes, 1, trail, j->st, base, bits, j->h_box_dev, ++j->box_seq)) return 1;
+		} else {
+			if (!launch_joint_commit_trail(thr_rows, M, B, j->d_votes, trail, j->st, base, bits, 1)) return 1;
+			hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, ntiles, j->h_box_dev, ++j->box_seq);
+			if (!MDNS_HIP(hipGetLastError())) return 1;
+		}
+		j->box_pending = true;
+	} else {
+		// the lane kernels' flags are 0 / 1 themselves: the votes go back into them
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_flags, j->d_votes, (size_t) B * sizeof(int), hipMemcpyDeviceToDevice, c->stream))) return 1;
+		if (joint_commit_dev(j, thr_rows, M, false, "mdns_backend_draw_commit") != 0) return 1;
+	}
+	j->trail_valid = false;
+	j->last_B = 0;
+	if (mdns_joint_fetch(j, M, accepted, fillbits) != 0) return 1;
 	if (*accepted >= 0) j->shelf_bound++;
 	return 0;
 }

@@ -179,6 +179,8 @@ class GaussJointState(object):
     EVAL_BUDGET = 2560000
     MIN_CHUNK = 32
 
+    nparams = 3
+
     def __init__(self, spectra, nlive, to_kernel_params, shelf_cap=64, fetch_rows=True, via_backend=False):
         #: copy the accepted candidate's likelihood row to the host with every draw (the sampler
         #: itself needs only the index and the fill bits: sample.py turns this off)
@@ -327,6 +329,61 @@ class GaussJointState(object):
         else:
             self.shelf_n[rows[beats]] += 1
         return idx, (self._Lrow[:M].copy() if self.fetch_rows else None), beats, B
+
+    # the two halves of a chunk through the entry points a native constrainer uses (include/mdns.h:
+    # mdns_backend_draw_score / mdns_backend_draw_commit): what parallel.ShardedJointState puts the MAX
+    # all-reduce of the candidates' votes between.  Both kinds of state (Gaussian line, MUSE-style).
+    def score_backend(self, params, rows, jitter=None):
+        """Scores the chunk against the selected data sets ``rows`` (ORIGINAL indices of this state's
+        spectra, ascending; None: all); one 0 / 1 vote per candidate stays on the device
+        (:meth:`votes_address`)."""
+        B = len(params)
+        if B > _lib.JOINT_MAX_BATCH:
+            raise ValueError("at most %d candidates per chunk" % _lib.JOINT_MAX_BATCH)
+        M = self.ndata if rows is None else len(rows)
+        params = _lib.as_f64(params) if B else numpy.zeros((0, self.nparams))
+        if rows is not None:
+            rows = numpy.ascontiguousarray(rows, dtype=numpy.int32)
+        if jitter is not None:
+            jitter = _lib.as_f64(jitter)
+            if jitter.shape != (B, M):
+                raise ValueError("jitter must be [B, M]")
+        self._check(self._lib.mdns_backend_draw_begin(self._h, _lib.ptr(rows) if rows is not None and M else None, M),
+                    "mdns_backend_draw_begin")
+        self._check(self._lib.mdns_backend_draw_score(self._h, _lib.ptr(params) if B else None, B,
+                                                      _lib.ptr(jitter) if jitter is not None and B * M else None),
+                    "mdns_backend_draw_score")
+        self._half = (rows, M, B)
+        self.nevals_scored += B * M
+        self.ncalls += 1
+
+    def votes_address(self):
+        return self._lib.mdns_joint_votes_dev(self._h)
+
+    def votes(self):
+        rows, M, B = self._half
+        out = numpy.zeros(B, dtype=numpy.int32)
+        if B:
+            self._check(self._lib.mdns_d2h(_lib.ptr(out), self.votes_address(), out.nbytes), "mdns_d2h")
+        return out
+
+    def set_votes(self, votes):
+        votes = numpy.ascontiguousarray(votes, dtype=numpy.int32)
+        if len(votes):
+            self._check(self._lib.mdns_h2d(self.votes_address(), _lib.ptr(votes), votes.nbytes), "mdns_h2d")
+
+    def commit_backend(self):
+        """The first candidate that has a vote now is the accepted point: (its index or -1, which of the
+        selected data sets of THIS state it beats)."""
+        rows, M, B = self._half
+        self._check(self._lib.mdns_backend_draw_commit(self._h, C.addressof(self._accepted), _lib.ptr(self._bits)),
+                    "mdns_backend_draw_commit")
+        idx = self._accepted.value
+        if idx < 0 or M == 0:
+            return idx, numpy.zeros(M, dtype=bool)
+        beats = numpy.unpackbits(self._bits[:(M + 63) // 64].view(numpy.uint8), bitorder='little')[:M].astype(bool)
+        self.took(rows, beats)
+        return idx, beats
 
     # the two halves of draw() (include/mdns.h: mdns_joint_score / mdns_joint_commit)
     def _reserve_for(self, rows):

@@ -324,6 +324,8 @@ class ShardedJointState(object):
         mine, counts = self._mine(rows)
         xs = params
         B = len(xs)
+        if hasattr(self.local, "score_backend"):
+            return self._draw_halves(params, mine, counts, jitter)
         if jitter is not None:
             # every rank's constrainer drew the noise of ALL selected data sets from the common stream
             # (candidate by candidate, musefuse.py:535): this rank adds the columns of its own
@@ -356,6 +358,64 @@ class ShardedJointState(object):
         L = np.concatenate([g[r, 0, :counts[r]] for r in range(self.world)]) if Lrow is not None else None
         b = np.concatenate([g[r, 1, :counts[r]] for r in range(self.world)]) != 0
         return idx, L, b, B
+
+    # ---- the chunk in two halves on the device (local states on the GPU) -------------------------
+    def _direct(self):
+        """RCCL called directly on the library's stream (massivedatans_amd.rccl), or None: backend not
+        nccl, library not bindable, or MDNS_SHARDED_COLLECTIVES=torch."""
+        if not hasattr(self, "_rccl"):
+            import os
+            self._rccl = None
+            torch, dist = _dist()
+            if dist.get_backend() == "nccl" and os.environ.get("MDNS_SHARDED_COLLECTIVES", "rccl") != "torch":
+                try:
+                    from . import _lib, rccl
+                    comm = rccl.from_torch_distributed()
+                    stream = _lib.require_device().mdns_get_stream()
+                    self._rccl = (rccl, comm, stream)
+                    self._allbits = None
+                except Exception:       # noqa: BLE001 -- the torch path is always there
+                    self._rccl = None
+        return self._rccl
+
+    def _draw_halves(self, params, mine, counts, jitter):
+        """One chunk: this rank scores its selected data sets (votes on the device), the ranks MAX-reduce
+        the votes -- in place, on the stream the kernels run on -- every rank commits the first candidate
+        that has a vote, and the fill bits of all ranks are gathered for the bookkeeping every rank keeps."""
+        torch, dist = _dist()
+        from . import _lib
+        B = len(params)
+        mine_jitter = None
+        if jitter is not None:
+            at = int(counts[:self.rank].sum())
+            mine_jitter = np.ascontiguousarray(np.asarray(jitter)[:, at:at + int(counts[self.rank])])
+        self.local.score_backend(params, mine, mine_jitter)
+        self.ncalls += 1
+        self.nevals_scored += B * int(counts.sum())
+        direct = self._direct()
+        if direct is not None:
+            rccl, comm, stream = direct
+            comm.all_reduce(self.local.votes_address(), self.local.votes_address(), B, rccl.INT32, rccl.MAX, stream)
+        elif dist.get_backend() == "nccl":
+            votes_t = device_view(self.local.votes_address(), (_lib.JOINT_MAX_BATCH,), "<i4")
+            dist.all_reduce(votes_t[:B], op=dist.ReduceOp.MAX)
+        else:
+            votes = torch.from_numpy(self.local.votes())
+            dist.all_reduce(votes, op=dist.ReduceOp.MAX)
+            self.local.set_votes(votes.numpy())
+        idx, beats = self.local.commit_backend()
+        # (every rank found the same first voted candidate; -1: nobody accepted anything)
+        if idx < 0:
+            return -1, None, None, B
+        width = int(counts.max())
+        block = np.zeros(width)
+        block[:len(beats)] = beats
+        mine_t = torch.from_numpy(block).to(_device())
+        gathered = torch.empty(self.world * width, dtype=mine_t.dtype, device=_device())
+        dist.all_gather_into_tensor(gathered, mine_t)
+        g = gathered.cpu().numpy().reshape(self.world, width)
+        b = np.concatenate([g[r, :counts[r]] for r in range(self.world)]) != 0
+        return idx, None, b, B
 
     def advance(self):
         self.local.advance()
