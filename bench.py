@@ -681,6 +681,52 @@ def bench_muse(args):
     def step():
         _lib.check(lib.mdns_muse_loglike_batch_dev(spectra, d_t, B, None, nd, d_L), "K2")
 
+    dist_step = None
+    if use_dist:
+        # N ranks: one STEP = one chunk of a constrained draw over the sharded joint state (what
+        # parallel.ShardedJointState does per chunk, BASELINE configs[4]): every rank scores the B
+        # candidates against ITS spectra (templates on the device + K2 into the dense block + accept
+        # test), the ranks MAX-reduce the B votes in place on the kernels' stream, every rank commits the
+        # first candidate that has a vote, and the fill bits of all ranks are gathered -- between an
+        # undo / prepare and an advance, so that every step is the same iteration.
+        NLIVE_M = 100
+        joint = lib.mdns_joint_create(spectra, NLIVE_M, 8)
+        if not joint:
+            raise _lib.MdnsError(_lib.last_error())
+        live5 = np.column_stack([rng.uniform(-1.0, 1.0, NLIVE_M), rng.uniform(0.0, 0.02, NLIVE_M), rng.uniform(-0.5, 0.5, NLIVE_M),
+                                 rng.uniform(0.2, 2.0, NLIVE_M), rng.uniform(0.2, 2.0, NLIVE_M)])
+        _lib.check(lib.mdns_joint_init_muse3(joint, _lib.ptr(live5), None), "init")
+        Lmin, arg, keep = np.empty(nd), np.empty(nd, dtype=np.int32), np.zeros((nd, lib.mdns_joint_keep_words(joint)), dtype=np.uint64)
+        _lib.check(lib.mdns_joint_prepare(joint, _lib.ptr(Lmin), _lib.ptr(arg), _lib.ptr(keep)), "prepare")
+        votes = lib.mdns_joint_votes_dev
+        nbits = (nd + 63) // 64
+        bits = np.zeros(nbits + 1, dtype=np.uint64)
+        t_allbits = torch.zeros(world * nbits, dtype=torch.int64, device="cuda")
+        accepted = C.c_int(-1)
+        direct, rccl, stream = COMM["direct"], COMM["rccl"], COMM["stream"]
+        from massivedatans_amd.parallel import device_view
+        state = {"advanced": False}
+
+        def dist_step():
+            if state["advanced"]:
+                _lib.check(lib.mdns_joint_undo_advance_dev(joint), "undo advance")
+            _lib.check(lib.mdns_joint_prepare_dev(joint), "prepare")
+            _lib.check(lib.mdns_backend_draw_begin(joint, None, nd), "draw_begin")
+            _lib.check(lib.mdns_backend_draw_score(joint, _lib.ptr(p5), B, None), "templates + K2 + accept")
+            d_votes = votes(joint)
+            if direct is not None:
+                direct.all_reduce(d_votes, d_votes, B, rccl.INT32, rccl.MAX, stream)
+            else:
+                dist.all_reduce(device_view(d_votes, (B,), "<i4"), op=dist.ReduceOp.MAX)
+            _lib.check(lib.mdns_backend_draw_commit(joint, C.addressof(accepted), _lib.ptr(bits)), "commit")
+            t_bits = torch.from_numpy(bits[:nbits].view(np.int64)).cuda()
+            if direct is not None:
+                direct.all_gather(t_bits.data_ptr(), t_allbits.data_ptr(), nbits, rccl.INT64, stream)
+            else:
+                dist.all_gather_into_tensor(t_allbits, t_bits)
+            _lib.check(lib.mdns_joint_advance_dev(joint), "advance")
+            state["advanced"] = True
+
     def fence():
         _lib.check(lib.mdns_sync(), "sync")
         if use_dist:
@@ -688,6 +734,8 @@ def bench_muse(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    if dist_step is not None:
+        step = dist_step
     lib.mdns_profile_every(1)
     lib.mdns_profile(2)
     elapsed = timed(step, fence, args, use_dist, torch, dist, lib, _lib)
@@ -695,7 +743,8 @@ def bench_muse(args):
     lib.mdns_profile(0)
     kernel = (lib.mdns_profile_kernel(1) or b"").decode()
     L = np.empty(B * nd)
-    _lib.check(lib.mdns_d2h(_lib.ptr(L), d_L, B * nd * 8), "d2h")
+    if dist_step is None:
+        _lib.check(lib.mdns_d2h(_lib.ptr(L), d_L, B * nd * 8), "d2h")
     L = L.reshape(B, nd)
 
     if rank == 0:
@@ -716,6 +765,11 @@ def bench_muse(args):
                                    "share of BASELINE.json configs[4]: 50 000 over 8), %d template%s per pass; y and 1/v = "
                                    "%.0f MB streamed from HBM" % (nd, nx, B, "" if B == 1 else "s", 16 * nx * nd / 1e6),
                        "spectra_per_gpu": nd, "channels": nx, "candidates_per_step": B,
+                       "step": ("one chunk of a constrained draw over the sharded joint state: templates + K2 + accept test per "
+                                "rank, MAX all-reduce of the votes, commit, all-gather of the fill bits" if dist_step is not None
+                                else "the K2 kernel alone"),
+                       "collectives": ("none" if dist_step is None else "RCCL called directly on the kernels' stream"
+                                       if COMM["direct"] is not None else "torch.distributed (nccl)"),
                        "parallelism": "datasets sharded x%d" % world},
             "roofline": ({"bound": "hbm", "kernel": kernel, "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": gbs / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

@@ -450,3 +450,21 @@ def test_bench_step_with_collectives_on_one_gpu():
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0
     assert line["config"]["collectives"], line["config"]
+
+
+@pytest.mark.gpu
+def test_bench_muse_step_with_collectives_on_one_gpu():
+    """`bench.py --workload muse --gpus N`'s step as far as one GPU allows: a chunk of a
+    constrained draw over the sharded MUSE-style joint state -- templates + K2 + accept test, MAX
+    all-reduce of the votes on the kernels' stream, commit, all-gather of the fill bits -- with one rank."""
+    import json
+    import subprocess
+    env = dict(os.environ, MDNS_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29900 + os.getpid() % 200),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "muse", "--batch", "8", "--muse-ndata", "1000",
+                          "--steps", "5", "--warmup", "2", "--no-e2e", "--no-cpu-baseline"], capture_output=True, text=True,
+                         timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["value"] > 0
+    assert "constrained draw" in line["config"]["step"] and line["config"]["collectives"] != "none", line["config"]
