@@ -445,6 +445,18 @@ typedef struct mdns_draw_backend {
 	 * draw_chunk.  chain_end waits for all of it: counts int32[n]; *nkept (-1: the chunk did not ride
 	 * along), *B (its size), *accepted, fillbits, params f64[B][nparams] the device scored with (may be
 	 * NULL).  The caller then asks region_radius as usual. */
+	/* Optional (NULL: not offered): the likelihood noise in BAND form (musefuse.py:535 without one
+	 * deviate per evaluation).  draw_band scores the chunk like draw_chunk, WITHOUT noise, and compares
+	 * every likelihood with its threshold +- 1.01 bound[b] (bound f64[B]: no deviate of candidate b exceeds
+	 * it): status int32[B] = 1 when some selected data set is beaten whatever the noise, 0 when none can
+	 * be, 2 when that hangs on the pairs listed: pair_b / pair_k int32 (candidate, position in the
+	 * selection), pair_L / pair_thr f64 (likelihood without noise, threshold); *npairs their number (more
+	 * than cap: the caller falls back to draw_chunk with the whole block).  Nothing is committed.
+	 * draw_band_commit: candidate b is the accepted one; jitter_row f64[M] is added to its likelihoods,
+	 * then shelves, thresholds and fill bits as in draw_chunk. */
+	int (*draw_band)(void *user, const double *params, int B, const double *bound, int *status, int *npairs,
+	                 int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap);
+	int (*draw_band_commit)(void *user, int b, const double *jitter_row, unsigned long long *fillbits);
 	int (*chain_begin)(void *user, void *region, const struct mdns_chain_request *rq);
 	int (*chain_end)(void *user, void *region, int *counts, int *nkept, int *B, int *accepted,
 	                 unsigned long long *fillbits, double *params);
@@ -523,11 +535,12 @@ int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, cons
  * transform, [15] draw_chunk, [16] mdns_constrainer_draw as a whole, [17] the likelihood jitter;
  * [18] first batches chained on the device together with their chunk (chain_begin / chain_end), [19] with
  * their membership counts only, [20] accepted candidates of chained chunks whose device parameters were
- * not bit for bit the host's (10**v), [21] nanoseconds between chain_begin and chain_end.
+ * not bit for bit the host's (10**v), [21] nanoseconds between chain_begin and chain_end; [22] pairs the
+ * device could not decide without their noise (draw_band), [23] candidates whose noise was replayed for them.
  * mdns_constrainer_share_stats:
  * every increment is also added to totals int64[MDNS_CONSTRAINER_COUNTERS] (the caller's: the sum
  * over a sampler's constrainers). */
-#define MDNS_CONSTRAINER_COUNTERS 22
+#define MDNS_CONSTRAINER_COUNTERS 24
 void mdns_constrainer_stats(const mdns_constrainer *c, long long *out);
 void mdns_constrainer_share_stats(mdns_constrainer *c, long long *totals);
 const char *mdns_host_last_error(void);
@@ -563,6 +576,9 @@ int *mdns_joint_votes_dev(mdns_joint *j);
 int mdns_backend_draw_commit(void *joint, int *accepted, unsigned long long *fillbits);
 /* the HIP stream the library launches on (its own, or the one given to mdns_set_stream) */
 void *mdns_get_stream(void);
+int mdns_backend_draw_band(void *joint, const double *params, int B, const double *bound, int *status, int *npairs,
+                           int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap);
+int mdns_backend_draw_band_commit(void *joint, int b, const double *jitter_row, unsigned long long *fillbits);
 int mdns_backend_chain_begin(void *joint, void *region, const mdns_chain_request *rq);
 int mdns_backend_chain_end(void *joint, void *region, int *counts, int *nkept, int *B, int *accepted,
                            unsigned long long *fillbits, double *params);

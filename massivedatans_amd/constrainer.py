@@ -35,6 +35,9 @@ _DRAW_CHUNK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C
 _CHUNK_SIZE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int)
 _REGION_BEGIN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int, C.POINTER(C.c_uint), C.c_int)
 _REGION_RADIUS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_double))
+_DRAW_BAND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                         C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
+_DRAW_BAND_COMMIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong))
 _CHAIN_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 _CHAIN_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                          C.POINTER(C.c_ulonglong), C.POINTER(C.c_double))
@@ -50,6 +53,8 @@ class DrawBackend(C.Structure):            # mdns_draw_backend
                 ("chunk_size", _CHUNK_SIZE),
                 # optional halves of region_create (NULL: not offered): K6 launched / its radius awaited
                 ("region_begin", _REGION_BEGIN), ("region_radius", _REGION_RADIUS),
+                # optional: the likelihood noise in band form (mdns.h Part 5)
+                ("draw_band", _DRAW_BAND), ("draw_band_commit", _DRAW_BAND_COMMIT),
                 # optional: the first batch of a region without a host look in between (mdns.h Part 5)
                 ("chain_begin", _CHAIN_BEGIN), ("chain_end", _CHAIN_END)]
 
@@ -68,7 +73,7 @@ METRICS = {'none': 0, 'simplescaling': 1, 'truncatedscaling': 2}
 #: mdns_constrainer_stats (include/mdns.h)
 COUNTERS = ("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals", "inside", "tries",
             "ns_bootstrap", "ns_region", "ns_count", "ns_propose", "ns_transform", "ns_chunk", "ns_draw", "ns_jitter",
-            "chains", "chain_counts", "param_mismatch", "ns_chain")
+            "chains", "chain_counts", "param_mismatch", "ns_chain", "band_pairs", "band_replays")
 
 _HOST = None
 
@@ -179,6 +184,9 @@ def hip_backend(joint):
                                ("region_begin", _REGION_BEGIN, "mdns_backend_region_begin"),
                                ("region_radius", _REGION_RADIUS, "mdns_backend_region_radius")):
         setattr(be, field, C.cast(getattr(lib, name), proto))
+    if os.environ.get("MDNS_JITTER_BAND", "1") != "0" and not joint_kind_gauss(joint):
+        be.draw_band = C.cast(lib.mdns_backend_draw_band, _DRAW_BAND)
+        be.draw_band_commit = C.cast(lib.mdns_backend_draw_band_commit, _DRAW_BAND_COMMIT)
     if os.environ.get("MDNS_CHAIN", "1") != "0" and joint_kind_gauss(joint):
         be.chain_begin = C.cast(lib.mdns_backend_chain_begin, _CHAIN_BEGIN)
         be.chain_end = C.cast(lib.mdns_backend_chain_end, _CHAIN_END)
@@ -282,6 +290,62 @@ def python_backend(joint, member_set_factory=None):
     def joint_nparams(j):
         return getattr(j, "nparams", 3)
 
+    # the likelihood noise in band form over a joint state that keeps the scored block (HostJointState):
+    # the numpy statement of mdns_backend_draw_band / _commit
+    def draw_band(_user, params_ptr, B, bound_ptr, status_ptr, npairs_ptr, pb_ptr, pk_ptr, pL_ptr, pthr_ptr, cap):
+        try:
+            params = numpy.ctypeslib.as_array(params_ptr, (B, joint_nparams(joint))).copy()
+            bound = numpy.ctypeslib.as_array(bound_ptr, (B,)).copy()
+            # (a CPU scorer pays per candidate: scored in growing pieces up to the first candidate that is
+            # accepted whatever its noise -- nobody looks at the ones behind it)
+            rows_L, pos, piece = [], 0, 1
+            while pos < B:
+                joint.score_params(params[pos:pos + piece], state["rows"])
+                rows_L.append(joint._scored_L)
+                thr = joint.higher[joint._scored_rows]
+                pos += len(rows_L[-1])
+                if (rows_L[-1] > thr[None, :] + (1.01 * bound[pos - len(rows_L[-1]):pos, None]
+                                                 + 1e-12 * (numpy.abs(rows_L[-1]) + numpy.abs(thr)[None, :]))).any():
+                    break
+                piece = min(64, 2 * piece)
+            L = numpy.vstack(rows_L)
+            if len(L) < B:
+                L = numpy.vstack((L, numpy.full((B - len(L), L.shape[1]), -numpy.inf)))
+            joint._scored_L = L
+            band = 1.01 * bound[:, None] + 1e-12 * (numpy.abs(L) + numpy.abs(thr)[None, :])
+            band[~numpy.isfinite(L)] = 0.0
+            clear = L > thr[None, :] + band
+            maybe = ~clear & (L >= thr[None, :] - band)
+            status = numpy.where(clear.any(axis=1), 1, numpy.where(maybe.any(axis=1), 2, 0))
+            numpy.ctypeslib.as_array(status_ptr, (B,))[:] = status
+            b_idx, k_idx = numpy.nonzero(maybe)
+            npairs_ptr[0] = len(b_idx)
+            n = min(len(b_idx), cap)
+            numpy.ctypeslib.as_array(pb_ptr, (cap,))[:n] = b_idx[:n]
+            numpy.ctypeslib.as_array(pk_ptr, (cap,))[:n] = k_idx[:n]
+            numpy.ctypeslib.as_array(pL_ptr, (cap,))[:n] = L[b_idx[:n], k_idx[:n]]
+            numpy.ctypeslib.as_array(pthr_ptr, (cap,))[:n] = thr[k_idx[:n]]
+            return 0
+        except Exception:       # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
+    def draw_band_commit(_user, b, row_ptr, bits_ptr):
+        try:
+            M = state["M"]
+            joint._scored_L[b] = joint._scored_L[b] + numpy.ctypeslib.as_array(row_ptr, (M,))
+            _, beats = joint.commit(b)
+            words = numpy.zeros((M + 63) // 64, dtype=numpy.uint64)
+            packed = numpy.packbits(numpy.asarray(beats, dtype=numpy.uint8), bitorder='little')
+            words.view(numpy.uint8)[:len(packed)] = packed
+            numpy.ctypeslib.as_array(bits_ptr, (len(words),))[:] = words
+            return 0
+        except Exception:       # noqa: BLE001
+            import traceback
+            traceback.print_exc()
+            return 1
+
     def chunk_size(_user, offered, M, hint):
         return int(joint.chunk_size(offered, M, hint))
 
@@ -296,7 +360,10 @@ def python_backend(joint, member_set_factory=None):
     be.draw_begin = _DRAW_BEGIN(draw_begin)
     be.draw_chunk = _DRAW_CHUNK(draw_chunk)
     be.chunk_size = _CHUNK_SIZE(chunk_size)
-    be._keep = (region_create, region_destroy, region_count, draw_begin, draw_chunk, chunk_size, regions, joint)
+    if hasattr(joint, "_threshold") and hasattr(joint, "score_params") and os.environ.get("MDNS_JITTER_BAND", "1") != "0":
+        be.draw_band = _DRAW_BAND(draw_band)
+        be.draw_band_commit = _DRAW_BAND_COMMIT(draw_band_commit)
+    be._keep = (region_create, region_destroy, region_count, draw_begin, draw_chunk, chunk_size, regions, joint, draw_band, draw_band_commit)
     return be
 
 

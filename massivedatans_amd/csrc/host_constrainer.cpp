@@ -225,7 +225,9 @@ enum { N_DRAWS, N_CHUNKS, N_CANDIDATES, N_PAIRS, N_REGIONS, N_RADII, N_COUNTS, N
        T_BOOTSTRAP, T_REGION, T_COUNT, T_PROPOSE, T_TRANSFORM, T_CHUNK, T_DRAW, T_JITTER,
        // first batches chained on the device: with their chunk / counts only; accepted candidates whose device
        // parameters were not bit for bit the host's (10**v: mdns_pow10.h); nanoseconds from chain_begin to chain_end
-       N_CHAINS, N_CHAIN_COUNTS, N_PARAM_MISMATCH, T_CHAIN, N_COUNTERS };
+       N_CHAINS, N_CHAIN_COUNTS, N_PARAM_MISMATCH, T_CHAIN,
+       // jitter in band form: pairs the device could not decide without their noise, candidates whose noise was replayed for them
+       N_BAND_PAIRS, N_BAND_REPLAYS, N_COUNTERS };
 
 inline long long now_ns()
 {
@@ -344,6 +346,7 @@ typedef std::shared_ptr<Region> RegionRef;
 // ---------------------------------------------------------------------------------------
 // the constrainer (hiermetriclearn.py)
 // ---------------------------------------------------------------------------------------
+namespace { struct BandSnap; }
 struct mdns_constrainer {
 	int ndim = 0;
 	int metriclearner = MDNS_METRIC_TRUNCATEDSCALING;
@@ -389,6 +392,10 @@ struct mdns_constrainer {
 	std::vector<unsigned long long> chain_bits;
 	std::vector<double> chain_params;
 	int chain_nkept = -1;
+	// the band form of the likelihood jitter (band_chunk)
+	std::vector<struct BandSnap> band_snap;
+	std::vector<double> band_bound, band_row, band_pL, band_pthr;
+	std::vector<int> band_status, band_pb, band_pk;
 	// likelihood jitter of a chunk and the stream's state after each candidate's share of it
 	struct Snapshot { MT mt; int has_gauss; double gauss; };
 	std::vector<double> jitter;
@@ -880,6 +887,138 @@ void transform(const mdns_prior *p, const double *us, int B, double *xs, double 
 		}
 }
 
+// ---------------------------------------------------------------------------------------
+// the likelihood noise of musefuse.py:535 WITHOUT drawing every deviate
+// ---------------------------------------------------------------------------------------
+// `Lout[mask] + numpy.random.normal(0, 1e-5, size=mask.sum())` consumes one Gaussian deviate per
+// (candidate, data set) evaluation -- billions per run -- and only pairs whose likelihood lies within a
+// few 1e-5 of the threshold can be decided by it.  numpy's legacy generator makes a PAIR of deviates
+// f x1, f x2 from two uniforms with r2 = x1^2 + x2^2 < 1, f = sqrt(-2 ln(r2) / r2): their magnitude is
+// at most sqrt(-2 ln r2).  So the stream is only ADVANCED -- the uniforms and the rejection test, no
+// logarithm, no root -- and each candidate gets a rigorous bound on its deviates from its smallest r2.
+// The device decides every pair outside  threshold +- bound  without the noise and lists the rest
+// (draw_band); exact deviates are made, by replaying the candidate's part of the stream with
+// legacy_gauss itself, only for candidates with listed pairs and for the accepted candidate's row,
+// which is what the state keeps (draw_band_commit).  Decisions, kept values and the position of the
+// stream are those of the deviate-per-evaluation path (tests/test_muse.py on the reference's traces).
+struct DoubleSource {
+	MT *mt;
+	MT start;                    // the state the buffered block was made from
+	double buf[256];
+	int pos = 0;
+	bool filled = false;
+	explicit DoubleSource(MT *m) : mt(m), start(*m) {}
+	inline double next()
+	{
+		if (!filled || pos == 256) { start = *mt; mt_fill_doubles(mt, buf, 256); pos = 0; filled = true; }
+		return buf[pos++];
+	}
+};
+
+struct BandSnap { MT start; int pos; int has_gauss; double gauss; };
+
+inline BandSnap band_snap(const DoubleSource &src, int has_gauss, double gauss)
+{
+	BandSnap s;
+	s.start = src.start;
+	s.pos = src.filled ? src.pos : 0;
+	s.has_gauss = has_gauss;
+	s.gauss = gauss;
+	return s;
+}
+
+void band_restore(MT *mt, const BandSnap &s)
+{
+	*mt = s.start;
+	if (s.pos > 0) { double skip[256]; mt_fill_doubles(mt, skip, (size_t) s.pos); }
+	g_has_gauss = s.has_gauss;
+	g_gauss = s.gauss;
+}
+
+// 0: done (*accepted, fillbits, stream positioned); 1: failed; 2: not possible for this chunk (stream
+// back where it was: the caller draws the whole block)
+int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsigned long long *fillbits)
+{
+	mdns_constrainer *c = e.c;
+	const mdns_draw_backend *be = e.be;
+	const double sigma = e.prior->jitter_sigma;
+	MT *mt = e.mt;
+	const long long t0 = now_ns();
+	std::vector<BandSnap> &snap = c->band_snap;
+	snap.resize((size_t) B + 1);
+	c->band_bound.resize(B);
+	DoubleSource src(mt);
+	int has_gauss = g_has_gauss;
+	double gauss = g_gauss;
+	snap[0] = band_snap(src, has_gauss, gauss);
+	for (int b = 0; b < B; b++) {
+		double minr2 = 2.0, cached_abs = 0.0;
+		int need = M;
+		if (has_gauss && need > 0) { cached_abs = std::fabs(gauss); has_gauss = 0; gauss = 0.0; need--; }
+		while (need > 0) {
+			const double x1 = 2.0 * src.next() - 1.0;
+			const double x2 = 2.0 * src.next() - 1.0;
+			const double r2 = x1 * x1 + x2 * x2;
+			if (r2 >= 1.0 || r2 == 0.0) continue;
+			if (r2 < minr2) minr2 = r2;
+			need--;                                       // f x2
+			if (need > 0) need--;                         // f x1, from the cache
+			else {
+				// the pair's other deviate waits in the cache beyond this candidate: its value is needed
+				const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+				gauss = f * x1;
+				has_gauss = 1;
+			}
+		}
+		double most = cached_abs;
+		if (minr2 < 2.0) { const double g = std::sqrt(-2.0 * std::log(minr2)); if (g > most) most = g; }
+		c->band_bound[b] = sigma * most;
+		snap[(size_t) b + 1] = band_snap(src, has_gauss, gauss);
+	}
+	c->stat.add(T_JITTER, now_ns() - t0);
+	const int cap = 4096;
+	c->band_status.resize(B);
+	c->band_pb.resize(cap); c->band_pk.resize(cap); c->band_pL.resize(cap); c->band_pthr.resize(cap);
+	int npairs = 0;
+	if (be->draw_band(be->user, params, B, c->band_bound.data(), c->band_status.data(), &npairs, c->band_pb.data(), c->band_pk.data(),
+	                  c->band_pL.data(), c->band_pthr.data(), cap) != 0) { set_error("draw_band failed"); return 1; }
+	if (npairs > cap) { band_restore(mt, snap[0]); return 2; }
+	const long long t1 = now_ns();
+	// the exact noise of candidate b: its part of the stream again, through legacy_gauss itself
+	auto replay = [&](int b) {
+		band_restore(mt, snap[b]);
+		c->band_row.resize(M);
+		for (int k = 0; k < M; k++) {
+			const double g = sigma * legacy_gauss(mt);
+			c->band_row[k] = 0.0 + g;
+		}
+	};
+	int bstar = -1;
+	for (int b = 0; b < B && bstar < 0; b++) {
+		const int st = c->band_status[b];
+		if (st == 0) continue;
+		if (st == 1) { bstar = b; break; }
+		replay(b);
+		for (int t = 0; t < npairs; t++) {
+			if (c->band_pb[t] != b) continue;
+			const int k = c->band_pk[t];
+			if (k < 0 || k >= M) { set_error("draw_band: pair of data set %d of %d", k, M); return 1; }
+			const double v = c->band_pL[t] + c->band_row[k];
+			if (v > c->band_pthr[t]) { bstar = b; break; }
+		}
+		c->stat.add(N_BAND_REPLAYS, 1);
+	}
+	c->stat.add(N_BAND_PAIRS, npairs);
+	if (bstar >= 0) {
+		replay(bstar);
+		if (be->draw_band_commit(be->user, bstar, c->band_row.data(), fillbits) != 0) { set_error("draw_band_commit failed"); return 1; }
+		band_restore(mt, snap[(size_t) bstar + 1]);
+	} else band_restore(mt, snap[B]);
+	c->stat.add(T_JITTER, now_ns() - t1);
+	*accepted = bstar;
+	return 0;
+}
+
 }  // namespace
 
 extern "C" const char *mdns_host_last_error(void) { return g_error; }
@@ -1021,7 +1160,13 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 		// the tie-breaking noise of musefuse.py:535, candidate by candidate, with the state of the
 		// stream remembered after each of them
 		const double *jitter = nullptr;
-		if (prior->jitter_sigma > 0) {
+		int band = 2;                                   // 2: the noise goes as a block (or there is none)
+		int band_accepted = -1;
+		if (prior->jitter_sigma > 0 && be->draw_band && be->draw_band_commit && !c->chain_valid) {
+			band = band_chunk(e, c->params.data(), B, M, &band_accepted, fillbits);
+			if (band == 1) return 1;
+		}
+		if (prior->jitter_sigma > 0 && band == 2) {
 			c->jitter.resize((size_t) B * M);
 			c->snap.resize(B);
 			for (int b = 0; b < B; b++) {
@@ -1051,7 +1196,8 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 				if (memcmp(&c->chain_params[(size_t) accepted * 3], &c->params[(size_t) accepted * prior->nparams], 3 * sizeof(double)) != 0)
 					c->stat.add(N_PARAM_MISMATCH, 1);
 			}
-		} else rc_chunk = be->draw_chunk(be->user, c->params.data(), B, jitter, &accepted, fillbits, &nscored);
+		} else if (band == 0) accepted = band_accepted;
+		else rc_chunk = be->draw_chunk(be->user, c->params.data(), B, jitter, &accepted, fillbits, &nscored);
 		if (jitter && rc_chunk == 0) {
 			// the reference evaluated exactly the candidates up to the accepted one (or all `nscored`)
 			const int last = accepted >= 0 ? accepted : nscored - 1;

@@ -320,6 +320,105 @@ __global__ __launch_bounds__(kBlock) void k_joint_commit_dense(
 	if (lane == 0) fillbits[tile] = word;
 }
 
+// ---- the likelihood noise in band form (mdns.h: draw_band / draw_band_commit) ----
+// every likelihood against its threshold +- (1.01 bound[b] + 1e-12 (|L| + |thr|)): a pair above the band
+// is beaten whatever the noise (clear[b] = 1), a pair inside it is listed for the host, which alone
+// makes the exact deviates
+static constexpr int kBandCap = 4096;
+struct BandBox {                   // mapped host memory
+	unsigned long long seq;
+	int npairs, pad;
+	int status[MDNS_JOINT_MAX_BATCH];
+	int pair_b[kBandCap], pair_k[kBandCap];
+	double pair_L[kBandCap], pair_thr[kBandCap];
+};
+struct BandScratch {               // device memory
+	int counter, pad;
+	int clear[MDNS_JOINT_MAX_BATCH], maybe[MDNS_JOINT_MAX_BATCH];
+	int pair_b[kBandCap], pair_k[kBandCap];
+	double pair_L[kBandCap], pair_thr[kBandCap];
+};
+
+__global__ __launch_bounds__(kBlock) void k_joint_band(const double *__restrict__ L, const double *__restrict__ bound, int B, int M,
+                                                       const int *__restrict__ thr_rows, const double *__restrict__ higher,
+                                                       BandScratch *__restrict__ sc, JointHeader *__restrict__ header)
+{
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) header->status = 0;
+	const int k = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+	if (k >= M) return;
+	const double v = L[(size_t) b * M + k];
+	const int d = thr_rows ? thr_rows[k] : k;
+	const double thr = higher[d];
+	const double band = 1.01 * bound[b] + 1e-12 * (fabs(v) + fabs(thr));
+	if (v > thr + band) sc->clear[b] = 1;
+	else if (v >= thr - band) {
+		sc->maybe[b] = 1;
+		const int at = atomicAdd(&sc->counter, 1);
+		if (at < kBandCap) { sc->pair_b[at] = b; sc->pair_k[at] = k; sc->pair_L[at] = v; sc->pair_thr[at] = thr; }
+	}
+}
+
+// one workgroup: what the host needs, into mapped memory (`seq` last), and the scratch ready for the next chunk
+__global__ __launch_bounds__(kBlock) void k_joint_band_publish(BandScratch *__restrict__ sc, int B, BandBox *__restrict__ box, unsigned long long seq)
+{
+	const int n = sc->counter;
+	const int m = n < kBandCap ? n : kBandCap;
+	for (int b = threadIdx.x; b < B; b += kBlock) {
+		box->status[b] = sc->clear[b] ? 1 : (sc->maybe[b] ? 2 : 0);
+		sc->clear[b] = 0; sc->maybe[b] = 0;
+	}
+	for (int t = threadIdx.x; t < m; t += kBlock) {
+		box->pair_b[t] = sc->pair_b[t]; box->pair_k[t] = sc->pair_k[t];
+		box->pair_L[t] = sc->pair_L[t]; box->pair_thr[t] = sc->pair_thr[t];
+	}
+	__threadfence_system();
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	sc->counter = 0;
+	box->npairs = n;
+	__hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// k_joint_commit_dense for a candidate the HOST names, with its noise row added first
+__global__ __launch_bounds__(kBlock) void k_joint_commit_band(
+    const double *__restrict__ L, const double *__restrict__ jrow, const int *__restrict__ thr_rows, int M, int bstar, int ntiles,
+    JointArrays st, JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits)
+{
+	if (blockIdx.x == 0 && threadIdx.x == 0) header->accepted = bstar;
+	const int lane = threadIdx.x & 63;
+	const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
+	if (tile >= ntiles) return;
+	const int k = tile * 64 + lane;
+	bool beats = false;
+	if (k < M) {
+		const int d = thr_rows ? thr_rows[k] : k;
+		const double v = L[(size_t) bstar * M + k] + jrow[k];
+		const double thr = st.higher[d];
+		beats = v > thr;
+		if (beats) {
+			const int n = st.shelfn[d];
+			if (n >= st.cap) atomicOr(&header->status, 1);
+			else {
+				int at_most = 0;
+				double next = INFINITY;
+				for (int p = 0; p < st.nlive; p++) {
+					const double w = st.live[(size_t) p * st.ndata + d];
+					if (w <= thr) at_most++; else next = fmin(next, w);
+				}
+				for (int e = 0; e < n; e++) {
+					const double w = st.shelfL[(size_t) e * st.ndata + d];
+					if (w <= thr) at_most++; else next = fmin(next, w);
+				}
+				st.shelfL[(size_t) n * st.ndata + d] = v;
+				st.shelfn[d] = n + 1;
+				st.higher[d] = at_most >= n + 2 ? thr : fmin(v, next);
+			}
+		}
+	}
+	const unsigned long long word = __ballot(beats);
+	if (lane == 0) fillbits[tile] = word;
+}
+
 __global__ void k_joint_add(double *__restrict__ p, const double *__restrict__ q, size_t n)
 {
 	for (size_t e = (size_t) blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (size_t) gridDim.x * blockDim.x) p[e] = p[e] + q[e];
@@ -402,6 +501,12 @@ struct mdns_joint {
 	ChainBox *h_chain = nullptr, *h_chain_dev = nullptr;   // mapped
 	double *d_chain_props = nullptr;
 	int *d_chain_counts = nullptr, *d_chain_ticket = nullptr;
+	// the likelihood noise in band form (mdns_backend_draw_band / _commit)
+	BandBox *h_band = nullptr, *h_band_dev = nullptr;
+	BandScratch *d_band = nullptr;
+	double *d_bound = nullptr;                // [MDNS_JOINT_MAX_BATCH] bounds, then room for one noise row [ndata]
+	unsigned long long band_seq = 0;
+	int band_B = 0;
 	// a chunk in two halves (mdns_backend_draw_score / _commit): one 0 / 1 vote per candidate, what the ranks
 	// of a sharded run MAX-reduce in between
 	int *d_votes = nullptr;
@@ -436,6 +541,9 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	if (j->d_chain_counts) (void) hipFree(j->d_chain_counts);
 	if (j->d_chain_ticket) (void) hipFree(j->d_chain_ticket);
 	if (j->d_votes) (void) hipFree(j->d_votes);
+	if (j->h_band) (void) hipHostFree(j->h_band);
+	if (j->d_band) (void) hipFree(j->d_band);
+	if (j->d_bound) (void) hipFree(j->d_bound);
 	void *trail[] = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L};
 	for (void *b : trail) if (b) (void) hipFree(b);
 	if (j->h_box) (void) hipHostFree(j->h_box);
@@ -1496,5 +1604,101 @@ extern "C" int mdns_backend_draw_commit(void *joint, int *accepted, unsigned lon
 	j->last_B = 0;
 	if (mdns_joint_fetch(j, M, accepted, fillbits) != 0) return 1;
 	if (*accepted >= 0) j->shelf_bound++;
+	return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// the likelihood noise in band form (mdns.h Part 5: draw_band / draw_band_commit)
+// ---------------------------------------------------------------------------------------
+extern "C" int mdns_backend_draw_band(void *joint, const double *params, int B, const double *bound, int *status, int *npairs,
+                                      int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !j || !params || !bound || !status || !npairs || !pair_b || !pair_k || !pair_L || !pair_thr) { set_error("mdns_backend_draw_band: null argument"); return 1; }
+	if (j->kind != 1) { set_error("mdns_backend_draw_band: a state of the scale-marginalised likelihood is needed"); return 1; }
+	if (!j->sel_open) { set_error("mdns_backend_draw_band: no draw begun"); return 1; }
+	const int M = j->sel_M;
+	if (!check_draw(j, B, M, "mdns_backend_draw_band") || B == 0 || M == 0) return 1;
+	if (!j->h_band) {
+		if (!MDNS_HIP(hipHostMalloc((void **) &j->h_band, sizeof(BandBox), hipHostMallocMapped)) ||
+		    !MDNS_HIP(hipHostGetDevicePointer((void **) &j->h_band_dev, j->h_band, 0)) ||
+		    !MDNS_HIP(hipMalloc((void **) &j->d_band, sizeof(BandScratch))) ||
+		    !MDNS_HIP(hipMemsetAsync(j->d_band, 0, sizeof(BandScratch), c->stream)) ||
+		    !MDNS_HIP(hipMalloc((void **) &j->d_bound, ((size_t) MDNS_JOINT_MAX_BATCH + j->ndata) * sizeof(double)))) return 1;
+		memset(j->h_band, 0, sizeof(BandBox));
+	}
+	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
+	// candidates and their bounds: one pinned block, two small copies
+	const size_t pbytes = (size_t) B * 5 * sizeof(double), bbytes = (size_t) B * sizeof(double), n = (size_t) B * M;
+	char *pin = joint_pin(j, pbytes + bbytes);
+	if (!pin) return 1;
+	memcpy(pin, params, pbytes);
+	memcpy(pin + pbytes, bound, bbytes);
+	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream)) ||
+	    !MDNS_HIP(hipMemcpyAsync(j->d_bound, pin + pbytes, bbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	if (j->sel_rows && !j->sel_on_device) {
+		if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, j->h_in + kInParams, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
+		j->sel_on_device = true;
+	}
+	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+	if (!joint_grow(&j->d_dense, &j->dense_cap, n)) return 1;
+	if (mdns_muse3_loglike_batch_dev(j->s, j->d_params, B, d_rows, M, j->d_dense) != 0) return 1;
+	hipLaunchKernelGGL(k_joint_band, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream, (const double *) j->d_dense,
+	                   (const double *) j->d_bound, B, M, d_rows, (const double *) j->st.higher, j->d_band, (JointHeader *) j->d_result);
+	hipLaunchKernelGGL(k_joint_band_publish, dim3(1), dim3(kBlock), 0, c->stream, j->d_band, B, j->h_band_dev, ++j->band_seq);
+	if (!MDNS_HIP(hipGetLastError())) return 1;
+	j->band_B = B;
+	j->trail_valid = false;
+	j->last_B = 0;
+	volatile unsigned long long *at = &j->h_band->seq;
+	long long started = 0;
+	for (unsigned spin = 0; *at != j->band_seq; spin++) {
+		if ((spin & 1023) != 1023) continue;
+		const hipError_t e = hipStreamQuery(c->stream);
+		if (e == hipErrorNotReady) {
+			if (poll_expired(&started)) { set_error("mdns_backend_draw_band: no outcome within MDNS_POLL_TIMEOUT_S"); return 1; }
+			continue;
+		}
+		if (e != hipSuccess) { set_error("mdns_backend_draw_band: %s", hipGetErrorString(e)); return 1; }
+		if (*at != j->band_seq) { set_error("mdns_backend_draw_band: finished without an outcome"); return 1; }
+	}
+	std::atomic_thread_fence(std::memory_order_acquire);
+	memcpy(status, (const void *) j->h_band->status, (size_t) B * sizeof(int));
+	*npairs = j->h_band->npairs;
+	const int m = *npairs < cap ? (*npairs < kBandCap ? *npairs : kBandCap) : cap;
+	if (*npairs > kBandCap && *npairs <= cap) *npairs = cap + 1;          // (more than the device lists: the caller falls back)
+	memcpy(pair_b, (const void *) j->h_band->pair_b, (size_t) m * sizeof(int));
+	memcpy(pair_k, (const void *) j->h_band->pair_k, (size_t) m * sizeof(int));
+	memcpy(pair_L, (const void *) j->h_band->pair_L, (size_t) m * sizeof(double));
+	memcpy(pair_thr, (const void *) j->h_band->pair_thr, (size_t) m * sizeof(double));
+	return 0;
+}
+
+extern "C" int mdns_backend_draw_band_commit(void *joint, int b, const double *jitter_row, unsigned long long *fillbits)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !j || !jitter_row) { set_error("mdns_backend_draw_band_commit: null argument"); return 1; }
+	if (j->kind != 1 || !j->sel_open || j->band_B <= 0 || b < 0 || b >= j->band_B) { set_error("mdns_backend_draw_band_commit: candidate %d of a chunk of %d", b, j->band_B); return 1; }
+	const int M = j->sel_M, ntiles = (M + 63) / 64;
+	j->band_B = 0;
+	double *d_row = j->d_bound + MDNS_JOINT_MAX_BATCH;
+	char *pin = joint_pin(j, (size_t) M * sizeof(double));
+	if (!pin) return 1;
+	memcpy(pin, jitter_row, (size_t) M * sizeof(double));
+	if (!MDNS_HIP(hipMemcpyAsync(d_row, pin, (size_t) M * sizeof(double), hipMemcpyHostToDevice, c->stream))) return 1;
+	char *base = j->d_result;
+	unsigned long long *bits = (unsigned long long *) (base + sizeof(JointHeader));
+	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+	hipLaunchKernelGGL(k_joint_commit_band, dim3((ntiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
+	                   (const double *) j->d_dense, (const double *) d_row, d_rows, M, b, ntiles, j->st, (JointHeader *) base, bits);
+	hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, ntiles, j->h_box_dev, ++j->box_seq);
+	if (!MDNS_HIP(hipGetLastError())) return 1;
+	j->box_pending = true;
+	int accepted = -1;
+	if (mdns_joint_fetch(j, M, &accepted, fillbits) != 0) return 1;
+	if (accepted != b) { set_error("mdns_backend_draw_band_commit: committed %d, asked for %d", accepted, b); return 1; }
+	j->shelf_bound++;
 	return 0;
 }

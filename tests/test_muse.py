@@ -29,7 +29,7 @@ def _run(g, backend, fused, native, jitter=True):
 
 
 @pytest.mark.parametrize("case", ["muse6", "muse10_graph"])
-@pytest.mark.parametrize("mode", ["single", "native"])
+@pytest.mark.parametrize("mode", ["single", "native", "native-block"])
 def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
     """``single``: one candidate per likelihood call, the noise from numpy.random.normal -- the
     reference's loop.  ``native``: whole chunks, the noise drawn in C from numpy's own Mersenne
@@ -37,6 +37,14 @@ def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
     where the accepted candidate's evaluation left it.  Both on the CPU oracle's cmuselike: integers,
     floats and the position of the random stream exactly the reference's."""
     g = load_trace(case)
+    if mode == "native-block":
+        # the noise drawn deviate by deviate and handed over as a [B, M] block (the round-3 form); "native"
+        # takes the band form: the stream only advanced, exact deviates for undecided pairs and the
+        # accepted candidate's row alone (csrc/host_constrainer.cpp, band_chunk)
+        if case != "muse6":
+            pytest.skip("the block form on the short trace only")
+        monkeypatch.setenv("MDNS_JITTER_BAND", "0")
+        mode = "native"
     if mode == "native":
         from massivedatans_amd import constrainer
         if not constrainer.available():
@@ -50,6 +58,10 @@ def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
     check_bookkeeping(g, sampler, rec, results)
     check_floats(g, rec, results, rtol=0)
     assert probe == float(g["rng_probe"])
+    if mode == "native":
+        import os
+        st = sampler.native.stats()
+        assert (st["band_pairs"] + st["band_replays"] > 0) == (os.environ.get("MDNS_JITTER_BAND", "1") != "0") or st["band_pairs"] == 0
 
 
 @pytest.mark.gpu
