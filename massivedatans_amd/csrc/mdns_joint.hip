@@ -1323,10 +1323,13 @@ extern "C" int mdns_backend_chunk_size(void *joint, int offered, int M, int hint
 	// chunk of 32 scored 30 of them for nothing -- with 8 a chunk over all 10 000 spectra is two
 	// launches and 22 us instead of five commands and 44.  Over a few hundred spectra at least 32:
 	// there a chunk costs its round trip whatever it holds, and 8 meant a fifth more chunks.)
-	const int MIN_CHUNK = muse ? 4 : (M > 4096 ? 8 : 32);
+	// (K2 with the noise in band form: a speculative candidate costs the host 2 ns per data set and the
+	// device a share of a launch that is latency-bound below ~64 candidates -- round 3, with a Gaussian
+	// deviate per pair on the host, kept these chunks at 4)
+	const int MIN_CHUNK = muse ? 32 : (M > 4096 ? 8 : 32);
 	long long budget = EVAL_BUDGET / (M > 0 ? M : 1);
 	if (budget < MIN_CHUNK) budget = MIN_CHUNK;
-	long long want = 4LL * (hint > 0 ? hint : 1);
+	long long want = (muse ? 8LL : 4LL) * (hint > 0 ? hint : 1);
 	if (want < MIN_CHUNK) want = MIN_CHUNK;
 	if (budget > want) budget = want;
 	if (budget > MDNS_JOINT_MAX_BATCH) budget = MDNS_JOINT_MAX_BATCH;
