@@ -179,6 +179,93 @@ def hbm_regime_leg(lib, _lib, ndata=1000000, nx=200, reps=20):
             "frac": gbs / HBM_PEAK_GBS, "evals_per_s": ndata / (us * 1e-6)}
 
 
+def muse_leg(lib, _lib, nd=6250, nx=4096):
+    """K2 (cmuselike.c:34-66) on one GPU's share of BASELINE configs[4], inside the default line: one
+    template per pass (the HBM regime: y and 1/v, 410 MB, streamed once per launch) and 64 templates per
+    pass (fp64 vector issue); HIP events around every launch, HBM traffic from the committed --pmc passes."""
+    from massivedatans_amd import gen
+    cube = gen.muse_like(nd, nx)
+    x = cube["x"]
+    sp = lib.mdns_spectra_create(_lib.ptr(x), _lib.ptr(np.ascontiguousarray(cube["y"])), _lib.ptr(np.ascontiguousarray(cube["v"])), nd, nx, 0)
+    if not sp:
+        return {"error": _lib.last_error()}
+    rng = np.random.RandomState(3)
+    out = {"workload": "%d spectra x %d channels with per-pixel variances (y and 1/v = %.0f MB > 256 MiB Infinity Cache)"
+                       % (nd, nx, 16 * nx * nd / 1e6)}
+    for B, reps in ((1, 30), (64, 8)):
+        p5 = np.column_stack([rng.uniform(-0.3, 0.3, B), rng.uniform(0.0, 0.02, B), rng.uniform(-0.2, 0.2, B),
+                              rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
+        templates = np.array([gen.muse_template(x, p) for p in p5])
+        d_t = lib.mdns_dev_alloc(templates.nbytes)
+        lib.mdns_h2d(d_t, _lib.ptr(templates), templates.nbytes)
+        d_L = lib.mdns_dev_alloc(B * nd * 8)
+        for _ in range(2):
+            lib.mdns_muse_loglike_batch_dev(sp, d_t, B, None, nd, d_L)
+        lib.mdns_sync()
+        lib.mdns_profile_every(1)
+        lib.mdns_profile(2)
+        for _ in range(reps):
+            lib.mdns_muse_loglike_batch_dev(sp, d_t, B, None, nd, d_L)
+        lib.mdns_sync()
+        n, us = read_profile(lib, 1)
+        lib.mdns_profile(0)
+        kernel = (lib.mdns_profile_kernel(1) or b"").decode()
+        lib.mdns_dev_free(d_t)
+        lib.mdns_dev_free(d_L)
+        phys = 16 * nx * nd + 8 * B * nd + 8 * B * nx
+        traffic, source = pmc_traffic(kernel)
+        if B == 1:
+            gbs = phys / (us * 1e-6) / 1e9
+            out["b1"] = {"bound": "hbm", "kernel": kernel, "launch_us": us, "launches_timed": n, "achieved": gbs, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "bytes_per_launch": phys, "traffic": traffic,
+                         "traffic_source": source, "evals_per_s": nd / (us * 1e-6)}
+        else:
+            tf = 10.0 * nx * B * nd / (us * 1e-6) / 1e12
+            out["b64"] = {"bound": "fp64_valu", "kernel": kernel, "launch_us": us, "launches_timed": n, "achieved": tf,
+                          "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
+                          "flops_per_launch": 10.0 * nx * B * nd, "traffic": traffic, "traffic_source": source,
+                          "evals_per_s": B * nd / (us * 1e-6)}
+    lib.mdns_spectra_destroy(sp)
+    return out
+
+
+def cpu_baseline_e2e(data, iterations):
+    """The same analysis -- our host orchestration, native constrainer, USE_GRAPH=1 -- on the CPU oracle's
+    kernels (the reference's own C where oracle/_ref is built), capped after `iterations` iterations
+    (about 15 s of one host core): the like-for-like CPU number for the constrained-draw metric.  Runs in
+    the cpu_baseline leg only, after the timed region; the geometry entry points of the package are
+    pointed at the oracle for its duration and put back."""
+    from massivedatans_amd import sample
+    from massivedatans_amd.clustering import neighbors
+    from oracle.oracle import Oracle, have_reference
+    from oracle.backends import OracleSpectra, patch_neighbors
+    kind = "reference" if have_reference() else "port"
+    orc = Oracle(kind)
+    saved = {}
+
+    class _Patch(object):
+        def setattr(self, obj, name, value):
+            saved.setdefault((obj, name), getattr(obj, name))
+            setattr(obj, name, value)
+
+    patch_neighbors(_Patch(), orc)
+    try:
+        with np.errstate(all="ignore"):
+            results, sampler, problem, duration = sample.run(data["x"], data["y"], nlive_points=NLIVE, max_samples=iterations,
+                                                             use_graph=True, backend=OracleSpectra(orc, data["x"], data["y"]),
+                                                             fused=True)
+    finally:
+        for (obj, name), value in saved.items():
+            setattr(obj, name, value)
+    evals_draws = int(sampler.nevals) - NLIVE * data["y"].shape[1]
+    return {"workload": "complete analysis of the same spectra on the CPU oracle's kernels, capped at %d iterations" % iterations,
+            "kind": kind, "cores": 1, "wall_s": duration, "iterations": int(results["nsamples"]), "ndraws": int(sampler.ndraws),
+            "constrained_draws": int(sampler.ndraw_calls), "evals_useful": evals_draws,
+            "draw_constrained_wall_s": sampler.draw_seconds,
+            "evals_per_s_in_draw_constrained": evals_draws / sampler.draw_seconds if sampler.draw_seconds else None,
+            "evals_per_s_whole_run": int(sampler.nevals) / duration, "logZ_first3": [float(v) for v in results["logZ"][:3]]}
+
+
 def e2e_leg(data, iterations, use_graph=False):
     """SURVEY 8(d)'s metric as it is defined: a real analysis (sampler + integrator + constrainers
     on the host, every kernel and the accept / fill decisions on the device) of the same spectra,
@@ -213,6 +300,9 @@ def e2e_leg(data, iterations, use_graph=False):
         out["draw_chunks"] = int(st["chunks"])
         out["launch_sequences"] = int(st["chunks"] + st["radii"] + st["counts"])
         out["evals_scored"] = int(st["pairs"] + NLIVE * data["y"].shape[1])
+    if hasattr(sampler, "core_stats"):
+        # the integer side of every iteration ran in the library as well (mdns.h Part 6): its counters
+        out["core"] = sampler.core_stats()
     if iterations == 0:
         out["workload"] = "COMPLETE analysis of the same spectra to the termination criterion (tolerance 0.5, nlive %d)" % NLIVE
     if joint is not None:
@@ -619,8 +709,14 @@ def bench_gauss(args):
                 res["e2e_full"] = e2e_leg(data, 0, use_graph=True)
         if world == 1 and not args.no_hbm_leg:
             res["roofline_hbm_regime"] = hbm_regime_leg(lib, _lib)
+            res["muse"] = muse_leg(lib, _lib)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline_gauss(data, priortransform(np.random.RandomState(2).uniform(size=(64, NDIM))))
+            if not args.no_e2e:
+                # like for like: the first iterations of the SAME analysis on the CPU oracle's kernels and, with
+                # the same cap, on the GPU (identical draws: the ratio of the two is the end-to-end speed-up)
+                res["cpu_baseline"]["e2e"] = cpu_baseline_e2e(data, args.cpu_e2e_iterations)
+                res["e2e_matched"] = e2e_leg(data, args.cpu_e2e_iterations, use_graph=True)
         print(json.dumps(res))
 
     lib.mdns_region_destroy(region)
@@ -813,6 +909,7 @@ def main():
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the 1.6 GB one-pass HBM-regime measurement")
     ap.add_argument("--no-e2e", action="store_true", help="skip the capped complete analysis")
     ap.add_argument("--e2e-iterations", type=int, default=400)
+    ap.add_argument("--cpu-e2e-iterations", type=int, default=100, help="cap of the CPU-oracle run of the same analysis (cpu_baseline.e2e)")
     ap.add_argument("--no-e2e-full", action="store_true", help="skip the complete analysis (about 40 s)")
     ap.add_argument("--event-every", type=int, default=4, help="time every n-th launch of the dominant kernel")
     ap.add_argument("--no-events", action="store_true", help="no per-launch events in the timed loop (roofline empty)")
