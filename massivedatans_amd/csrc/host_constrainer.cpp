@@ -966,6 +966,20 @@ int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsign
 		while (need > 0) {
 			if (!src.filled || src.pos == 256) src.refill();
 			int p = src.pos >> 1;
+			// whole groups of eight pairs while they cannot finish the candidate: no branch per pair (rejected
+			// pairs carry r2 = 3, which no minimum takes), the compiler vectorises the two reductions
+			while (p + 8 <= 128 && need > 16) {
+				int ok = 0;
+				double m = minr2;
+				for (int t = 0; t < 8; t++) {
+					const double r2 = src.r2[p + t];
+					ok += r2 < 1.5 ? 1 : 0;
+					m = r2 < m ? r2 : m;
+				}
+				minr2 = m;
+				need -= 2 * ok;
+				p += 8;
+			}
 			for (; p < 128 && need > 0; p++) {
 				const double r2 = src.r2[p];
 				if (r2 > 1.5) continue;                         // rejected pair (legacy_gauss: r2 >= 1 or r2 == 0)
