@@ -196,6 +196,10 @@ bool launch_bootstrap(const double *d_members, int K, int ndim, const double *d_
 bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const unsigned *d_packed,
                              int nbootstraps, double *d_round_sq, const BootstrapFinish *finish);
 bool launch_nn_maxsq(const double *d_members, int K, int ndim, double *d_out);
+// K6 with the pool in Morton order and tile culling (mdns_k6sort.hip): the same radius, bit for bit
+bool bootstrap_sorted_applies(int K, int ndim, int nbootstraps);
+bool launch_bootstrap_sorted(const double *d_members, int K, int ndim, const unsigned *d_packed, int nbootstraps,
+                             double *d_round_sq, const BootstrapFinish *finish);
 
 // ---- the first batch of a region without a host look in between (mdns_chain.hip) --------
 // what the chain kernels need of a region whose radius computation has been launched (mdns_core.hip)

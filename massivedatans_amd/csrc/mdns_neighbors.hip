@@ -13,6 +13,7 @@
 // radii (cneighbors.c:64-71,160-174) the root is taken once after the max of the min squared
 // distances -- the same number because sqrt is monotone.
 #include "mdns_internal.h"
+#include "mdns_radius.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -196,46 +197,6 @@ __global__ void k_pack_chosen(const double *__restrict__ chosen, int K, int nboo
 	for (int b = 0; b < kRounds; b++)
 		if (b < nb) m |= (row[b] != 0.0 ? 1u : 0u) << b;
 	mask[i] = m;
-}
-
-// Radius and membership threshold of a region, on the device: radius = sqrt(max_b round_sq[b])
-// (cneighbors.c:160-174; sqrt after the max, monotone) and thresh = the smallest double T
-// with sqrt(T) >= radius, so that  sqrt(d) < radius  <=>  d < T  (cneighbors.c:88,109).  Same
-// bisection over bit patterns as mdns::sqrt_threshold on the host; hipcc's sqrt(double) is
-// correctly rounded (verified bit for bit against the host on 1.6e7 inputs, and the parity
-// tests compare both paths), so the two agree exactly.  Run by one lane of the last workgroup
-// of a radius computation (normally ~15 square roots).
-__device__ void radius_and_threshold(double max_sq, double &radius, double &thresh)
-{
-	const double r = sqrt(max_sq);     // sqrt after the max: same number, sqrt is monotone
-	double T;
-	if (!(r > 0.0)) T = 0.0;                       // nothing is strictly within a zero radius
-	else if (r == __longlong_as_double(0x7ff0000000000000LL)) T = r;
-	else {
-		// T lies within a few ulps of r*r: walk there, and keep the full bisection for the
-		// cases where r*r leaves the normal range or the walk does not settle
-		const double t0 = r * r;
-		unsigned long long u = (unsigned long long) __double_as_longlong(t0);
-		bool settled = false;
-		if (t0 > 1e-300 && t0 < 1e300) {
-			int guard = 0;
-			while (sqrt(__longlong_as_double((long long) u)) < r && guard < 8) { u++; guard++; }
-			while (guard < 16 && sqrt(__longlong_as_double((long long) (u - 1))) >= r) { u--; guard++; }
-			settled = guard < 16 && sqrt(__longlong_as_double((long long) u)) >= r &&
-			          sqrt(__longlong_as_double((long long) (u - 1))) < r;
-		}
-		if (!settled) {
-			unsigned long long lo = 0, hi = 0x7ff0000000000000ULL;
-			while (hi - lo > 1) {
-				const unsigned long long mid = lo + (hi - lo) / 2;
-				if (sqrt(__longlong_as_double((long long) mid)) >= r) hi = mid; else lo = mid;
-			}
-			u = hi;
-		}
-		T = __longlong_as_double((long long) u);
-	}
-	radius = r;
-	thresh = T;
 }
 
 // NN == false (K6, cneighbors.c:137-168): rounds of the window packed in `mask`; a left-out
@@ -687,6 +648,8 @@ bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const uns
                              int nbootstraps, double *d_round_sq, const BootstrapFinish *finish)
 {
 	if (nbootstraps > kRounds || !finish) { set_error("packed bootstrap: at most %d rounds, finishing only", kRounds); return false; }
+	// pools of a thousand points and more: Morton order + tile culling (mdns_k6sort.hip)
+	if (bootstrap_sorted_applies(K, ndim, nbootstraps)) return launch_bootstrap_sorted(d_members, K, ndim, d_packed, nbootstraps, d_round_sq, finish);
 	Context *c = ctx();
 	static const char *forced = getenv("MDNS_K6_PATH");                   // "classic": the masked-NaN kernel (experiments)
 	const bool classic = forced && !strcmp(forced, "classic");
