@@ -290,8 +290,14 @@ static bool launched(const char *name)
 // whether the sorted form applies (pools of 1 024 .. 16 384 points in at most 5 dimensions, 10 or 16 rounds)
 bool bootstrap_sorted_applies(int K, int ndim, int nbootstraps)
 {
-	static const char *forced = getenv("MDNS_K6_PATH");                   // "sorted" / "uniform" / "classic" (experiments)
-	if (forced && strcmp(forced, "sorted") != 0 && forced[0]) return false;
+	// Opt-in (MDNS_K6_PATH=sorted): measured on the MI355X (profiles/r04_k6_sorted.txt) the pair of kernels
+	// takes 104 + 101 us at 5 000 points against 51 us for the all-pairs pair -- the sort is one workgroup on
+	// one CU (91 bitonic stages of 1 us), and a wave that walks its tiles alone has nothing to hide the
+	// latency of its 28-instruction chain behind (300 cycles per member instead of the 28 x 5 the all-pairs
+	// kernel reaches with five waves per SIMD).  Kept for its tests and as the starting point of a version
+	// with a multi-workgroup sort and four members in flight per wave.
+	static const char *forced = getenv("MDNS_K6_PATH");
+	if (!forced || strcmp(forced, "sorted") != 0) return false;
 	return ndim >= 1 && ndim <= 5 && K >= 1024 && K <= kMostSorted && nbootstraps >= 1 && nbootstraps <= 16;
 }
 

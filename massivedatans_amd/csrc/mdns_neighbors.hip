@@ -369,7 +369,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 template <int D, int RT>
 __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
     const double *__restrict__ members, int K, const unsigned *__restrict__ mask, int kchunk, int tile_n,
-    double *__restrict__ part)
+    double *__restrict__ part, unsigned *__restrict__ block_tickets, int nb, double *__restrict__ round_sq,
+    BootstrapFinish fin, int nround_all)
 {
 	extern __shared__ double smem[];
 	double *tile = smem;                                                   // [tile_n][D]
@@ -427,6 +428,81 @@ __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
 		const int p = blockIdx.x * 64 + l;
 		if (p < K) part[((size_t) blockIdx.y * K + p) * RT + b] = v;
 	}
+	if (!block_tickets) return;                        // (the merge is a kernel of its own: k_nearest_finish)
+	// Round 4: the merge rides in this kernel.  Of the gridDim.y workgroups that share these 64 points the
+	// one that arrives LAST takes the min over the member chunks and the max over the left-out points
+	// (cneighbors.c:160-168); of those, the last one finishes the radius (k_nearest_chosen's epilogue).
+	__shared__ int s_last;
+	__shared__ double wmax[4][RT];
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const unsigned t = atomicAdd(block_tickets + blockIdx.x, 1u);
+		s_last = t == gridDim.y - 1 ? 1 : 0;
+		if (s_last) block_tickets[blockIdx.x] = 0;       // for the next computation (stream order)
+	}
+	__syncthreads();
+	if (!s_last) return;
+	__threadfence();
+	{
+		const int ny = (int) gridDim.y;
+		const int i2 = blockIdx.x * 64 + ((int) threadIdx.x >> 2), yq = threadIdx.x & 3;
+		double v[RT];
+#pragma unroll
+		for (int b = 0; b < RT; b++) v[b] = 0.0;
+		const bool counts = i2 < K && i2 >= 1;
+		if (counts) {
+#pragma unroll
+			for (int b = 0; b < RT; b++) v[b] = 1e300;
+			for (int y = yq; y < ny; y += 4) {
+				const double *row = part + ((size_t) y * K + i2) * RT;
+#pragma unroll
+				for (int b = 0; b < RT; b++) v[b] = fmin(v[b], __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+			}
+		}
+#pragma unroll
+		for (int b = 0; b < RT; b++) {
+			v[b] = fmin(v[b], __shfl_xor(v[b], 1, 64));
+			v[b] = fmin(v[b], __shfl_xor(v[b], 2, 64));
+		}
+		if (counts) {
+			const unsigned m = mask[i2];
+#pragma unroll
+			for (int b = 0; b < RT; b++) if (b >= nb || (m >> b & 1u)) v[b] = 0.0;
+		}
+#pragma unroll
+		for (int b = 0; b < RT; b++) {
+			const double w = wave_max(v[b]);
+			if (lane == 0) wmax[wv][b] = w;
+		}
+		__syncthreads();
+		if ((int) threadIdx.x < RT && (int) threadIdx.x < nb) {
+			const double w = fmax(fmax(wmax[0][threadIdx.x], wmax[1][threadIdx.x]), fmax(wmax[2][threadIdx.x], wmax[3][threadIdx.x]));
+			if (w > 0.0) atomic_max_nonneg(round_sq + threadIdx.x, w);
+		}
+	}
+	if (!fin.counter) return;
+	__threadfence();
+	__syncthreads();
+	if (wv != 0) return;
+	unsigned ticket = 0;
+	if (lane == 0) ticket = atomicAdd(fin.counter, 1u);
+	if (__shfl(ticket, 0, 64) != gridDim.x - 1) return;
+	__threadfence();
+	double best = 0.0;
+	for (int b = lane; b < nround_all; b += 64)
+		best = fmax(best, __hip_atomic_load(round_sq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	best = wave_max(best);
+	for (int b = lane; b < nround_all; b += 64) round_sq[b] = 0.0;
+	if (lane != 0) return;
+	double radius, thresh;
+	radius_and_threshold(best, radius, thresh);
+	fin.d_res->radius = radius;
+	fin.d_res->thresh = thresh;
+	*fin.counter = 0;
+	fin.h_res->radius = radius;
+	fin.h_res->thresh = thresh;
+	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // min over the member chunks, then per round the max over the left-out points with index >= 1
@@ -670,12 +746,26 @@ bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const uns
 		dim3 grid((K + 63) / 64, ny);
 		ProfileScope prof(3);
 		note_kernel(3, "k_nearest_uniform<%d, %d>", ndim, rt);
-#define UNI_LAUNCH(D) do { if (rt == 10) hipLaunchKernelGGL((k_nearest_uniform<D, 10>), grid, dim3(kBlock), lds, c->stream, d_members, K, d_packed, kchunk, tile_n, d_part); \
-		else hipLaunchKernelGGL((k_nearest_uniform<D, kRounds>), grid, dim3(kBlock), lds, c->stream, d_members, K, d_packed, kchunk, tile_n, d_part); } while (0)
+		// the merge inside the kernel (its last workgroups) unless MDNS_K6_MERGE=kernel asks for the separate one
+		static const char *merge = getenv("MDNS_K6_MERGE");
+		const bool fold = !(merge && !strcmp(merge, "kernel"));
+		static unsigned *d_tickets = nullptr;
+		static int tickets_cap = 0;
+		if (fold && (int) grid.x > tickets_cap) {
+			if (d_tickets) { (void) hipStreamSynchronize(c->stream); (void) hipFree(d_tickets); d_tickets = nullptr; }
+			const int cap = (int) grid.x + 1024;
+			if (!MDNS_HIP(hipMalloc((void **) &d_tickets, (size_t) cap * sizeof(unsigned))) ||
+			    !MDNS_HIP(hipMemsetAsync(d_tickets, 0, (size_t) cap * sizeof(unsigned), c->stream))) { d_tickets = nullptr; tickets_cap = 0; return false; }
+			tickets_cap = cap;
+		}
+		unsigned *tickets = fold ? d_tickets : nullptr;
+#define UNI_LAUNCH(D) do { if (rt == 10) hipLaunchKernelGGL((k_nearest_uniform<D, 10>), grid, dim3(kBlock), lds, c->stream, d_members, K, d_packed, kchunk, tile_n, d_part, tickets, nbootstraps, d_round_sq, *finish, nbootstraps); \
+		else hipLaunchKernelGGL((k_nearest_uniform<D, kRounds>), grid, dim3(kBlock), lds, c->stream, d_members, K, d_packed, kchunk, tile_n, d_part, tickets, nbootstraps, d_round_sq, *finish, nbootstraps); } while (0)
 		switch (ndim) { case 1: UNI_LAUNCH(1); break; case 2: UNI_LAUNCH(2); break; case 3: UNI_LAUNCH(3); break;
 		                case 4: UNI_LAUNCH(4); break; default: UNI_LAUNCH(5); break; }
 #undef UNI_LAUNCH
 		if (!launched("k_nearest_uniform")) return false;
+		if (fold) return true;
 		const dim3 fgrid((K + kBlock / 4 - 1) / (kBlock / 4));
 		if (rt == 10) hipLaunchKernelGGL((k_nearest_finish<10>), fgrid, dim3(kBlock), 0, c->stream, (const double *) d_part, K, ny, d_packed, nbootstraps, d_round_sq, *finish, nbootstraps);
 		else hipLaunchKernelGGL((k_nearest_finish<kRounds>), fgrid, dim3(kBlock), 0, c->stream, (const double *) d_part, K, ny, d_packed, nbootstraps, d_round_sq, *finish, nbootstraps);

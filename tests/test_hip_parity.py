@@ -779,10 +779,11 @@ def test_muse_multi_loglikelihood_with_jitter(oracle):
                                           (16384, 3, 10), (9000, 3, 10)])
 def test_k6_in_morton_order_gives_the_all_pairs_radius(K, ndim, nboot, oracle, monkeypatch):
     """K6 with the pool sorted along a Morton curve and far tiles culled (csrc/mdns_k6sort.hip) against the
-    all-pairs kernel of round 3 (MDNS_K6_PATH=uniform) and the oracle, bit for bit -- on point sets built to
+    all-pairs kernel (the default) and the oracle, bit for bit -- on point sets built to
     hurt a spatial scheme: a dense core inside a thin halo, duplicated points, a degenerate axis, and the
     pool's point 0 (which the reference never lets contribute, cneighbors.c:162) placed far outside."""
     import subprocess, sys, json
+    from massivedatans_amd.clustering import neighbors
     rng = np.random.RandomState(K + ndim)
     core = rng.normal(0.5, 0.002, size=(K // 2, ndim))
     halo = rng.uniform(size=(K - K // 2, ndim))
@@ -798,10 +799,10 @@ def test_k6_in_morton_order_gives_the_all_pairs_radius(K, ndim, nboot, oracle, m
     chosen = neighbors.unpack_bootstrap_masks(masks, nboot)
     want = oracle.bootstrapped_maxdistance(np.ascontiguousarray(pts), np.ascontiguousarray(chosen))
     s = neighbors.MemberSet(pts)
-    got = s.bootstrap_radius_packed(masks, nboot)
+    got = s.bootstrap_radius_packed(masks, nboot)          # the default path: all pairs
     s.close()
     assert got == want
-    # the same through the all-pairs kernel, in a fresh process (the path is chosen once per process)
+    # the same through the sorted form, in a fresh process (the path is chosen once per process)
     code = ("import sys, numpy as np; sys.path.insert(0, %r); from massivedatans_amd.clustering import neighbors; "
             "d = np.load(sys.argv[1]); s = neighbors.MemberSet(d['pts']); print(repr(s.bootstrap_radius_packed(d['masks'], int(d['nboot']))))" % ROOT)
     import tempfile
@@ -809,6 +810,6 @@ def test_k6_in_morton_order_gives_the_all_pairs_radius(K, ndim, nboot, oracle, m
         path = os.path.join(tmp, "k6.npz")
         np.savez(path, pts=pts, masks=masks, nboot=nboot)
         out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, timeout=300,
-                             env=dict(os.environ, MDNS_K6_PATH="uniform"))
+                             env=dict(os.environ, MDNS_K6_PATH="sorted"))
     assert out.returncode == 0, out.stderr[-1500:]
     assert float(out.stdout.strip().splitlines()[-1]) == want
