@@ -746,9 +746,12 @@ bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const uns
 		dim3 grid((K + 63) / 64, ny);
 		ProfileScope prof(3);
 		note_kernel(3, "k_nearest_uniform<%d, %d>", ndim, rt);
-		// the merge inside the kernel (its last workgroups) unless MDNS_K6_MERGE=kernel asks for the separate one
+		// MDNS_K6_MERGE=fold: the merge inside the kernel (its last workgroups) instead of k_nearest_finish.
+		// Measured (profiles/r04_k6_sorted.txt): 33.9 / 87.9 / 263.6 / 417.6 us at 1 000 / 2 000 / 5 000 / 9 000
+		// points against 20.1 / 24.2 / 50.9 / 113.6 for the pair of kernels -- the device-scope fence every
+		// workgroup needs before its ticket costs far more than the launch it saves.  Not the default.
 		static const char *merge = getenv("MDNS_K6_MERGE");
-		const bool fold = !(merge && !strcmp(merge, "kernel"));
+		const bool fold = merge && !strcmp(merge, "fold");
 		static unsigned *d_tickets = nullptr;
 		static int tickets_cap = 0;
 		if (fold && (int) grid.x > tickets_cap) {

@@ -784,6 +784,7 @@ def test_k6_in_morton_order_gives_the_all_pairs_radius(K, ndim, nboot, oracle, m
     pool's point 0 (which the reference never lets contribute, cneighbors.c:162) placed far outside."""
     import subprocess, sys, json
     from massivedatans_amd.clustering import neighbors
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rng = np.random.RandomState(K + ndim)
     core = rng.normal(0.5, 0.002, size=(K // 2, ndim))
     halo = rng.uniform(size=(K - K // 2, ndim))
