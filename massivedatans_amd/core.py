@@ -115,6 +115,7 @@ class NativeCoreSampler(MultiNestedSampler):
 
     def __init__(self, *args, **kwargs):
         self._core = None
+        self._pile_cache = {}
         settings = kwargs.pop("constrainer_settings", ("truncatedscaling", 1000, 20, True))
         kwargs.setdefault("superset_draw_constrained", None)
         kwargs.setdefault("individual_draw_constrained", None)
@@ -166,6 +167,7 @@ class NativeCoreSampler(MultiNestedSampler):
         self._check(L.mdns_core_set_initial(self._core, us.ctypes.data, xs.ctypes.data), "mdns_core_set_initial")
         self._stats = numpy.zeros(len(COUNTERS), dtype=numpy.int64)
         self._lp_cache = None
+        self._pile_cache = {}
         self.fill_seconds = 0.0
 
     def __del__(self):
@@ -195,16 +197,22 @@ class NativeCoreSampler(MultiNestedSampler):
         self._L.mdns_core_stats(self._core, self._stats.ctypes.data)
         return int(self._stats[k])
 
-    def _pile(self, getter):
+    def _pile(self, getter, which):
+        """A copy of the pile (the library's buffer moves when it grows), kept until the next draw."""
         n = int(self._L.mdns_core_npoints(self._core))
+        cached = self._pile_cache.get(which)
+        if cached is not None and len(cached) == n:
+            return cached
         ptr = getter(self._core)
-        return numpy.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (n, self.ndim)).copy()
+        out = numpy.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_double)), (n, self.ndim)).copy()
+        self._pile_cache[which] = out
+        return out
 
     @property
     def pointpile(self):
         if self._core is None:
             return self.__dict__["_init_pointpile"]
-        return self._pile(self._L.mdns_core_pile_u)
+        return self._pile(self._L.mdns_core_pile_u, 'u')
 
     @pointpile.setter
     def pointpile(self, value):
@@ -215,7 +223,7 @@ class NativeCoreSampler(MultiNestedSampler):
     def pointpilex(self):
         if self._core is None:
             return self.__dict__["_init_pointpilex"]
-        return self._pile(self._L.mdns_core_pile_x)
+        return self._pile(self._L.mdns_core_pile_x, 'x')
 
     @pointpilex.setter
     def pointpilex(self, value):

@@ -499,6 +499,8 @@ _POP8 = numpy.array([bin(i).count("1") for i in range(256)], dtype=numpy.int64)
 
 def _popcount(words):
     """Set bits of every uint64 of ``words``."""
+    if hasattr(numpy, "bitwise_count"):
+        return numpy.bitwise_count(numpy.ascontiguousarray(words)).astype(numpy.int64)
     return _POP8[numpy.ascontiguousarray(words).view(numpy.uint8).reshape(len(words), 8)].sum(axis=1)
 
 
