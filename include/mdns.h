@@ -579,6 +579,14 @@ void *mdns_get_stream(void);
 int mdns_backend_draw_band(void *joint, const double *params, int B, const double *bound, int *status, int *npairs,
                            int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap);
 int mdns_backend_draw_band_commit(void *joint, int b, const double *jitter_row, unsigned long long *fillbits);
+/* mdns_backend_draw_band scores large chunks (>= 8 candidates x >= 512 spectra) as two matrix products on
+ * v_mfma_f64_16x16x4_f64 with the band widened by a rigorous bound on the rounding of that form
+ * (csrc/mdns_k2gemm.hip); whatever that leaves undecided is scored again by the exact row kernels, and the
+ * accepted candidate's row always is.  mode: -1 by shape (default; MDNS_K2_FILTER=0 / 1 at start), 0 never,
+ * 1 for every chunk.  stats: chunks filtered | of those scored again exactly | exact rows made for a
+ * commit | spectra handles prepared. */
+void mdns_muse_filter_mode(int mode);
+void mdns_muse_filter_stats(long long *out4);
 int mdns_backend_chain_begin(void *joint, void *region, const mdns_chain_request *rq);
 int mdns_backend_chain_end(void *joint, void *region, int *counts, int *nkept, int *B, int *accepted,
                            unsigned long long *fillbits, double *params);

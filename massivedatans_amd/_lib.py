@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "mdns_backend_draw_begin", "mdns_backend_draw_chunk", "mdns_backend_chunk_size",
     "mdns_backend_region_begin", "mdns_backend_region_radius", "mdns_backend_chain_begin", "mdns_backend_chain_end",
     "mdns_backend_draw_score", "mdns_joint_votes_dev", "mdns_backend_draw_commit", "mdns_get_stream",
-    "mdns_backend_draw_band", "mdns_backend_draw_band_commit",
+    "mdns_backend_draw_band", "mdns_backend_draw_band_commit", "mdns_muse_filter_mode", "mdns_muse_filter_stats",
 )
 
 #: the symbols of include/mdns.h Part 5 that live in libmdns_host.so (plain host code, no GPU)
@@ -177,6 +177,8 @@ def _declare(lib):
         "mdns_get_stream": (vp, []),
         "mdns_backend_draw_band": (i, [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i]),
         "mdns_backend_draw_band_commit": (i, [vp, i, vp, vp]),
+        "mdns_muse_filter_mode": (None, [i]),
+        "mdns_muse_filter_stats": (None, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

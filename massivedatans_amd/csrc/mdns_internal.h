@@ -56,6 +56,11 @@ struct mdns_spectra {
 	int *d_rows = nullptr; size_t rows_cap = 0;
 	double *d_out = nullptr; size_t out_cap = 0;
 	double *d_sel = nullptr; size_t sel_cap = 0;       // compact replica of the current selection (K1 lane kernel)
+	// K2 on the matrix cores (mdns_k2gemm.hip), made on first use: y w and w [ndata, ldf] with ldf = nx rounded
+	// up to 16 (zero padded; d_fw is d_w itself when the strides agree), A = sum y^2 w [ndata]
+	double *d_fyw = nullptr, *d_fw = nullptr, *d_fa = nullptr;
+	int ldf = 0;
+	bool fw_owned = false;
 };
 
 namespace mdns {
@@ -150,7 +155,15 @@ bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B
 bool launch_gauss_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
                        double scale, const int *d_rows, int M, double *d_out);
 bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
-                      const int *d_rows, int M, double *d_out);
+                      const int *d_rows, int M, double *d_out, int B_shape = 0);
+int muse_rows_variant(int B, int M);
+// the band test of a chunk (mdns_joint.hip, k_joint_band) on K2 as two matrix products (mdns_k2gemm.hip):
+// where its outcome goes (device memory; clear / maybe per candidate, listed pairs behind a counter)
+struct MuseBandOut { int *counter, *clear, *maybe, *pair_b, *pair_k; double *pair_L, *pair_thr; int cap; int *zero_at; };
+bool muse_filter_applies(const mdns_spectra *s, int B, int M);
+bool launch_muse_filter(mdns_spectra *s, const double *d_model, int ldm, int B, const int *d_rows, int M,
+                        const double *d_higher, const double *d_bound, const MuseBandOut &out);
+void muse_filter_note(int which);          // 1: a chunk scored again exactly, 2: an exact row for a commit
 // src [nx][lds] -> dst [ndata][ld] (only the nx x ndata corner is touched)
 bool launch_transpose(const double *d_src, int nx, int ndata, double *d_dst, int ld,
                       bool invert, int lds);

@@ -507,6 +507,7 @@ struct mdns_joint {
 	double *d_bound = nullptr;                // [MDNS_JOINT_MAX_BATCH] bounds, then room for one noise row [ndata]
 	unsigned long long band_seq = 0;
 	int band_B = 0;
+	bool band_exact = true;           // d_dense holds the exact likelihoods of the chunk (not the matrix-core filter's)
 	// a chunk in two halves (mdns_backend_draw_score / _commit): one 0 / 1 vote per candidate, what the ranks
 	// of a sharded run MAX-reduce in between
 	int *d_votes = nullptr;
@@ -1646,27 +1647,44 @@ extern "C" int mdns_backend_draw_band(void *joint, const double *params, int B, 
 	}
 	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
 	if (!joint_grow(&j->d_dense, &j->dense_cap, n)) return 1;
-	if (mdns_muse3_loglike_batch_dev(j->s, j->d_params, B, d_rows, M, j->d_dense) != 0) return 1;
-	hipLaunchKernelGGL(k_joint_band, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream, (const double *) j->d_dense,
-	                   (const double *) j->d_bound, B, M, d_rows, (const double *) j->st.higher, j->d_band, (JointHeader *) j->d_result);
-	hipLaunchKernelGGL(k_joint_band_publish, dim3(1), dim3(kBlock), 0, c->stream, j->d_band, B, j->h_band_dev, ++j->band_seq);
-	if (!MDNS_HIP(hipGetLastError())) return 1;
-	j->band_B = B;
-	j->trail_valid = false;
-	j->last_B = 0;
-	volatile unsigned long long *at = &j->h_band->seq;
-	long long started = 0;
-	for (unsigned spin = 0; *at != j->band_seq; spin++) {
-		if ((spin & 1023) != 1023) continue;
-		const hipError_t e = hipStreamQuery(c->stream);
-		if (e == hipErrorNotReady) {
-			if (poll_expired(&started)) { set_error("mdns_backend_draw_band: no outcome within MDNS_POLL_TIMEOUT_S"); return 1; }
-			continue;
+	// Large chunks first as two matrix products with a widened band (mdns_k2gemm.hip): whatever that settles
+	// is settled as the exact kernels would; a chunk it lists a pair of is scored again by those.
+	const int ldm = model_ld(j->s->nx);
+	bool filtered = muse_filter_applies(j->s, B, M);
+	for (;;) {
+		if (filtered) {
+			if (!ensure_model(j->s, (size_t) B * ldm) || !launch_muse3_model(j->s->d_x, j->s->nx, j->d_params, B, j->s->d_model, ldm)) return 1;
+			const MuseBandOut out = {&j->d_band->counter, j->d_band->clear, j->d_band->maybe, j->d_band->pair_b, j->d_band->pair_k,
+			                         j->d_band->pair_L, j->d_band->pair_thr, kBandCap, &((JointHeader *) j->d_result)->status};
+			if (!launch_muse_filter(j->s, j->s->d_model, ldm, B, d_rows, M, j->st.higher, j->d_bound, out)) return 1;
+		} else {
+			if (mdns_muse3_loglike_batch_dev(j->s, j->d_params, B, d_rows, M, j->d_dense) != 0) return 1;
+			hipLaunchKernelGGL(k_joint_band, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream, (const double *) j->d_dense,
+			                   (const double *) j->d_bound, B, M, d_rows, (const double *) j->st.higher, j->d_band, (JointHeader *) j->d_result);
 		}
-		if (e != hipSuccess) { set_error("mdns_backend_draw_band: %s", hipGetErrorString(e)); return 1; }
-		if (*at != j->band_seq) { set_error("mdns_backend_draw_band: finished without an outcome"); return 1; }
+		hipLaunchKernelGGL(k_joint_band_publish, dim3(1), dim3(kBlock), 0, c->stream, j->d_band, B, j->h_band_dev, ++j->band_seq);
+		if (!MDNS_HIP(hipGetLastError())) return 1;
+		j->band_B = B;
+		j->band_exact = !filtered;
+		j->trail_valid = false;
+		j->last_B = 0;
+		volatile unsigned long long *at = &j->h_band->seq;
+		long long started = 0;
+		for (unsigned spin = 0; *at != j->band_seq; spin++) {
+			if ((spin & 1023) != 1023) continue;
+			const hipError_t e = hipStreamQuery(c->stream);
+			if (e == hipErrorNotReady) {
+				if (poll_expired(&started)) { set_error("mdns_backend_draw_band: no outcome within MDNS_POLL_TIMEOUT_S"); return 1; }
+				continue;
+			}
+			if (e != hipSuccess) { set_error("mdns_backend_draw_band: %s", hipGetErrorString(e)); return 1; }
+			if (*at != j->band_seq) { set_error("mdns_backend_draw_band: finished without an outcome"); return 1; }
+		}
+		std::atomic_thread_fence(std::memory_order_acquire);
+		if (!filtered || j->h_band->npairs == 0) break;
+		filtered = false;
+		muse_filter_note(1);
 	}
-	std::atomic_thread_fence(std::memory_order_acquire);
 	memcpy(status, (const void *) j->h_band->status, (size_t) B * sizeof(int));
 	*npairs = j->h_band->npairs;
 	const int m = *npairs < cap ? (*npairs < kBandCap ? *npairs : kBandCap) : cap;
@@ -1685,6 +1703,17 @@ extern "C" int mdns_backend_draw_band_commit(void *joint, int b, const double *j
 	if (!c || !j || !jitter_row) { set_error("mdns_backend_draw_band_commit: null argument"); return 1; }
 	if (j->kind != 1 || !j->sel_open || j->band_B <= 0 || b < 0 || b >= j->band_B) { set_error("mdns_backend_draw_band_commit: candidate %d of a chunk of %d", b, j->band_B); return 1; }
 	const int M = j->sel_M, ntiles = (M + 63) / 64;
+	if (!j->band_exact) {
+		// the chunk went through the matrix-core filter: what the state keeps is the exact kernel's row --
+		// from the instantiation that would have scored the whole block, bit for bit (the templates of
+		// the chunk are still in place)
+		const int ldm = model_ld(j->s->nx), Bc = j->band_B;
+		const int lo = muse_rows_variant(Bc, M) == 1 ? (b & ~1) : b;
+		const int nb = lo == b && muse_rows_variant(Bc, M) != 1 ? 1 : (Bc - lo < 2 ? Bc - lo : 2);
+		if (!launch_muse_rows(j->s, j->s->d_model + (size_t) lo * ldm, ldm, nb, j->sel_rows ? j->d_sel_rows : nullptr, M,
+		                      j->d_dense + (size_t) lo * M, Bc)) return 1;
+		muse_filter_note(2);
+	}
 	j->band_B = 0;
 	double *d_row = j->d_bound + MDNS_JOINT_MAX_BATCH;
 	char *pin = joint_pin(j, (size_t) M * sizeof(double));

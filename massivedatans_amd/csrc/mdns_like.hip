@@ -1397,16 +1397,29 @@ bool launch_gauss_rows(const mdns_spectra *s, const double *d_model, int ldm, in
 	return launched("k_gauss_rows");
 }
 
+// which instantiation scores a block of B candidates x M spectra: 2 two rows per workgroup, 1 pairs of
+// candidates, 0 one candidate.  (Their reductions associate differently: the last bits of a likelihood
+// depend on the instantiation and, for pairs, on the candidate's place in its pair.)
+int muse_rows_variant(int B, int M)
+{
+	Context *c = ctx();
+	static const char *k2v = getenv("MDNS_K2_ROWS2");         // experiments only: "0" disables
+	if (B >= 4 && M >= 2 * c->num_cus && !(k2v && k2v[0] == '0')) return 2;
+	return B >= 2 ? 1 : 0;
+}
+
+// B_shape > 0: score these B candidates with the instantiation a block of B_shape candidates would take
+// (for variant 1 the caller passes whole pairs of that block)
 bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int B, const int *d_rows,
-                      int M, double *d_out)
+                      int M, double *d_out, int B_shape)
 {
 	Context *c = ctx();
 	const int nx = s->nx;
 	int blocks = M < c->num_cus * 8 ? M : c->num_cus * 8;
 	if (blocks < 1) blocks = 1;
 	ProfileScope prof(1);
-	static const char *k2v = getenv("MDNS_K2_ROWS2");         // experiments only: "0" disables
-	const bool two_rows = B >= 4 && M >= 2 * c->num_cus && !(k2v && k2v[0] == '0');
+	const int variant = muse_rows_variant(B_shape > 0 ? B_shape : B, M);
+	const bool two_rows = variant == 2;
 	// few rows, several candidates: split the candidates over grid.y until ~2 workgroups per CU
 	// (45 rows x 64 candidates: 69 us as one workgroup per row)
 	// (with more than half a workgroup per CU it measured slower: 407 rows x 16: 29.7 vs 24.2 us)
@@ -1415,11 +1428,11 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 	if (gy < 1) gy = 1;
 	const int bchunk = 2 * (((B + gy - 1) / gy + 1) / 2);         // even: k_muse_rows<NP, 2> walks pairs
 	gy = (B + bchunk - 1) / bchunk;
-	note_kernel(1, two_rows ? "k_muse_rows2<%d>" : (B >= 2 ? "k_muse_rows<%d, 2>" : "k_muse_rows<%d, 1>"),
+	note_kernel(1, two_rows ? "k_muse_rows2<%d>" : (variant == 1 ? "k_muse_rows<%d, 2>" : "k_muse_rows<%d, 1>"),
 	            nx <= 512 ? 1 : nx <= 1024 ? 2 : nx <= 2048 ? 4 : 8);
 #define MUSE_LAUNCH(NP) do { if (two_rows) hipLaunchKernelGGL((k_muse_rows2<NP>), dim3((blocks + 1) / 2), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
-	else if (B >= 2) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks, gy), dim3(kBlock), 0, c->stream, \
+	else if (variant == 1) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks, gy), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, bchunk); \
 	else hipLaunchKernelGGL((k_muse_rows<NP, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, B); } while (0)

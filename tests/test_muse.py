@@ -4,12 +4,17 @@ global random stream on every evaluation -- behind the sampler, through the clas
 constrainer and through the native one (csrc/host_constrainer.cpp), against traces recorded from
 the REFERENCE's own sampler / integrator / constrainers driven with the same problem definition
 (oracle/make_trace.py, cases muse*)."""
+import os
+import sys
+
 import numpy as np
 import pytest
 
-from massivedatans_amd import gen, musefuse
+from massivedatans_amd import _lib, gen, musefuse
 from oracle_backend import OracleMuseSpectra, patch_neighbors
 from tracing import Recorder, check_bookkeeping, check_floats, load_trace
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(g, backend, fused, native, jitter=True):
@@ -188,3 +193,68 @@ def test_configs4_whole_on_one_gpu():
         second = np.sort(np.vstack([live[:, took], L[pick][None, :]]), axis=0)[1, :]
         assert len(took) > 0 and np.allclose(thr_after[took], second, rtol=1e-12, atol=0)
     js.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ndata,nx,B,sparse", [(1500, 700, 40, False), (2000, 4096, 64, False), (1300, 333, 17, True), (600, 1024, 9, True)])
+def test_k2_matrix_core_filter_decides_like_the_exact_kernels(ndata, nx, B, sparse):
+    """mdns_backend_draw_band through the matrix-core filter (csrc/mdns_k2gemm.hip) against the exact row
+    kernels, with thresholds planted on the candidates' own likelihoods at relative distances from 1e-3 down
+    to 0 on both sides: every candidate's status and the listed pairs (which only the exact kernels may
+    produce) are the same; the filter handed the chunk over (it cannot settle a threshold 1e-13 away); and
+    the commit keeps the exact kernel's row."""
+    import ctypes as C
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import k2_filter_bench as kb
+    rng = np.random.RandomState(ndata + B)
+    rows = np.sort(rng.choice(ndata, size=ndata * 2 // 3, replace=False)).astype(np.int32) if sparse else None
+    results = {}
+    for mode in (0, 1):
+        sp, st, params, L, thr = kb.planted_state(ndata, nx, 6, B, 5, [-1e-3, -1e-9, -1e-13, 0.0, 1e-13, 1e-9, 1e-3])
+        lib = st._lib
+        s0 = kb.stats(lib)
+        res = kb.band(st, params, rows, np.zeros(B), mode)
+        s1 = kb.stats(lib)
+        M = ndata if rows is None else len(rows)
+        bits = np.zeros((M + 63) // 64, dtype=np.uint64)
+        first = int(np.flatnonzero(res[0] == 1)[0])
+        st._check(lib.mdns_backend_draw_band_commit(st._h, first, _lib.ptr(np.zeros(M)), _lib.ptr(bits)), "draw_band_commit")
+        higher, shelf_n = st.thresholds()
+        results[mode] = (res[:6], bits.copy(), higher.copy(), shelf_n.copy(), [b - a for a, b in zip(s0, s1)])
+        lib.mdns_muse_filter_mode(-1)
+        st.close(); sp.close()
+    exact, filt = results[0], results[1]
+    assert np.array_equal(exact[0][0], filt[0][0])                     # status per candidate
+    assert exact[0][1] == filt[0][1] and exact[0][1] > 0               # listed pairs: some thresholds are too close to call
+    for a, b in zip(exact[0][2:], filt[0][2:]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(exact[1], filt[1]) and np.array_equal(exact[2], filt[2]) and np.array_equal(exact[3], filt[3])
+    assert exact[4][0] == 0 and filt[4][0] == 1 and filt[4][1] == 1 and filt[4][2] == 0   # filtered once, handed over, commit from the exact block
+    assert (exact[0][0] == 1).any() and (exact[1] != 0).any()
+
+
+@pytest.mark.gpu
+def test_k2_matrix_core_filter_settles_clear_chunks_alone():
+    """Thresholds 1 % away from every candidate: the filter decides the whole chunk, nothing is scored
+    again, and the commit makes the accepted candidate's exact row (shelves and thresholds as without it)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import k2_filter_bench as kb
+    out = {}
+    for mode in (0, 1):
+        sp, st, params, L, thr = kb.planted_state(1800, 1200, 6, 48, 9, [-1e-2, 1e-2])
+        lib = st._lib
+        s0 = kb.stats(lib)
+        res = kb.band(st, params, None, np.full(48, 5e-5), mode)
+        bits = np.zeros((1800 + 63) // 64, dtype=np.uint64)
+        first = int(np.flatnonzero(res[0] == 1)[0])
+        jrow = np.random.RandomState(3).normal(0, 1e-5, size=1800)
+        st._check(lib.mdns_backend_draw_band_commit(st._h, first, _lib.ptr(jrow), _lib.ptr(bits)), "draw_band_commit")
+        higher, shelf_n = st.thresholds()
+        s1 = kb.stats(lib)
+        out[mode] = (res[0].copy(), res[1], bits, higher, shelf_n, [b - a for a, b in zip(s0, s1)])
+        lib.mdns_muse_filter_mode(-1)
+        st.close(); sp.close()
+    for a, b in zip(out[0][:5], out[1][:5]):
+        assert np.array_equal(a, b)
+    assert out[0][1] == 0
+    assert out[1][5][:3] == [1, 0, 1] and out[0][5][:3] == [0, 0, 0]
