@@ -460,6 +460,13 @@ typedef struct mdns_draw_backend {
 	int (*chain_begin)(void *user, void *region, const struct mdns_chain_request *rq);
 	int (*chain_end)(void *user, void *region, int *counts, int *nkept, int *B, int *accepted,
 	                 unsigned long long *fillbits, double *params);
+	/* Optional (all three or none): draw_band in two halves with a cheap look in between.  While a chunk
+	 * is being scored the constrainer already advances the stream for the candidates that FOLLOW it in
+	 * the same batch (their bounds do not depend on the outcome; if the chunk accepts somebody that work is
+	 * dropped), one candidate at a time until draw_band_ready returns nonzero. */
+	int (*draw_band_begin)(void *user, const double *params, int B, const double *bound);
+	int (*draw_band_ready)(void *user);
+	int (*draw_band_end)(void *user, int *status, int *npairs, int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap);
 } mdns_draw_backend;
 
 struct mdns_prior;
@@ -536,11 +543,12 @@ int mdns_constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, cons
  * [18] first batches chained on the device together with their chunk (chain_begin / chain_end), [19] with
  * their membership counts only, [20] accepted candidates of chained chunks whose device parameters were
  * not bit for bit the host's (10**v), [21] nanoseconds between chain_begin and chain_end; [22] pairs the
- * device could not decide without their noise (draw_band), [23] candidates whose noise was replayed for them.
+ * device could not decide without their noise (draw_band), [23] candidates whose noise was replayed for them,
+ * [24] candidates whose bound was ready before their chunk (made while the previous chunk was scored).
  * mdns_constrainer_share_stats:
  * every increment is also added to totals int64[MDNS_CONSTRAINER_COUNTERS] (the caller's: the sum
  * over a sampler's constrainers). */
-#define MDNS_CONSTRAINER_COUNTERS 24
+#define MDNS_CONSTRAINER_COUNTERS 25
 void mdns_constrainer_stats(const mdns_constrainer *c, long long *out);
 void mdns_constrainer_share_stats(mdns_constrainer *c, long long *totals);
 const char *mdns_host_last_error(void);
@@ -579,6 +587,9 @@ void *mdns_get_stream(void);
 int mdns_backend_draw_band(void *joint, const double *params, int B, const double *bound, int *status, int *npairs,
                            int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap);
 int mdns_backend_draw_band_commit(void *joint, int b, const double *jitter_row, unsigned long long *fillbits);
+int mdns_backend_draw_band_begin(void *joint, const double *params, int B, const double *bound);
+int mdns_backend_draw_band_ready(void *joint);
+int mdns_backend_draw_band_end(void *joint, int *status, int *npairs, int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap);
 /* mdns_backend_draw_band scores large chunks (>= 8 candidates x >= 512 spectra) as two matrix products on
  * v_mfma_f64_16x16x4_f64 with the band widened by a rigorous bound on the rounding of that form
  * (csrc/mdns_k2gemm.hip); whatever that leaves undecided is scored again by the exact row kernels, and the

@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "mdns_backend_region_begin", "mdns_backend_region_radius", "mdns_backend_chain_begin", "mdns_backend_chain_end",
     "mdns_backend_draw_score", "mdns_joint_votes_dev", "mdns_backend_draw_commit", "mdns_get_stream",
     "mdns_backend_draw_band", "mdns_backend_draw_band_commit", "mdns_muse_filter_mode", "mdns_muse_filter_stats",
+    "mdns_backend_draw_band_begin", "mdns_backend_draw_band_ready", "mdns_backend_draw_band_end",
 )
 
 #: the symbols of include/mdns.h Part 5 that live in libmdns_host.so (plain host code, no GPU)
@@ -177,6 +178,9 @@ def _declare(lib):
         "mdns_get_stream": (vp, []),
         "mdns_backend_draw_band": (i, [vp, vp, i, vp, vp, vp, vp, vp, vp, vp, i]),
         "mdns_backend_draw_band_commit": (i, [vp, i, vp, vp]),
+        "mdns_backend_draw_band_begin": (i, [vp, vp, i, vp]),
+        "mdns_backend_draw_band_ready": (i, [vp]),
+        "mdns_backend_draw_band_end": (i, [vp, vp, vp, vp, vp, vp, vp, i]),
         "mdns_muse_filter_mode": (None, [i]),
         "mdns_muse_filter_stats": (None, [vp]),
     }

@@ -38,6 +38,10 @@ _REGION_RADIUS = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_doub
 _DRAW_BAND = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int),
                          C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
 _DRAW_BAND_COMMIT = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_ulonglong))
+_DRAW_BAND_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_double))
+_DRAW_BAND_READY = C.CFUNCTYPE(C.c_int, C.c_void_p)
+_DRAW_BAND_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                             C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int)
 _CHAIN_BEGIN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p)
 _CHAIN_END = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int),
                          C.POINTER(C.c_ulonglong), C.POINTER(C.c_double))
@@ -56,7 +60,9 @@ class DrawBackend(C.Structure):            # mdns_draw_backend
                 # optional: the likelihood noise in band form (mdns.h Part 5)
                 ("draw_band", _DRAW_BAND), ("draw_band_commit", _DRAW_BAND_COMMIT),
                 # optional: the first batch of a region without a host look in between (mdns.h Part 5)
-                ("chain_begin", _CHAIN_BEGIN), ("chain_end", _CHAIN_END)]
+                ("chain_begin", _CHAIN_BEGIN), ("chain_end", _CHAIN_END),
+                # optional: draw_band in two halves, the noise bounds of the next chunk made in between
+                ("draw_band_begin", _DRAW_BAND_BEGIN), ("draw_band_ready", _DRAW_BAND_READY), ("draw_band_end", _DRAW_BAND_END)]
 
 
 class Prior(C.Structure):                  # mdns_prior
@@ -73,7 +79,7 @@ METRICS = {'none': 0, 'simplescaling': 1, 'truncatedscaling': 2}
 #: mdns_constrainer_stats (include/mdns.h)
 COUNTERS = ("draws", "chunks", "candidates", "pairs", "regions", "radii", "counts", "proposals", "inside", "tries",
             "ns_bootstrap", "ns_region", "ns_count", "ns_propose", "ns_transform", "ns_chunk", "ns_draw", "ns_jitter",
-            "chains", "chain_counts", "param_mismatch", "ns_chain", "band_pairs", "band_replays")
+            "chains", "chain_counts", "param_mismatch", "ns_chain", "band_pairs", "band_replays", "band_ahead")
 
 _HOST = None
 
@@ -187,6 +193,10 @@ def hip_backend(joint):
     if os.environ.get("MDNS_JITTER_BAND", "1") != "0" and not joint_kind_gauss(joint):
         be.draw_band = C.cast(lib.mdns_backend_draw_band, _DRAW_BAND)
         be.draw_band_commit = C.cast(lib.mdns_backend_draw_band_commit, _DRAW_BAND_COMMIT)
+        if os.environ.get("MDNS_BAND_AHEAD", "1") != "0":
+            be.draw_band_begin = C.cast(lib.mdns_backend_draw_band_begin, _DRAW_BAND_BEGIN)
+            be.draw_band_ready = C.cast(lib.mdns_backend_draw_band_ready, _DRAW_BAND_READY)
+            be.draw_band_end = C.cast(lib.mdns_backend_draw_band_end, _DRAW_BAND_END)
     if os.environ.get("MDNS_CHAIN", "1") != "0" and joint_kind_gauss(joint):
         be.chain_begin = C.cast(lib.mdns_backend_chain_begin, _CHAIN_BEGIN)
         be.chain_end = C.cast(lib.mdns_backend_chain_end, _CHAIN_END)
@@ -346,6 +356,25 @@ def python_backend(joint, member_set_factory=None):
             traceback.print_exc()
             return 1
 
+    # the two halves: nothing runs beside Python here, but the native side gets its chance to look ahead
+    # (MDNS_BAND_READY_AFTER looks at `ready` before the chunk counts as scored)
+    pending = {}
+
+    def draw_band_begin(_user, params_ptr, B, bound_ptr):
+        pending["params"] = numpy.ctypeslib.as_array(params_ptr, (B, joint_nparams(joint))).copy()
+        pending["bound"] = numpy.ctypeslib.as_array(bound_ptr, (B,)).copy()
+        pending["polls"] = int(os.environ.get("MDNS_BAND_READY_AFTER", "3"))
+        return 0
+
+    def draw_band_ready(_user):
+        pending["polls"] -= 1
+        return 1 if pending["polls"] < 0 else 0
+
+    def draw_band_end(user, status_ptr, npairs_ptr, pb_ptr, pk_ptr, pL_ptr, pthr_ptr, cap):
+        params, bound = pending.pop("params"), pending.pop("bound")
+        return draw_band(user, params.ctypes.data_as(C.POINTER(C.c_double)), len(params), bound.ctypes.data_as(C.POINTER(C.c_double)),
+                         status_ptr, npairs_ptr, pb_ptr, pk_ptr, pL_ptr, pthr_ptr, cap)
+
     def chunk_size(_user, offered, M, hint):
         return int(joint.chunk_size(offered, M, hint))
 
@@ -363,7 +392,12 @@ def python_backend(joint, member_set_factory=None):
     if hasattr(joint, "_threshold") and hasattr(joint, "score_params") and os.environ.get("MDNS_JITTER_BAND", "1") != "0":
         be.draw_band = _DRAW_BAND(draw_band)
         be.draw_band_commit = _DRAW_BAND_COMMIT(draw_band_commit)
-    be._keep = (region_create, region_destroy, region_count, draw_begin, draw_chunk, chunk_size, regions, joint, draw_band, draw_band_commit)
+        if os.environ.get("MDNS_BAND_AHEAD", "1") != "0":
+            be.draw_band_begin = _DRAW_BAND_BEGIN(draw_band_begin)
+            be.draw_band_ready = _DRAW_BAND_READY(draw_band_ready)
+            be.draw_band_end = _DRAW_BAND_END(draw_band_end)
+    be._keep = (region_create, region_destroy, region_count, draw_begin, draw_chunk, chunk_size, regions, joint, draw_band, draw_band_commit,
+                draw_band_begin, draw_band_ready, draw_band_end)
     return be
 
 

@@ -227,7 +227,9 @@ enum { N_DRAWS, N_CHUNKS, N_CANDIDATES, N_PAIRS, N_REGIONS, N_RADII, N_COUNTS, N
        // parameters were not bit for bit the host's (10**v: mdns_pow10.h); nanoseconds from chain_begin to chain_end
        N_CHAINS, N_CHAIN_COUNTS, N_PARAM_MISMATCH, T_CHAIN,
        // jitter in band form: pairs the device could not decide without their noise, candidates whose noise was replayed for them
-       N_BAND_PAIRS, N_BAND_REPLAYS, N_COUNTERS };
+       N_BAND_PAIRS, N_BAND_REPLAYS,
+       // candidates whose bound was ready before their chunk (made while the previous chunk was scored)
+       N_BAND_AHEAD, N_COUNTERS };
 
 inline long long now_ns()
 {
@@ -393,7 +395,7 @@ struct mdns_constrainer {
 	std::vector<double> chain_params;
 	int chain_nkept = -1;
 	// the band form of the likelihood jitter (band_chunk)
-	std::vector<struct BandSnap> band_snap;
+	std::shared_ptr<void> look;                // BandLook (band_chunk)
 	std::vector<double> band_bound, band_row, band_pL, band_pthr;
 	std::vector<int> band_status, band_pb, band_pk;
 	// likelihood jitter of a chunk and the stream's state after each candidate's share of it
@@ -943,23 +945,45 @@ void band_restore(MT *mt, const BandSnap &s)
 	g_gauss = s.gauss;
 }
 
-// 0: done (*accepted, fillbits, stream positioned); 1: failed; 2: not possible for this chunk (stream
-// back where it was: the caller draws the whole block)
-int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsigned long long *fillbits)
-{
-	mdns_constrainer *c = e.c;
-	const mdns_draw_backend *be = e.be;
-	const double sigma = e.prior->jitter_sigma;
-	MT *mt = e.mt;
-	const long long t0 = now_ns();
-	std::vector<BandSnap> &snap = c->band_snap;
-	snap.resize((size_t) B + 1);
-	c->band_bound.resize(B);
-	DoubleSource src(mt);
-	int has_gauss = g_has_gauss;
-	double gauss = g_gauss;
-	snap[0] = band_snap(src, has_gauss, gauss);
-	for (int b = 0; b < B; b++) {
+// The candidates of a batch take their noise from the stream one after the other, M deviates each, and
+// nothing else draws from it between two chunks of the same batch: the bound of a candidate depends on its
+// place behind the chunk's first one only.  So the bounds are made by a generator of their own that runs AHEAD
+// of the caller's: while a chunk is being scored it goes on with the candidates that follow in the batch, and
+// the next chunk -- if this one accepts nobody -- finds its bounds made.  The caller's stream is only ever
+// PUT to a remembered place (band_restore); what was looked at beyond it is dropped.
+struct BandLook {
+	bool valid = false;
+	int M = 0;
+	double sigma = 0.0;
+	MT own;                              // the generator that runs ahead
+	DoubleSource src;                    // ... in blocks
+	int has_gauss = 0;                   // numpy's cached second deviate behind the last candidate looked at
+	double gauss = 0.0;
+	size_t base = 0;                     // entries before `base` belong to chunks that are done
+	std::vector<BandSnap> snap;          // snap[base + i]: the stream before candidate i; one more than bounds
+	std::vector<double> bound;           // bound[base + i]
+	MT expect;                           // the caller's stream where candidate 0 starts: what it must still be
+	int expect_has = 0;
+	double expect_gauss = 0.0;
+	BandLook() : src(&own) {}
+	size_t count() const { return bound.size() - base; }
+	void reset(const MT *mt, int M_, double sigma_)
+	{
+		own = *mt;
+		src = DoubleSource(&own);
+		has_gauss = g_has_gauss; gauss = g_gauss;
+		snap.clear(); bound.clear(); base = 0;
+		snap.push_back(band_snap(src, has_gauss, gauss));
+		M = M_; sigma = sigma_;
+	}
+	bool matches(const MT *mt, int M_, double sigma_) const
+	{
+		return valid && M == M_ && sigma == sigma_ && expect_has == g_has_gauss &&
+		       (!expect_has || memcmp(&expect_gauss, &g_gauss, sizeof(double)) == 0) && memcmp(&expect, mt, sizeof(MT)) == 0;
+	}
+	// one more candidate: M deviates further, the largest of them bounded from the smallest r2 of its pairs
+	void advance()
+	{
 		double minr2 = 2.0, cached_abs = 0.0;
 		int need = M;
 		if (has_gauss && need > 0) { cached_abs = std::fabs(gauss); has_gauss = 0; gauss = 0.0; need--; }
@@ -998,17 +1022,43 @@ int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsign
 		}
 		double most = cached_abs;
 		if (minr2 < 2.0) { const double g = std::sqrt(-2.0 * std::log(minr2)); if (g > most) most = g; }
-		c->band_bound[b] = sigma * most;
-		snap[(size_t) b + 1] = band_snap(src, has_gauss, gauss);
+		bound.push_back(sigma * most);
+		snap.push_back(band_snap(src, has_gauss, gauss));
 	}
+};
+
+// 0: done (*accepted, fillbits, stream positioned); 1: failed; 2: not possible for this chunk (stream
+// back where it was: the caller draws the whole block)
+int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsigned long long *fillbits)
+{
+	mdns_constrainer *c = e.c;
+	const mdns_draw_backend *be = e.be;
+	const double sigma = e.prior->jitter_sigma;
+	MT *mt = e.mt;
+	const long long t0 = now_ns();
+	if (!c->look) c->look = std::make_shared<BandLook>();
+	BandLook &L = *static_cast<BandLook *>(c->look.get());
+	if (L.matches(mt, M, sigma)) c->stat.add(N_BAND_AHEAD, (long long) (L.count() < (size_t) B ? L.count() : (size_t) B));
+	else L.reset(mt, M, sigma);
+	L.valid = false;                                    // (until this chunk ends without an accepted candidate)
+	while (L.count() < (size_t) B) L.advance();
 	const long long t_band = now_ns();
 	c->stat.add(T_JITTER, t_band - t0);
 	const int cap = 4096;
 	c->band_status.resize(B);
 	c->band_pb.resize(cap); c->band_pk.resize(cap); c->band_pL.resize(cap); c->band_pthr.resize(cap);
 	int npairs = 0;
-	if (be->draw_band(be->user, params, B, c->band_bound.data(), c->band_status.data(), &npairs, c->band_pb.data(), c->band_pk.data(),
-	                  c->band_pL.data(), c->band_pthr.data(), cap) != 0) { set_error("draw_band failed"); return 1; }
+	if (be->draw_band_begin && be->draw_band_ready && be->draw_band_end) {
+		if (be->draw_band_begin(be->user, params, B, &L.bound[L.base]) != 0) { set_error("draw_band failed"); return 1; }
+		// what follows in the batch (the next chunk starts there if this one accepts nobody)
+		long long ahead = (long long) c->buf_n - c->buf_pos - B;
+		if (ahead > 2048) ahead = 2048;
+		while ((long long) L.count() < B + ahead && !be->draw_band_ready(be->user)) L.advance();
+		if (be->draw_band_end(be->user, c->band_status.data(), &npairs, c->band_pb.data(), c->band_pk.data(), c->band_pL.data(),
+		                      c->band_pthr.data(), cap) != 0) { set_error("draw_band failed"); return 1; }
+	} else if (be->draw_band(be->user, params, B, &L.bound[L.base], c->band_status.data(), &npairs, c->band_pb.data(), c->band_pk.data(),
+	                         c->band_pL.data(), c->band_pthr.data(), cap) != 0) { set_error("draw_band failed"); return 1; }
+	const BandSnap *snap = &L.snap[L.base];
 	if (npairs > cap) { band_restore(mt, snap[0]); return 2; }
 	const long long t1 = now_ns();
 	c->stat.add(T_CHUNK, t1 - t_band);
@@ -1041,7 +1091,20 @@ int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsign
 		replay(bstar);
 		if (be->draw_band_commit(be->user, bstar, c->band_row.data(), fillbits) != 0) { set_error("draw_band_commit failed"); return 1; }
 		band_restore(mt, snap[(size_t) bstar + 1]);
-	} else band_restore(mt, snap[B]);
+	} else {
+		band_restore(mt, snap[B]);
+		// the candidates looked at beyond this chunk stay, for a chunk that starts exactly here
+		L.base += (size_t) B;
+		if (L.count() == 0 || L.base > 8192) {
+			L.snap.erase(L.snap.begin(), L.snap.begin() + (long) L.base);
+			L.bound.erase(L.bound.begin(), L.bound.begin() + (long) L.base);
+			L.base = 0;
+		}
+		L.expect = *mt;
+		L.expect_has = g_has_gauss;
+		L.expect_gauss = g_gauss;
+		L.valid = true;
+	}
 	c->stat.add(T_JITTER, now_ns() - t1);
 	*accepted = bstar;
 	return 0;

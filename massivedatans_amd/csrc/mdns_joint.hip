@@ -507,6 +507,7 @@ struct mdns_joint {
 	double *d_bound = nullptr;                // [MDNS_JOINT_MAX_BATCH] bounds, then room for one noise row [ndata]
 	unsigned long long band_seq = 0;
 	int band_B = 0;
+	bool band_pending = false;        // a chunk begun and not collected (mdns_backend_draw_band_begin / _end)
 	bool band_exact = true;           // d_dense holds the exact likelihoods of the chunk (not the matrix-core filter's)
 	// a chunk in two halves (mdns_backend_draw_score / _commit): one 0 / 1 vote per candidate, what the ranks
 	// of a sharded run MAX-reduce in between
@@ -1614,14 +1615,44 @@ extern "C" int mdns_backend_draw_commit(void *joint, int *accepted, unsigned lon
 // ---------------------------------------------------------------------------------------
 // the likelihood noise in band form (mdns.h Part 5: draw_band / draw_band_commit)
 // ---------------------------------------------------------------------------------------
-extern "C" int mdns_backend_draw_band(void *joint, const double *params, int B, const double *bound, int *status, int *npairs,
-                                      int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap)
+// candidates and their bounds travel as ONE block [B x 5 | B] into the head of d_bound; the noise row of a
+// commit lives behind it
+static constexpr size_t kBandRowAt = (size_t) MDNS_JOINT_MAX_BATCH * 6;
+
+// launches of one scoring of the chunk in place (by the matrix-core filter or by the exact kernels)
+static int band_launch(mdns_joint *j, bool filtered)
+{
+	Context *c = ctx();
+	const int B = j->band_B, M = j->sel_M;
+	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
+	const double *d_p = j->d_bound, *d_b = j->d_bound + (size_t) B * 5;
+	if (filtered) {
+		const int ldm = model_ld(j->s->nx);
+		if (!ensure_model(j->s, (size_t) B * ldm) || !launch_muse3_model(j->s->d_x, j->s->nx, d_p, B, j->s->d_model, ldm)) return 1;
+		const MuseBandOut out = {&j->d_band->counter, j->d_band->clear, j->d_band->maybe, j->d_band->pair_b, j->d_band->pair_k,
+		                         j->d_band->pair_L, j->d_band->pair_thr, kBandCap, &((JointHeader *) j->d_result)->status};
+		if (!launch_muse_filter(j->s, j->s->d_model, ldm, B, d_rows, M, j->st.higher, d_b, out)) return 1;
+	} else {
+		if (mdns_muse3_loglike_batch_dev(j->s, d_p, B, d_rows, M, j->d_dense) != 0) return 1;
+		hipLaunchKernelGGL(k_joint_band, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream, (const double *) j->d_dense,
+		                   d_b, B, M, d_rows, (const double *) j->st.higher, j->d_band, (JointHeader *) j->d_result);
+	}
+	hipLaunchKernelGGL(k_joint_band_publish, dim3(1), dim3(kBlock), 0, c->stream, j->d_band, B, j->h_band_dev, ++j->band_seq);
+	if (!MDNS_HIP(hipGetLastError())) return 1;
+	j->band_exact = !filtered;
+	return 0;
+}
+
+// the chunk is on its way when this returns; mdns_backend_draw_band_ready tells whether its outcome has
+// arrived (a look at mapped memory), mdns_backend_draw_band_end waits for it and hands it over
+extern "C" int mdns_backend_draw_band_begin(void *joint, const double *params, int B, const double *bound)
 {
 	Context *c = ctx();
 	mdns_joint *j = (mdns_joint *) joint;
-	if (!c || !j || !params || !bound || !status || !npairs || !pair_b || !pair_k || !pair_L || !pair_thr) { set_error("mdns_backend_draw_band: null argument"); return 1; }
+	if (!c || !j || !params || !bound) { set_error("mdns_backend_draw_band: null argument"); return 1; }
 	if (j->kind != 1) { set_error("mdns_backend_draw_band: a state of the scale-marginalised likelihood is needed"); return 1; }
 	if (!j->sel_open) { set_error("mdns_backend_draw_band: no draw begun"); return 1; }
+	if (j->band_pending) { set_error("mdns_backend_draw_band_begin: the last chunk was not collected"); return 1; }
 	const int M = j->sel_M;
 	if (!check_draw(j, B, M, "mdns_backend_draw_band") || B == 0 || M == 0) return 1;
 	if (!j->h_band) {
@@ -1629,45 +1660,48 @@ extern "C" int mdns_backend_draw_band(void *joint, const double *params, int B, 
 		    !MDNS_HIP(hipHostGetDevicePointer((void **) &j->h_band_dev, j->h_band, 0)) ||
 		    !MDNS_HIP(hipMalloc((void **) &j->d_band, sizeof(BandScratch))) ||
 		    !MDNS_HIP(hipMemsetAsync(j->d_band, 0, sizeof(BandScratch), c->stream)) ||
-		    !MDNS_HIP(hipMalloc((void **) &j->d_bound, ((size_t) MDNS_JOINT_MAX_BATCH + j->ndata) * sizeof(double)))) return 1;
+		    !MDNS_HIP(hipMalloc((void **) &j->d_bound, (kBandRowAt + j->ndata) * sizeof(double)))) return 1;
 		memset(j->h_band, 0, sizeof(BandBox));
 	}
 	if (j->shelf_bound + 1 > j->cap && mdns_joint_reserve(j, j->shelf_bound + 1) != 0) return 1;
-	// candidates and their bounds: one pinned block, two small copies
 	const size_t pbytes = (size_t) B * 5 * sizeof(double), bbytes = (size_t) B * sizeof(double), n = (size_t) B * M;
 	char *pin = joint_pin(j, pbytes + bbytes);
 	if (!pin) return 1;
 	memcpy(pin, params, pbytes);
 	memcpy(pin + pbytes, bound, bbytes);
-	if (!MDNS_HIP(hipMemcpyAsync(j->d_params, pin, pbytes, hipMemcpyHostToDevice, c->stream)) ||
-	    !MDNS_HIP(hipMemcpyAsync(j->d_bound, pin + pbytes, bbytes, hipMemcpyHostToDevice, c->stream))) return 1;
+	if (!MDNS_HIP(hipMemcpyAsync(j->d_bound, pin, pbytes + bbytes, hipMemcpyHostToDevice, c->stream))) return 1;
 	if (j->sel_rows && !j->sel_on_device) {
 		if (!MDNS_HIP(hipMemcpyAsync(j->d_sel_rows, j->h_in + kInParams, (size_t) M * sizeof(int), hipMemcpyHostToDevice, c->stream))) return 1;
 		j->sel_on_device = true;
 	}
-	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
 	if (!joint_grow(&j->d_dense, &j->dense_cap, n)) return 1;
+	j->band_B = B;
+	j->trail_valid = false;
+	j->last_B = 0;
 	// Large chunks first as two matrix products with a widened band (mdns_k2gemm.hip): whatever that settles
-	// is settled as the exact kernels would; a chunk it lists a pair of is scored again by those.
-	const int ldm = model_ld(j->s->nx);
-	bool filtered = muse_filter_applies(j->s, B, M);
+	// is settled as the exact kernels would; a chunk it lists a pair of is scored again by those (_end).
+	if (band_launch(j, muse_filter_applies(j->s, B, M)) != 0) { j->band_B = 0; return 1; }
+	j->band_pending = true;
+	return 0;
+}
+
+extern "C" int mdns_backend_draw_band_ready(void *joint)
+{
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!j || !j->band_pending || !j->h_band) return 1;
+	return *(volatile unsigned long long *) &j->h_band->seq == j->band_seq ? 1 : 0;
+}
+
+extern "C" int mdns_backend_draw_band_end(void *joint, int *status, int *npairs, int *pair_b, int *pair_k, double *pair_L, double *pair_thr,
+                                          int cap)
+{
+	Context *c = ctx();
+	mdns_joint *j = (mdns_joint *) joint;
+	if (!c || !j || !status || !npairs || !pair_b || !pair_k || !pair_L || !pair_thr) { set_error("mdns_backend_draw_band: null argument"); return 1; }
+	if (!j->band_pending) { set_error("mdns_backend_draw_band_end: no chunk begun"); return 1; }
+	j->band_pending = false;
+	const int B = j->band_B;
 	for (;;) {
-		if (filtered) {
-			if (!ensure_model(j->s, (size_t) B * ldm) || !launch_muse3_model(j->s->d_x, j->s->nx, j->d_params, B, j->s->d_model, ldm)) return 1;
-			const MuseBandOut out = {&j->d_band->counter, j->d_band->clear, j->d_band->maybe, j->d_band->pair_b, j->d_band->pair_k,
-			                         j->d_band->pair_L, j->d_band->pair_thr, kBandCap, &((JointHeader *) j->d_result)->status};
-			if (!launch_muse_filter(j->s, j->s->d_model, ldm, B, d_rows, M, j->st.higher, j->d_bound, out)) return 1;
-		} else {
-			if (mdns_muse3_loglike_batch_dev(j->s, j->d_params, B, d_rows, M, j->d_dense) != 0) return 1;
-			hipLaunchKernelGGL(k_joint_band, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream, (const double *) j->d_dense,
-			                   (const double *) j->d_bound, B, M, d_rows, (const double *) j->st.higher, j->d_band, (JointHeader *) j->d_result);
-		}
-		hipLaunchKernelGGL(k_joint_band_publish, dim3(1), dim3(kBlock), 0, c->stream, j->d_band, B, j->h_band_dev, ++j->band_seq);
-		if (!MDNS_HIP(hipGetLastError())) return 1;
-		j->band_B = B;
-		j->band_exact = !filtered;
-		j->trail_valid = false;
-		j->last_B = 0;
 		volatile unsigned long long *at = &j->h_band->seq;
 		long long started = 0;
 		for (unsigned spin = 0; *at != j->band_seq; spin++) {
@@ -1681,9 +1715,9 @@ extern "C" int mdns_backend_draw_band(void *joint, const double *params, int B, 
 			if (*at != j->band_seq) { set_error("mdns_backend_draw_band: finished without an outcome"); return 1; }
 		}
 		std::atomic_thread_fence(std::memory_order_acquire);
-		if (!filtered || j->h_band->npairs == 0) break;
-		filtered = false;
+		if (j->band_exact || j->h_band->npairs == 0) break;
 		muse_filter_note(1);
+		if (band_launch(j, false) != 0) return 1;
 	}
 	memcpy(status, (const void *) j->h_band->status, (size_t) B * sizeof(int));
 	*npairs = j->h_band->npairs;
@@ -1694,6 +1728,13 @@ extern "C" int mdns_backend_draw_band(void *joint, const double *params, int B, 
 	memcpy(pair_L, (const void *) j->h_band->pair_L, (size_t) m * sizeof(double));
 	memcpy(pair_thr, (const void *) j->h_band->pair_thr, (size_t) m * sizeof(double));
 	return 0;
+}
+
+extern "C" int mdns_backend_draw_band(void *joint, const double *params, int B, const double *bound, int *status, int *npairs,
+                                      int *pair_b, int *pair_k, double *pair_L, double *pair_thr, int cap)
+{
+	if (mdns_backend_draw_band_begin(joint, params, B, bound) != 0) return 1;
+	return mdns_backend_draw_band_end(joint, status, npairs, pair_b, pair_k, pair_L, pair_thr, cap);
 }
 
 extern "C" int mdns_backend_draw_band_commit(void *joint, int b, const double *jitter_row, unsigned long long *fillbits)
@@ -1715,7 +1756,7 @@ extern "C" int mdns_backend_draw_band_commit(void *joint, int b, const double *j
 		muse_filter_note(2);
 	}
 	j->band_B = 0;
-	double *d_row = j->d_bound + MDNS_JOINT_MAX_BATCH;
+	double *d_row = j->d_bound + kBandRowAt;
 	char *pin = joint_pin(j, (size_t) M * sizeof(double));
 	if (!pin) return 1;
 	memcpy(pin, jitter_row, (size_t) M * sizeof(double));

@@ -34,7 +34,7 @@ def _run(g, backend, fused, native, jitter=True):
 
 
 @pytest.mark.parametrize("case", ["muse6", "muse10_graph"])
-@pytest.mark.parametrize("mode", ["single", "native", "native-block"])
+@pytest.mark.parametrize("mode", ["single", "native", "native-block", "native-far-ahead", "native-not-ahead"])
 def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
     """``single``: one candidate per likelihood call, the noise from numpy.random.normal -- the
     reference's loop.  ``native``: whole chunks, the noise drawn in C from numpy's own Mersenne
@@ -49,6 +49,17 @@ def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
         if case != "muse6":
             pytest.skip("the block form on the short trace only")
         monkeypatch.setenv("MDNS_JITTER_BAND", "0")
+        mode = "native"
+    ahead = None
+    if mode in ("native-far-ahead", "native-not-ahead"):
+        # the bounds of the candidates that follow a chunk in its batch are made while the chunk is scored
+        # (band_chunk, BandLook): as far as the batch goes / not at all -- the same trace either way
+        if case != "muse6":
+            pytest.skip("on the short trace only")
+        ahead = mode == "native-far-ahead"
+        monkeypatch.setenv("MDNS_BAND_READY_AFTER", "100000" if ahead else "0")
+        if not ahead:
+            monkeypatch.setenv("MDNS_BAND_AHEAD", "0")
         mode = "native"
     if mode == "native":
         from massivedatans_amd import constrainer
@@ -67,6 +78,8 @@ def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
         import os
         st = sampler.native.stats()
         assert (st["band_pairs"] + st["band_replays"] > 0) == (os.environ.get("MDNS_JITTER_BAND", "1") != "0") or st["band_pairs"] == 0
+        if os.environ.get("MDNS_JITTER_BAND", "1") != "0":
+            assert (st["band_ahead"] > 0) == (ahead is not False), st
 
 
 @pytest.mark.gpu
