@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <memory>
 #include <time.h>
 #include <vector>
@@ -147,6 +148,128 @@ inline double legacy_gauss(MT *s)
 	g_gauss = f * x1;
 	g_has_gauss = 1;
 	return f * x2;
+}
+
+// ---- the double stream in blocks, with what the polar method makes of their pairs -------------
+// numpy's legacy Gaussian takes the doubles two at a time, (x1, x2) = 2 u - 1, and rejects the pair unless
+// 0 < r2 = x1^2 + x2^2 < 1: which pairs of a block survive, and their r2, are flat loops over the block.
+enum { kBlockDoubles = 1024, kBlockPairs = kBlockDoubles / 2 };
+
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+void pairs_r2(const double *buf, double *r2, int npairs)
+{
+	for (int p = 0; p < npairs; p++) {
+		const double x1 = 2.0 * buf[2 * p] - 1.0, x2 = 2.0 * buf[2 * p + 1] - 1.0;
+		const double v = x1 * x1 + x2 * x2;
+		r2[p] = (v >= 1.0 || v == 0.0) ? 3.0 : v;           // 3: rejected (no minimum takes it)
+	}
+}
+
+// (a loop of its own: with the byte store in the loop above the compiler gives up its wide form)
+#if defined(__x86_64__) && defined(__GNUC__)
+__attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+void pairs_ok(const double *r2, uint8_t *ok, int npairs)
+{
+	for (int p = 0; p < npairs; p++) ok[p] = r2[p] < 1.5;
+}
+
+struct DoubleSource {
+	MT *mt;
+	MT start;                    // the state the buffered block was made from
+	double buf[kBlockDoubles];
+	double r2[kBlockPairs];      // of the block's pairs: x1^2 + x2^2, or 3 where the pair is rejected
+	alignas(8) uint8_t ok[kBlockPairs];          // 1: accepted
+	uint16_t cum8[kBlockPairs / 8 + 1];          // pairs accepted before group g of eight
+	int pos = 0;                 // doubles consumed of the block (always even: they go in pairs)
+	bool filled = false;
+	explicit DoubleSource(MT *m) : mt(m), start(*m) {}
+	uint64_t group(int g) const { uint64_t w; memcpy(&w, ok + 8 * g, 8); return w; }
+	void refill()
+	{
+		start = *mt;
+		mt_fill_doubles(mt, buf, kBlockDoubles);
+		pos = 0;
+		filled = true;
+		pairs_r2(buf, r2, kBlockPairs);
+		pairs_ok(r2, ok, kBlockPairs);
+		unsigned n = 0;
+		for (int g = 0; g < kBlockPairs / 8; g++) { cum8[g] = (uint16_t) n; n += (unsigned) __builtin_popcountll(group(g)); }
+		cum8[kBlockPairs / 8] = (uint16_t) n;
+	}
+	int total() const { return cum8[kBlockPairs / 8]; }
+	// pairs accepted before pair p
+	int before(int p) const
+	{
+		if (p >= kBlockPairs) return total();
+		const int k = p & 7;
+		return cum8[p >> 3] + (k ? __builtin_popcountll(group(p >> 3) & ((1ull << (8 * k)) - 1)) : 0);
+	}
+	// smallest pe with `pairs` (>= 1) accepted pairs in [p, pe)  (there are that many)
+	int end_of(int p, int pairs) const
+	{
+		const unsigned target = (unsigned) before(p) + (unsigned) pairs;
+		int lo = (p >> 3) + 1, hi = kBlockPairs / 8;             // first group boundary g with cum8[g] >= target
+		while (lo < hi) {
+			const int mid = (lo + hi) >> 1;
+			if (cum8[mid] >= target) hi = mid; else lo = mid + 1;
+		}
+		const int g = lo - 1;
+		unsigned n = cum8[g];
+		for (int j = 0; j < 8; j++) { n += ok[8 * g + j]; if (n >= target) return 8 * g + j + 1; }
+		return 8 * g + 8;
+	}
+	double min_r2(int p, int pe, double m) const
+	{
+		double a = m, b = m, c = m, d = m;
+		int i = p;
+		for (; i + 4 <= pe; i += 4) {
+			a = r2[i] < a ? r2[i] : a; b = r2[i + 1] < b ? r2[i + 1] : b;
+			c = r2[i + 2] < c ? r2[i + 2] : c; d = r2[i + 3] < d ? r2[i + 3] : d;
+		}
+		for (; i < pe; i++) a = r2[i] < a ? r2[i] : a;
+		a = b < a ? b : a; c = d < c ? d : c;
+		return c < a ? c : a;
+	}
+};
+
+// the stream `pos` doubles behind `start`
+void mt_place(MT *mt, const MT &start, int pos)
+{
+	*mt = start;
+	if (pos > 0) { double skip[kBlockDoubles]; mt_fill_doubles(mt, skip, (size_t) pos); }
+}
+
+// out[i] = legacy_gauss(s), i = 0 .. n-1: the same numbers, the same cache and the same place in the stream
+// afterwards.  Pairs are tested a block at a time, the logarithms and roots of the accepted ones follow in a
+// flat loop (glibc's scalar log, as numpy calls it).
+void gauss_fill(MT *s, double *out, size_t n)
+{
+	size_t i = 0;
+	if (n < 48) { for (; i < n; i++) out[i] = legacy_gauss(s); return; }
+	if (g_has_gauss) { out[i++] = g_gauss; g_has_gauss = 0; g_gauss = 0.0; }
+	DoubleSource src(s);
+	int idx[kBlockPairs];
+	double f[kBlockPairs];
+	while (i < n) {
+		src.refill();
+		const size_t want = (n - i + 1) / 2;                  // accepted pairs still needed
+		const int have = src.total();
+		const int take = (size_t) have < want ? have : (int) want;
+		const int pe = (size_t) have < want ? kBlockPairs : src.end_of(0, take);   // (ends BEHIND its last accepted pair)
+		int k = 0;
+		for (int p = 0; p < pe; p++) { idx[k] = p; k += src.ok[p]; }
+		for (int t = 0; t < take; t++) { const double r2 = src.r2[idx[t]]; f[t] = std::sqrt(-2.0 * std::log(r2) / r2); }
+		for (int t = 0; t < take; t++) {
+			const double x1 = 2.0 * src.buf[2 * idx[t]] - 1.0, x2 = 2.0 * src.buf[2 * idx[t] + 1] - 1.0;
+			out[i++] = f[t] * x2;
+			if (i < n) out[i++] = f[t] * x1;
+			else { g_gauss = f[t] * x1; g_has_gauss = 1; }
+		}
+		if (pe < kBlockPairs) mt_place(s, src.start, 2 * pe);
+	}
 }
 
 // RandomState.randint(0, K, size=n) (random_bounded_uint64_fill, masked rejection, 32-bit draws)
@@ -348,7 +471,6 @@ typedef std::shared_ptr<Region> RegionRef;
 // ---------------------------------------------------------------------------------------
 // the constrainer (hiermetriclearn.py)
 // ---------------------------------------------------------------------------------------
-namespace { struct BandSnap; }
 struct mdns_constrainer {
 	int ndim = 0;
 	int metriclearner = MDNS_METRIC_TRUNCATEDSCALING;
@@ -380,7 +502,7 @@ struct mdns_constrainer {
 	bool has_buf = false;
 	Counters stat;
 	// scratch
-	std::vector<double> us, ws, dir, rad, coin, xs, params, wtmp;
+	std::vector<double> us, ws, dir, rad, coin, coins, xs, params, wtmp;
 	std::vector<int32_t> idx;
 	std::vector<int> counts;
 	// the draw in progress (what the chained first batch needs to know of the accept loop's state)
@@ -774,8 +896,9 @@ bool next_batch_inner(Env &e)
 			c->stat.add(N_PROPOSALS, N);
 			// direction = normal(0, 1, (N, ndim)); direction / sqrt((direction ** 2).sum(axis=1))
 			c->dir.resize((size_t) N * ndim);
+			gauss_fill(e.mt, c->dir.data(), (size_t) N * ndim);
 			for (size_t t = 0; t < (size_t) N * ndim; t++) {
-				const double g = 1.0 * legacy_gauss(e.mt);
+				const double g = 1.0 * c->dir[t];
 				c->dir[t] = 0.0 + g;
 			}
 			double sq[MDNS_MAX_DIM];
@@ -788,8 +911,9 @@ bool next_batch_inner(Env &e)
 			}
 			// radius = maxdistance * uniform(0, 1, (N, 1)) ** (1. / ndim)
 			c->rad.resize(N);
+			mt_fill_doubles(e.mt, c->rad.data(), (size_t) N);
 			for (int i = 0; i < N; i++) {
-				const double t = 1.0 * mt_double(e.mt);
+				const double t = 1.0 * c->rad[i];
 				c->rad[i] = 0.0 + t;
 			}
 			// numpy's scalar-exponent fast paths: ** 1.0 leaves the values, ** 0.5 is sqrt
@@ -814,8 +938,10 @@ bool next_batch_inner(Env &e)
 			// accept = uniform(size=N) < 1. / nnear
 			c->ws.clear();
 			int n = 0;
+			c->coins.resize(N);
+			mt_fill_doubles(e.mt, c->coins.data(), (size_t) N);
 			for (int i = 0; i < N; i++) {
-				const double t = 1.0 * mt_double(e.mt);
+				const double t = 1.0 * c->coins[i];
 				const double coin = 0.0 + t;
 				const double inv = 1. / (double) c->counts[i];          // 1/0 = inf: accepted (never occurs: the centre is within reach)
 				if (coin < inv) {
@@ -842,8 +968,9 @@ bool next_batch_inner(Env &e)
 				c->ntotal = c->ntotal + NN;
 				c->stat.add(N_PROPOSALS, NN);
 				c->us.resize((size_t) NN * ndim);
+				mt_fill_doubles(e.mt, c->us.data(), (size_t) NN * ndim);
 				for (size_t q = 0; q < (size_t) NN * ndim; q++) {
-					const double v = 1.0 * mt_double(e.mt);
+					const double v = 1.0 * c->us[q];
 					c->us[q] = 0.0 + v;
 				}
 				if (!c->region) { set_error("the constrainer's region was dropped while its generator is in use"); return false; }
@@ -903,47 +1030,8 @@ void transform(const mdns_prior *p, const double *us, int B, double *xs, double 
 // legacy_gauss itself, only for candidates with listed pairs and for the accepted candidate's row,
 // which is what the state keeps (draw_band_commit).  Decisions, kept values and the position of the
 // stream are those of the deviate-per-evaluation path (tests/test_muse.py on the reference's traces).
-struct DoubleSource {
-	MT *mt;
-	MT start;                    // the state the buffered block was made from
-	double buf[256];
-	double r2[128];              // of the block's 128 pairs (x1, x2) = 2 u - 1: x1^2 + x2^2, or 3 where the pair is rejected
-	int pos = 0;                 // doubles consumed of the block (always even: they go in pairs)
-	bool filled = false;
-	explicit DoubleSource(MT *m) : mt(m), start(*m) {}
-	void refill()
-	{
-		start = *mt;
-		mt_fill_doubles(mt, buf, 256);
-		pos = 0;
-		filled = true;
-		for (int p = 0; p < 128; p++) {                 // (a flat loop the compiler vectorises)
-			const double x1 = 2.0 * buf[2 * p] - 1.0, x2 = 2.0 * buf[2 * p + 1] - 1.0;
-			const double v = x1 * x1 + x2 * x2;
-			r2[p] = (v >= 1.0 || v == 0.0) ? 3.0 : v;
-		}
-	}
-};
-
-struct BandSnap { MT start; int pos; int has_gauss; double gauss; };
-
-inline BandSnap band_snap(const DoubleSource &src, int has_gauss, double gauss)
-{
-	BandSnap s;
-	s.start = src.start;
-	s.pos = src.filled ? src.pos : 0;
-	s.has_gauss = has_gauss;
-	s.gauss = gauss;
-	return s;
-}
-
-void band_restore(MT *mt, const BandSnap &s)
-{
-	*mt = s.start;
-	if (s.pos > 0) { double skip[256]; mt_fill_doubles(mt, skip, (size_t) s.pos); }
-	g_has_gauss = s.has_gauss;
-	g_gauss = s.gauss;
-}
+// a place in the stream: `pos` doubles into block `block` of a BandLook, with numpy's cached deviate
+struct BandSnap { long long block; int pos; int has_gauss; double gauss; };
 
 // The candidates of a batch take their noise from the stream one after the other, M deviates each, and
 // nothing else draws from it between two chunks of the same batch: the bound of a candidate depends on its
@@ -960,6 +1048,8 @@ struct BandLook {
 	int has_gauss = 0;                   // numpy's cached second deviate behind the last candidate looked at
 	double gauss = 0.0;
 	size_t base = 0;                     // entries before `base` belong to chunks that are done
+	std::deque<MT> blocks;               // the generator at the start of the blocks it has made: number block_first onwards
+	long long block_first = 0;
 	std::vector<BandSnap> snap;          // snap[base + i]: the stream before candidate i; one more than bounds
 	std::vector<double> bound;           // bound[base + i]
 	MT expect;                           // the caller's stream where candidate 0 starts: what it must still be
@@ -972,9 +1062,28 @@ struct BandLook {
 		own = *mt;
 		src = DoubleSource(&own);
 		has_gauss = g_has_gauss; gauss = g_gauss;
-		snap.clear(); bound.clear(); base = 0;
-		snap.push_back(band_snap(src, has_gauss, gauss));
+		snap.clear(); bound.clear(); blocks.clear(); base = 0; block_first = 0;
+		blocks.push_back(own);
+		snap.push_back(here());
 		M = M_; sigma = sigma_;
+	}
+	BandSnap here() const { return BandSnap{block_first + (long long) blocks.size() - 1, src.filled ? src.pos : 0, has_gauss, gauss}; }
+	// the caller's stream (and numpy's cache) at a remembered place
+	void restore(MT *mt, const BandSnap &at) const
+	{
+		mt_place(mt, blocks[(size_t) (at.block - block_first)], at.pos);
+		g_has_gauss = at.has_gauss;
+		g_gauss = at.gauss;
+	}
+	// forget what lies before snap[base]
+	void compact()
+	{
+		while (block_first < snap[base].block) { blocks.pop_front(); block_first++; }
+		if (count() == 0 || base > 8192) {
+			snap.erase(snap.begin(), snap.begin() + (long) base);
+			bound.erase(bound.begin(), bound.begin() + (long) base);
+			base = 0;
+		}
 	}
 	bool matches(const MT *mt, int M_, double sigma_) const
 	{
@@ -982,48 +1091,36 @@ struct BandLook {
 		       (!expect_has || memcmp(&expect_gauss, &g_gauss, sizeof(double)) == 0) && memcmp(&expect, mt, sizeof(MT)) == 0;
 	}
 	// one more candidate: M deviates further, the largest of them bounded from the smallest r2 of its pairs
+	// (an accepted pair gives two deviates, f x2 and then, from the cache, f x1)
 	void advance()
 	{
 		double minr2 = 2.0, cached_abs = 0.0;
 		int need = M;
 		if (has_gauss && need > 0) { cached_abs = std::fabs(gauss); has_gauss = 0; gauss = 0.0; need--; }
-		while (need > 0) {
-			if (!src.filled || src.pos == 256) src.refill();
-			int p = src.pos >> 1;
-			// whole groups of eight pairs while they cannot finish the candidate: no branch per pair (rejected
-			// pairs carry r2 = 3, which no minimum takes), the compiler vectorises the two reductions
-			while (p + 8 <= 128 && need > 16) {
-				int ok = 0;
-				double m = minr2;
-				for (int t = 0; t < 8; t++) {
-					const double r2 = src.r2[p + t];
-					ok += r2 < 1.5 ? 1 : 0;
-					m = r2 < m ? r2 : m;
-				}
-				minr2 = m;
-				need -= 2 * ok;
-				p += 8;
+		const bool odd = need & 1;
+		int pairs = (need + 1) / 2;
+		while (pairs > 0) {
+			if (!src.filled || src.pos == kBlockDoubles) { src.refill(); blocks.push_back(src.start); }
+			const int p = src.pos >> 1;
+			const int avail = src.total() - src.before(p);
+			int pe = kBlockPairs;
+			if (avail < pairs) pairs -= avail;
+			else { pe = src.end_of(p, pairs); pairs = 0; }
+			minr2 = src.min_r2(p, pe, minr2);
+			src.pos = 2 * pe;
+			if (pairs == 0 && odd) {
+				// the last pair's other deviate waits in the cache beyond this candidate: its value is needed
+				const double r2 = src.r2[pe - 1];
+				const double x1 = 2.0 * src.buf[2 * (pe - 1)] - 1.0;
+				const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+				gauss = f * x1;
+				has_gauss = 1;
 			}
-			for (; p < 128 && need > 0; p++) {
-				const double r2 = src.r2[p];
-				if (r2 > 1.5) continue;                         // rejected pair (legacy_gauss: r2 >= 1 or r2 == 0)
-				if (r2 < minr2) minr2 = r2;
-				need--;                                          // f x2
-				if (need > 0) need--;                            // f x1, from the cache
-				else {
-					// the pair's other deviate waits in the cache beyond this candidate: its value is needed
-					const double x1 = 2.0 * src.buf[2 * p] - 1.0;
-					const double f = std::sqrt(-2.0 * std::log(r2) / r2);
-					gauss = f * x1;
-					has_gauss = 1;
-				}
-			}
-			src.pos = 2 * p;
 		}
 		double most = cached_abs;
 		if (minr2 < 2.0) { const double g = std::sqrt(-2.0 * std::log(minr2)); if (g > most) most = g; }
 		bound.push_back(sigma * most);
-		snap.push_back(band_snap(src, has_gauss, gauss));
+		snap.push_back(here());
 	}
 };
 
@@ -1059,15 +1156,16 @@ int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsign
 	} else if (be->draw_band(be->user, params, B, &L.bound[L.base], c->band_status.data(), &npairs, c->band_pb.data(), c->band_pk.data(),
 	                         c->band_pL.data(), c->band_pthr.data(), cap) != 0) { set_error("draw_band failed"); return 1; }
 	const BandSnap *snap = &L.snap[L.base];
-	if (npairs > cap) { band_restore(mt, snap[0]); return 2; }
+	if (npairs > cap) { L.restore(mt, snap[0]); return 2; }
 	const long long t1 = now_ns();
 	c->stat.add(T_CHUNK, t1 - t_band);
 	// the exact noise of candidate b: its part of the stream again, through legacy_gauss itself
 	auto replay = [&](int b) {
-		band_restore(mt, snap[b]);
+		L.restore(mt, snap[b]);
 		c->band_row.resize(M);
+		gauss_fill(mt, c->band_row.data(), (size_t) M);
 		for (int k = 0; k < M; k++) {
-			const double g = sigma * legacy_gauss(mt);
+			const double g = sigma * c->band_row[k];
 			c->band_row[k] = 0.0 + g;
 		}
 	};
@@ -1090,16 +1188,12 @@ int band_chunk(Env &e, const double *params, int B, int M, int *accepted, unsign
 	if (bstar >= 0) {
 		replay(bstar);
 		if (be->draw_band_commit(be->user, bstar, c->band_row.data(), fillbits) != 0) { set_error("draw_band_commit failed"); return 1; }
-		band_restore(mt, snap[(size_t) bstar + 1]);
+		L.restore(mt, snap[(size_t) bstar + 1]);
 	} else {
-		band_restore(mt, snap[B]);
+		L.restore(mt, snap[B]);
 		// the candidates looked at beyond this chunk stay, for a chunk that starts exactly here
 		L.base += (size_t) B;
-		if (L.count() == 0 || L.base > 8192) {
-			L.snap.erase(L.snap.begin(), L.snap.begin() + (long) L.base);
-			L.bound.erase(L.bound.begin(), L.bound.begin() + (long) L.base);
-			L.base = 0;
-		}
+		L.compact();
 		L.expect = *mt;
 		L.expect_has = g_has_gauss;
 		L.expect_gauss = g_gauss;
@@ -1262,8 +1356,9 @@ static int constrainer_draw(mdns_constrainer *c, const mdns_draw_backend *be, co
 			c->snap.resize(B);
 			for (int b = 0; b < B; b++) {
 				double *row = &c->jitter[(size_t) b * M];
+				gauss_fill(mt, row, (size_t) M);
 				for (int k = 0; k < M; k++) {
-					const double g = prior->jitter_sigma * legacy_gauss(mt);
+					const double g = prior->jitter_sigma * row[k];
 					row[k] = 0.0 + g;
 				}
 				c->snap[b].mt = *mt;
