@@ -58,6 +58,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X fp64 vector peak: 256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (v_mfma_f64_16x16x4_f64: 1024 FMAs in 64 cycles per SIMD; the probe in tools/probes reaches 69.4)
 NDIM = 3
 NLIVE = 100
 NBOOT = 10                     # clustering/radfriendsregion.py:59
@@ -225,6 +226,42 @@ def muse_leg(lib, _lib, nd=6250, nx=4096):
                           "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TFLOPS,
                           "flops_per_launch": 10.0 * nx * B * nd, "traffic": traffic, "traffic_source": source,
                           "evals_per_s": B * nd / (us * 1e-6)}
+    # the accept pass of a 64-candidate chunk as two matrix products (csrc/mdns_k2gemm.hip): what a constrained
+    # draw runs for chunks of this size; thresholds far from the candidates, a noise bound as in a run
+    B = 64
+    p5 = np.column_stack([rng.uniform(-0.3, 0.3, B), rng.uniform(0.0, 0.02, B), rng.uniform(-0.2, 0.2, B),
+                          rng.uniform(0.5, 1.5, B), rng.uniform(0.5, 1.5, B)])
+    templates = np.array([gen.muse_template(x, p) for p in p5])
+    d_t = lib.mdns_dev_alloc(templates.nbytes)
+    lib.mdns_h2d(d_t, _lib.ptr(templates), templates.nbytes)
+    thr, bound, flags = np.full(nd, 1e30), np.full(B, 5e-5), np.zeros(2 * B + 1, dtype=np.int32)
+    d_thr, d_bound, d_flags = lib.mdns_dev_alloc(thr.nbytes), lib.mdns_dev_alloc(bound.nbytes), lib.mdns_dev_alloc(flags.nbytes)
+    lib.mdns_h2d(d_thr, _lib.ptr(thr), thr.nbytes)
+    lib.mdns_h2d(d_bound, _lib.ptr(bound), bound.nbytes)
+    lib.mdns_h2d(d_flags, _lib.ptr(flags), flags.nbytes)
+    for _ in range(2):
+        lib.mdns_muse_filter_dev(sp, d_t, B, None, nd, d_thr, d_bound, d_flags)
+    lib.mdns_sync()
+    lib.mdns_profile_every(1)
+    lib.mdns_profile(2)
+    for _ in range(20):
+        lib.mdns_muse_filter_dev(sp, d_t, B, None, nd, d_thr, d_bound, d_flags)
+    lib.mdns_sync()
+    n, us = read_profile(lib, 1)
+    lib.mdns_profile(0)
+    kernel = (lib.mdns_profile_kernel(1) or b"").decode()
+    lib.mdns_d2h(_lib.ptr(flags), d_flags, flags.nbytes)
+    for d in (d_t, d_thr, d_bound, d_flags):
+        lib.mdns_dev_free(d)
+    nxp = (nx + 15) // 16 * 16
+    tf = 4.0 * nxp * B * nd / (us * 1e-6) / 1e12
+    traffic, source = pmc_traffic(kernel)
+    out["b64_filter"] = {"bound": "mfma", "kernel": kernel, "launch_us": us, "launches_timed": n, "achieved": tf,
+                         "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_MFMA_PEAK_TFLOPS,
+                         "flops_per_launch": 4.0 * nxp * B * nd, "bytes_per_launch": 16 * nxp * nd + 8 * B * nxp, "traffic": traffic,
+                         "traffic_source": source, "evals_per_s": B * nd / (us * 1e-6), "undecided_pairs": int(flags[2 * B]),
+                         "note": "executed flops: 2 products x 2 per (candidate, channel, spectrum) on v_mfma_f64_16x16x4_f64; "
+                                 "decisions are the exact kernel's (tests/test_muse.py), the accepted candidate's row is made by it"}
     lib.mdns_spectra_destroy(sp)
     return out
 

@@ -597,6 +597,12 @@ int mdns_backend_draw_band_end(void *joint, int *status, int *npairs, int *pair_
  * 1 for every chunk.  stats: chunks filtered | of those scored again exactly | exact rows made for a
  * commit | spectra handles prepared. */
 void mdns_muse_filter_mode(int mode);
+/* the filter pass alone on device pointers (asynchronous on the library stream): d_ypred f64[B][nx] templates,
+ * d_thr f64[ndata] thresholds by data set, d_bound f64[B]; d_out int32[2 B + 1], zeroed by the caller: [b] set to
+ * 1 when candidate b certainly beats a threshold, [B + b] when a pair of its cannot be settled, [2 B] the number
+ * of such pairs */
+int mdns_muse_filter_dev(mdns_spectra *s, const double *d_ypred, int B, const int *d_row_ids, int M, const double *d_thr,
+                         const double *d_bound, int *d_out);
 void mdns_muse_filter_stats(long long *out4);
 int mdns_backend_chain_begin(void *joint, void *region, const mdns_chain_request *rq);
 int mdns_backend_chain_end(void *joint, void *region, int *counts, int *nkept, int *B, int *accepted,

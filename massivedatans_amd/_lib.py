@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "mdns_backend_draw_begin", "mdns_backend_draw_chunk", "mdns_backend_chunk_size",
     "mdns_backend_region_begin", "mdns_backend_region_radius", "mdns_backend_chain_begin", "mdns_backend_chain_end",
     "mdns_backend_draw_score", "mdns_joint_votes_dev", "mdns_backend_draw_commit", "mdns_get_stream",
-    "mdns_backend_draw_band", "mdns_backend_draw_band_commit", "mdns_muse_filter_mode", "mdns_muse_filter_stats",
+    "mdns_backend_draw_band", "mdns_backend_draw_band_commit", "mdns_muse_filter_mode", "mdns_muse_filter_stats", "mdns_muse_filter_dev",
     "mdns_backend_draw_band_begin", "mdns_backend_draw_band_ready", "mdns_backend_draw_band_end",
 )
 
@@ -181,6 +181,7 @@ def _declare(lib):
         "mdns_backend_draw_band_begin": (i, [vp, vp, i, vp]),
         "mdns_backend_draw_band_ready": (i, [vp]),
         "mdns_backend_draw_band_end": (i, [vp, vp, vp, vp, vp, vp, vp, i]),
+        "mdns_muse_filter_dev": (i, [vp, vp, i, vp, i, vp, vp, vp]),
         "mdns_muse_filter_mode": (None, [i]),
         "mdns_muse_filter_stats": (None, [vp]),
     }

@@ -136,6 +136,186 @@ __global__ __launch_bounds__(64 * KW) void k_muse_gemm_band(
 	}
 }
 
+// The same products with the work spread evenly (stream-K): tiles x channel groups form ONE line of units,
+// workgroup w of P (one per CU) takes the stretch [w U / P, (w + 1) U / P) of it whatever tiles that crosses --
+// 391 row tiles on 256 CUs would otherwise leave half the chip idle for the second half of the launch.  A
+// stretch that covers a whole tile ends in the band test as above; a piece of a split tile goes into a
+// slot of its workgroup in device memory behind a count of the groups delivered, and the workgroup whose
+// piece completes the count -- it alone knows that all pieces are there -- adds the slots up in a fixed order,
+// tests the tile and leaves the count at zero for the next launch.  (Adding the pieces into one scratch tile
+// with f64 atomics measured 365 us against 221 for whole tiles, 6250 x 4096 x 64: 1.6 million device-scope
+// atomics.)
+template <int NC>
+__global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
+    const double *__restrict__ YW, const double *__restrict__ WF, int ldf, const double *__restrict__ A,
+    const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M, int bt,
+    const double *__restrict__ higher, const double *__restrict__ bound, double gamma, MuseBandOut out,
+    double *__restrict__ scratch, unsigned *__restrict__ delivered, const double *__restrict__ zeros)
+{
+	constexpr int KW = 8, NE = NC * 2 * 256;
+	if (out.zero_at && blockIdx.x == 0 && threadIdx.x == 0) *out.zero_at = 0;
+	__shared__ double red[NE];                                            // [c][S1 | S2][v * 64 + lane]
+	__shared__ int last_piece;
+	// (the wave number as a scalar: with it in a vector register the loop below counts as divergent and the
+	// compiler waits for every load in flight, vmcnt(0), at its head)
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+	const int i = lane & 15, q = lane >> 4;
+	const int ng = ldf >> 4, rt = (M + 15) >> 4;
+	const double *zr = zeros + 4 * q;
+	const long long U = (long long) rt * bt * ng;
+	long long u = U * blockIdx.x / gridDim.x;
+	const long long u1 = U * (blockIdx.x + 1) / gridDim.x;
+	while (u < u1) {
+		const int tile = (int) (u / ng), g0 = (int) (u - (long long) tile * ng);
+		const int g1 = u1 - u < ng - g0 ? g0 + (int) (u1 - u) : ng;       // this workgroup's groups [g0, g1) of the tile
+		u += g1 - g0;
+		const int k0 = (tile / bt) * 16, b0 = (tile % bt) * 16 * NC;
+		for (int t = threadIdx.x; t < NE; t += 64 * KW) red[t] = 0.0;
+		const int krow = k0 + i < M ? k0 + i : M - 1;
+		const size_t r = rows ? rows[krow] : krow;
+		const double *pyw = YW + r * ldf + 4 * q, *pw = WF + r * ldf + 4 * q;
+		const double *pm[NC];
+#pragma unroll
+		for (int c = 0; c < NC; c++) {
+			const int b = b0 + 16 * c + i < B ? b0 + 16 * c + i : B - 1;
+			pm[c] = model + (size_t) b * ldm + 4 * q;
+		}
+		double4_t acc1[NC], acc2[NC];
+#pragma unroll
+		for (int c = 0; c < NC; c++) { acc1[c] = double4_t{0, 0, 0, 0}; acc2[c] = double4_t{0, 0, 0, 0}; }
+		double4_t yw[2], w[2], m[2][NC];
+		// whole rounds of both register sets, straight-line: a group past the end of the stretch takes its spectrum
+		// operands from 16 zeros (and any template), so the loads in flight can be counted and waited for one set at a time
+#define K2_FETCH(SET, G) { \
+		const bool ok_ = (G) < g1; \
+		const size_t o_ = (size_t) (ok_ ? (G) : g1 - 1) << 4; \
+		yw[SET] = *reinterpret_cast<const double4_t *>(ok_ ? pyw + o_ : zr); \
+		w[SET] = *reinterpret_cast<const double4_t *>(ok_ ? pw + o_ : zr); \
+		_Pragma("unroll") for (int c = 0; c < NC; c++) m[SET][c] = *reinterpret_cast<const double4_t *>(pm[c] + o_); }
+#define K2_BODY(SET) { \
+		_Pragma("unroll") for (int t = 0; t < 4; t++) { \
+			_Pragma("unroll") for (int c = 0; c < NC; c++) { \
+				const double mv = m[SET][c][t]; \
+				acc1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(yw[SET][t], mv, acc1[c], 0, 0, 0); \
+				acc2[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[SET][t], mv * mv, acc2[c], 0, 0, 0); \
+			} } }
+		K2_FETCH(0, g0 + wave)
+#pragma unroll 1
+		for (int g = g0 + wave; g < g1; g += 2 * KW) {
+			// (the fence keeps the loads of the next group at the head of the 32 multiplications they overlap
+			// with; left alone the scheduler sinks them to a few instructions before their use)
+			K2_FETCH(1, g + KW)
+			__builtin_amdgcn_sched_barrier(0);
+			K2_BODY(0)
+			__builtin_amdgcn_sched_barrier(0);
+			K2_FETCH(0, g + 2 * KW)
+			__builtin_amdgcn_sched_barrier(0);
+			K2_BODY(1)
+			__builtin_amdgcn_sched_barrier(0);
+		}
+#undef K2_BODY
+#undef K2_FETCH
+		__syncthreads();                                                  // (the zeros are in place)
+		if (g0 + wave < g1) {
+#pragma unroll
+			for (int c = 0; c < NC; c++)
+#pragma unroll
+				for (int v = 0; v < 4; v++) {
+					unsafeAtomicAdd(&red[(c * 2) * 256 + v * 64 + lane], acc1[c][v]);
+					unsafeAtomicAdd(&red[(c * 2 + 1) * 256 + v * 64 + lane], acc2[c][v]);
+				}
+		}
+		__syncthreads();
+		bool finish = true;
+		if (g1 - g0 < ng) {
+			// a piece of a tile: into this workgroup's own slot (0: the piece its stretch starts with, 1: the
+			// one it ends with); the piece that completes the count of groups delivered adds up the slots of
+			// the workgroups the tile is spread over, in their order
+			const long long ubeg = U * blockIdx.x / gridDim.x;
+			const long long upiece = (long long) tile * ng + g0;
+			double *slot = scratch + ((size_t) blockIdx.x * 2 + (upiece == ubeg ? 0 : 1)) * NE;
+			// (agent-scope stores go through to memory and the loads below come from there; what has to be waited
+			// for is their completion -- a device-scope fence would write back and invalidate this XCD's whole L2,
+			// templates included, once per piece: 365 us a launch against 221 without split tiles)
+			for (int e = threadIdx.x; e < NE; e += 64 * KW) __hip_atomic_store(&slot[e], red[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__syncthreads();
+			if (threadIdx.x == 0) {
+				const unsigned before = atomicAdd(&delivered[tile], (unsigned) (g1 - g0));
+				last_piece = before + (unsigned) (g1 - g0) == (unsigned) ng ? 1 : 0;
+			}
+			__syncthreads();
+			finish = last_piece != 0;
+			if (finish) {
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+				const long long t0 = (long long) tile * ng, t1 = t0 + ng;
+				// workgroups w with [U w / P, U (w + 1) / P) meeting [t0, t1)
+				long long wlo = t0 * gridDim.x / U, whi = (t1 * gridDim.x + U - 1) / U;
+				while (wlo > 0 && U * wlo / gridDim.x > t0) wlo--;
+				while (U * (wlo + 1) / gridDim.x <= t0) wlo++;
+				if (whi > gridDim.x) whi = gridDim.x;
+				for (int e = threadIdx.x; e < NE; e += 64 * KW) red[e] = 0.0;
+				for (long long wg = wlo; wg < whi; wg++) {
+					const long long a0 = U * wg / gridDim.x, a1 = U * (wg + 1) / gridDim.x;
+					const long long p0 = a0 > t0 ? a0 : t0, p1 = a1 < t1 ? a1 : t1;
+					if (p0 >= p1) continue;
+					const double *from = scratch + ((size_t) wg * 2 + (p0 == a0 ? 0 : 1)) * NE;
+					for (int e = threadIdx.x; e < NE; e += 64 * KW) red[e] += __hip_atomic_load(&from[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				if (threadIdx.x == 0) delivered[tile] = 0;
+				__syncthreads();
+			}
+		}
+		if (finish) {
+			for (int e = threadIdx.x; e < NC * 256; e += 64 * KW) {
+				const int c = e >> 8, rem = e & 255, v = rem >> 6, l = rem & 63;
+				const int k = k0 + 4 * v + (l >> 4), b = b0 + 16 * c + (l & 15);
+				if (k >= M || b >= B) continue;
+				const double S1 = red[(c * 2) * 256 + rem], S2 = red[(c * 2 + 1) * 256 + rem];
+				const int d = rows ? rows[k] : k;
+				const double a = A[d], thr = higher[d];
+				const double s = S1 / (1e-10 + S2);
+				const double Lf = -0.5 * ((a - 2.0 * s * S1) + s * s * S2);
+				const double band = (1.01 * bound[b] + 1e-12 * (fabs(Lf) + fabs(thr))) + gamma * a;
+				if (Lf > thr + band) out.clear[b] = 1;
+				else if (!(Lf < thr - band)) {                               // (NaN lands here)
+					out.maybe[b] = 1;
+					const int at = atomicAdd(out.counter, 1);
+					if (at < out.cap) { out.pair_b[at] = b; out.pair_k[at] = k; out.pair_L[at] = Lf; out.pair_thr[at] = thr; }
+				}
+			}
+		}
+		__syncthreads();                                                  // (red is free for the next stretch)
+	}
+}
+
+// scratch tiles and delivery counts of the stream-K form: grow-only, zero whenever no launch is in flight
+static double *g_sk_scratch = nullptr, *g_sk_zeros = nullptr;
+static unsigned *g_sk_delivered = nullptr;
+static size_t g_sk_tiles = 0, g_sk_doubles = 0;
+
+static bool sk_reserve(size_t tiles, size_t doubles)
+{
+	Context *c = ctx();
+	if (!g_sk_zeros && (!MDNS_HIP(hipMalloc((void **) &g_sk_zeros, 16 * sizeof(double))) ||
+	                    !MDNS_HIP(hipMemsetAsync(g_sk_zeros, 0, 16 * sizeof(double), c->stream)))) return false;
+	if (tiles > g_sk_tiles) {
+		if (g_sk_delivered) { (void) hipStreamSynchronize(c->stream); (void) hipFree(g_sk_delivered); g_sk_delivered = nullptr; g_sk_tiles = 0; }
+		const size_t want = tiles + tiles / 2 + 64;
+		if (!MDNS_HIP(hipMalloc((void **) &g_sk_delivered, want * sizeof(unsigned))) ||
+		    !MDNS_HIP(hipMemsetAsync(g_sk_delivered, 0, want * sizeof(unsigned), c->stream))) return false;
+		g_sk_tiles = want;
+	}
+	if (doubles > g_sk_doubles) {
+		if (g_sk_scratch) { (void) hipStreamSynchronize(c->stream); (void) hipFree(g_sk_scratch); g_sk_scratch = nullptr; g_sk_doubles = 0; }
+		const size_t want = doubles + doubles / 2;
+		if (!MDNS_HIP(hipMalloc((void **) &g_sk_scratch, want * sizeof(double))) ||
+		    !MDNS_HIP(hipMemsetAsync(g_sk_scratch, 0, want * sizeof(double), c->stream))) return false;
+		g_sk_doubles = want;
+	}
+	return true;
+}
+
 static long long g_filter_stats[4];        // chunks filtered | scored again exactly | exact rows for a commit | prepared handles
 
 void muse_filter_note(int which) { if (which >= 0 && which < 4) g_filter_stats[which]++; }
@@ -194,8 +374,31 @@ bool launch_muse_filter(mdns_spectra *s, const double *d_model, int ldm, int B, 
 	int nc = B > 32 ? 4 : (B > 16 ? 2 : 1);
 	if (nc_forced) { const int f = atoi(nc_forced); if (f == 1 || f == 2 || f == 4) nc = f; }
 	const int bt = (B + 16 * nc - 1) / (16 * nc);
-	// waves over the channels of a tile: as many as it takes to give every SIMD a few waves
+	static const char *sk_forced = getenv("MDNS_K2_FILTER_SK");          // "0": one workgroup per tile (experiments)
 	const long long tiles = (long long) rt * bt;
+	if (!(sk_forced && sk_forced[0] == '0')) {
+		// stream-K: one workgroup per CU, fewer when that would leave a workgroup less than 16 groups of channels
+		const long long U = tiles * (s->ldf >> 4);
+		long long P = c->num_cus;
+		if (P > (U + 15) / 16) P = (U + 15) / 16;
+		if (P < 1) P = 1;
+		static const char *p_forced = getenv("MDNS_K2_FILTER_P");        // experiments only; 0: one per tile
+		if (p_forced) { const long long f = atoll(p_forced); P = f > 0 ? f : tiles; }
+		if (!sk_reserve((size_t) tiles, (size_t) P * 2 * nc * 512)) return false;
+		note_kernel(1, "k_muse_gemm_band_sk<%d>", nc);
+#define K2_SK(NC) hipLaunchKernelGGL((k_muse_gemm_band_sk<NC>), dim3((unsigned) P), dim3(512), 0, c->stream, \
+		(const double *) s->d_fyw, (const double *) s->d_fw, s->ldf, (const double *) s->d_fa, d_model, ldm, B, d_rows, M, bt, d_higher, d_bound, gamma, out, \
+		g_sk_scratch, g_sk_delivered, (const double *) g_sk_zeros)
+		{
+			ProfileScope prof(1);
+			if (nc == 4) K2_SK(4); else if (nc == 2) K2_SK(2); else K2_SK(1);
+		}
+#undef K2_SK
+		if (!MDNS_HIP(hipGetLastError())) return false;
+		muse_filter_note(0);
+		return true;
+	}
+	// waves over the channels of a tile: as many as it takes to give every SIMD a few waves
 	int kw = tiles * 4 >= 3LL * 4 * c->num_cus ? 4 : 8;
 	if (kw_forced) { const int f = atoi(kw_forced); if (f == 4 || f == 8) kw = f; }
 	while (kw > 4 && (s->ldf >> 4) < 2 * kw) kw >>= 1;
@@ -215,6 +418,19 @@ bool launch_muse_filter(mdns_spectra *s, const double *d_model, int ldm, int B, 
 }
 
 }  // namespace mdns
+
+// Part 3 (raw device pointers): the accept pass alone, for benches and tests
+extern "C" int mdns_muse_filter_dev(mdns_spectra *s, const double *d_ypred, int B, const int *d_row_ids, int M, const double *d_thr,
+                                    const double *d_bound, int *d_out)
+{
+	using namespace mdns;
+	if (!ctx() || !s || !d_ypred || !d_thr || !d_bound || !d_out || B < 1 || M < 1 || M > s->ndata) { set_error("mdns_muse_filter_dev: bad arguments"); return 1; }
+	if (!s->d_w) { set_error("spectra were created without variances"); return 1; }
+	const int ldm = model_ld(s->nx);
+	if (!ensure_model(s, (size_t) B * ldm) || !launch_pad_model(d_ypred, s->nx, B, s->d_model, ldm)) return 1;
+	const MuseBandOut out = {d_out + 2 * B, d_out, d_out + B, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
+	return launch_muse_filter(s, s->d_model, ldm, B, d_row_ids, M, d_thr, d_bound, out) ? 0 : 1;
+}
 
 extern "C" void mdns_muse_filter_mode(int mode) { mdns::g_filter_mode = mode == 0 || mode == 1 ? mode : -1; }
 
