@@ -161,6 +161,7 @@ int muse_rows_variant(int B, int M);
 // where its outcome goes (device memory; clear / maybe per candidate, listed pairs behind a counter)
 struct MuseBandOut { int *counter, *clear, *maybe, *pair_b, *pair_k; double *pair_L, *pair_thr; int cap; int *zero_at; };
 bool muse_filter_applies(const mdns_spectra *s, int B, int M);
+int muse_filter_ld(int nx);              // row stride of its operands; templates of a chunk it may take: model_ld(nx) + 16 apart
 bool launch_muse_filter(mdns_spectra *s, const double *d_model, int ldm, int B, const int *d_rows, int M,
                         const double *d_higher, const double *d_bound, const MuseBandOut &out);
 void muse_filter_note(int which);          // 1: a chunk scored again exactly, 2: an exact row for a commit

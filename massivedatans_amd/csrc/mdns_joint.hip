@@ -1627,7 +1627,7 @@ static int band_launch(mdns_joint *j, bool filtered)
 	const int *d_rows = j->sel_rows ? j->d_sel_rows : nullptr;
 	const double *d_p = j->d_bound, *d_b = j->d_bound + (size_t) B * 5;
 	if (filtered) {
-		const int ldm = model_ld(j->s->nx);
+		const int ldm = model_ld(j->s->nx) + 16;            // (not a power of two: mdns_k2gemm.hip, muse_filter_ld)
 		if (!ensure_model(j->s, (size_t) B * ldm) || !launch_muse3_model(j->s->d_x, j->s->nx, d_p, B, j->s->d_model, ldm)) return 1;
 		const MuseBandOut out = {&j->d_band->counter, j->d_band->clear, j->d_band->maybe, j->d_band->pair_b, j->d_band->pair_k,
 		                         j->d_band->pair_L, j->d_band->pair_thr, kBandCap, &((JointHeader *) j->d_result)->status};
@@ -1748,7 +1748,7 @@ extern "C" int mdns_backend_draw_band_commit(void *joint, int b, const double *j
 		// the chunk went through the matrix-core filter: what the state keeps is the exact kernel's row --
 		// from the instantiation that would have scored the whole block, bit for bit (the templates of
 		// the chunk are still in place)
-		const int ldm = model_ld(j->s->nx), Bc = j->band_B;
+		const int ldm = model_ld(j->s->nx) + 16, Bc = j->band_B;
 		const int lo = muse_rows_variant(Bc, M) == 1 ? (b & ~1) : b;
 		const int nb = lo == b && muse_rows_variant(Bc, M) != 1 ? 1 : (Bc - lo < 2 ? Bc - lo : 2);
 		if (!launch_muse_rows(j->s, j->s->d_model + (size_t) lo * ldm, ldm, nb, j->sel_rows ? j->d_sel_rows : nullptr, M,

@@ -27,6 +27,8 @@
 namespace mdns {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+// the spectrum operands are read once per launch: past the caches' replacement (the templates are re-read by everybody)
+#define K2_ROWLOAD(p) __builtin_nontemporal_load(p)
 
 // one workgroup per spectrum: y w and w, zero padded to ldf channels, and A = sum y^2 w
 __global__ __launch_bounds__(256) void k_muse_filter_prepare(const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64 * KW) void k_muse_gemm_band(
 	double4_t acc1[NC], acc2[NC];
 #pragma unroll
 	for (int c = 0; c < NC; c++) { acc1[c] = double4_t{0, 0, 0, 0}; acc2[c] = double4_t{0, 0, 0, 0}; }
-	const int ng = ldf >> 4;
+	const int ng = (ldf >> 4) - 1;                                        // (the last 16 of a row are padding: muse_filter_ld)
 	// two register sets in rotation: the loads of the wave's next group are in flight while this one is
 	// multiplied (a group past the end fetches the last one again: straight-line loads, exact counts)
 	double4_t yw[2], w[2], m[2][NC];
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
 	// compiler waits for every load in flight, vmcnt(0), at its head)
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
 	const int i = lane & 15, q = lane >> 4;
-	const int ng = ldf >> 4, rt = (M + 15) >> 4;
+	const int ng = (ldf >> 4) - 1, rt = (M + 15) >> 4;                    // (the last 16 of a row are padding: muse_filter_ld)
 	const double *zr = zeros + 4 * q;
 	const long long U = (long long) rt * bt * ng;
 	long long u = U * blockIdx.x / gridDim.x;
@@ -189,19 +191,36 @@ __global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
 #define K2_FETCH(SET, G) { \
 		const bool ok_ = (G) < g1; \
 		const size_t o_ = (size_t) (ok_ ? (G) : g1 - 1) << 4; \
-		yw[SET] = *reinterpret_cast<const double4_t *>(ok_ ? pyw + o_ : zr); \
-		w[SET] = *reinterpret_cast<const double4_t *>(ok_ ? pw + o_ : zr); \
+		yw[SET] = K2_ROWLOAD(reinterpret_cast<const double4_t *>(ok_ ? pyw + o_ : zr)); \
+		w[SET] = K2_ROWLOAD(reinterpret_cast<const double4_t *>(ok_ ? pw + o_ : zr)); \
 		_Pragma("unroll") for (int c = 0; c < NC; c++) m[SET][c] = *reinterpret_cast<const double4_t *>(pm[c] + o_); }
+		// (the squares first, all of them: a multiplication waiting for the square made just before it held up the
+		// matrix pipe -- the multiplications alone took 153 us of the 176 with the squares in between)
 #define K2_BODY(SET) { \
+		double4_t m2[NC]; \
+		_Pragma("unroll") for (int c = 0; c < NC; c++) m2[c] = m[SET][c] * m[SET][c]; \
+		__builtin_amdgcn_sched_barrier(0); \
 		_Pragma("unroll") for (int t = 0; t < 4; t++) { \
 			_Pragma("unroll") for (int c = 0; c < NC; c++) { \
-				const double mv = m[SET][c][t]; \
-				acc1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(yw[SET][t], mv, acc1[c], 0, 0, 0); \
-				acc2[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[SET][t], mv * mv, acc2[c], 0, 0, 0); \
+				acc1[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(yw[SET][t], m[SET][c][t], acc1[c], 0, 0, 0); \
+				acc2[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[SET][t], m2[c][t], acc2[c], 0, 0, 0); \
 			} } }
 		K2_FETCH(0, g0 + wave)
 #pragma unroll 1
 		for (int g = g0 + wave; g < g1; g += 2 * KW) {
+#ifdef MDNS_K2_PROBE
+			// (experiments: 1 no loads in the loop; 2 no multiplications)
+#if MDNS_K2_PROBE == 1
+			K2_BODY(0) K2_BODY(1)
+			continue;
+#elif MDNS_K2_PROBE == 2
+			K2_FETCH(1, g + KW)
+			K2_FETCH(0, g + 2 * KW)
+			acc1[0] += yw[0] + w[0] + yw[1] + w[1];
+			_Pragma("unroll") for (int c = 0; c < NC; c++) acc2[c] += m[0][c] + m[1][c];
+			continue;
+#endif
+#endif
 			// (the fence keeps the loads of the next group at the head of the 32 multiplications they overlap
 			// with; left alone the scheduler sinks them to a few instructions before their use)
 			K2_FETCH(1, g + KW)
@@ -337,26 +356,30 @@ bool muse_filter_applies(const mdns_spectra *s, int B, int M)
 	return B >= 8 && M >= 512 && s->nx >= 256;
 }
 
+// row stride of the filter's operands (spectra and templates alike): nx rounded up to 16, plus 16.  A wave's
+// load touches 16 rows at once; with rows a power of two apart (4096 channels = 32 KB) all 16 lines fall into
+// the same L2 channel (measured: the loads alone took as long as the whole kernel)
+int muse_filter_ld(int nx) { return ((nx + 15) & ~15) + 16; }
+
 bool muse_filter_prepare(mdns_spectra *s)
 {
 	if (s->d_fyw) return true;
 	Context *c = ctx();
-	const int ldf = (s->nx + 15) & ~15;
+	const int ldf = muse_filter_ld(s->nx);
 	const size_t elems = (size_t) s->ndata * ldf;
 	double *yw = nullptr, *wf = nullptr, *a = nullptr;
-	const bool own_w = ldf != s->ld;
 	if (!MDNS_HIP(hipMalloc((void **) &yw, (elems ? elems : 1) * sizeof(double))) ||
 	    !MDNS_HIP(hipMalloc((void **) &a, (size_t) (s->ndata ? s->ndata : 1) * sizeof(double))) ||
-	    (own_w && !MDNS_HIP(hipMalloc((void **) &wf, (elems ? elems : 1) * sizeof(double))))) {
+	    !MDNS_HIP(hipMalloc((void **) &wf, (elems ? elems : 1) * sizeof(double)))) {
 		if (yw) (void) hipFree(yw);
 		if (a) (void) hipFree(a);
 		return false;
 	}
 	if (s->ndata > 0)
 		hipLaunchKernelGGL(k_muse_filter_prepare, dim3(s->ndata), dim3(256), 0, c->stream, (const double *) s->d_y, (const double *) s->d_w,
-		                   s->ld, s->nx, yw, own_w ? wf : (double *) nullptr, ldf, a);
-	if (!MDNS_HIP(hipGetLastError())) { (void) hipFree(yw); (void) hipFree(a); if (wf) (void) hipFree(wf); return false; }
-	s->d_fyw = yw; s->d_fw = own_w ? wf : s->d_w; s->fw_owned = own_w; s->d_fa = a; s->ldf = ldf;
+		                   s->ld, s->nx, yw, wf, ldf, a);
+	if (!MDNS_HIP(hipGetLastError())) { (void) hipFree(yw); (void) hipFree(a); (void) hipFree(wf); return false; }
+	s->d_fyw = yw; s->d_fw = wf; s->fw_owned = true; s->d_fa = a; s->ldf = ldf;
 	muse_filter_note(3);
 	return true;
 }
@@ -378,7 +401,7 @@ bool launch_muse_filter(mdns_spectra *s, const double *d_model, int ldm, int B, 
 	const long long tiles = (long long) rt * bt;
 	if (!(sk_forced && sk_forced[0] == '0')) {
 		// stream-K: one workgroup per CU, fewer when that would leave a workgroup less than 16 groups of channels
-		const long long U = tiles * (s->ldf >> 4);
+		const long long U = tiles * ((s->ldf >> 4) - 1);
 		long long P = c->num_cus;
 		if (P > (U + 15) / 16) P = (U + 15) / 16;
 		if (P < 1) P = 1;
@@ -401,7 +424,7 @@ bool launch_muse_filter(mdns_spectra *s, const double *d_model, int ldm, int B, 
 	// waves over the channels of a tile: as many as it takes to give every SIMD a few waves
 	int kw = tiles * 4 >= 3LL * 4 * c->num_cus ? 4 : 8;
 	if (kw_forced) { const int f = atoi(kw_forced); if (f == 4 || f == 8) kw = f; }
-	while (kw > 4 && (s->ldf >> 4) < 2 * kw) kw >>= 1;
+	while (kw > 4 && (s->ldf >> 4) - 1 < 2 * kw) kw >>= 1;
 	note_kernel(1, "k_muse_gemm_band<%d, %d>", nc, kw);
 #define K2_LAUNCH(NC, KW) hipLaunchKernelGGL((k_muse_gemm_band<NC, KW>), dim3(rt, bt), dim3(64 * KW), 0, c->stream, \
 		(const double *) s->d_fyw, (const double *) s->d_fw, s->ldf, (const double *) s->d_fa, d_model, ldm, B, d_rows, M, d_higher, d_bound, gamma, out)
@@ -426,7 +449,7 @@ extern "C" int mdns_muse_filter_dev(mdns_spectra *s, const double *d_ypred, int 
 	using namespace mdns;
 	if (!ctx() || !s || !d_ypred || !d_thr || !d_bound || !d_out || B < 1 || M < 1 || M > s->ndata) { set_error("mdns_muse_filter_dev: bad arguments"); return 1; }
 	if (!s->d_w) { set_error("spectra were created without variances"); return 1; }
-	const int ldm = model_ld(s->nx);
+	const int ldm = model_ld(s->nx) + 16;
 	if (!ensure_model(s, (size_t) B * ldm) || !launch_pad_model(d_ypred, s->nx, B, s->d_model, ldm)) return 1;
 	const MuseBandOut out = {d_out + 2 * B, d_out, d_out + B, nullptr, nullptr, nullptr, nullptr, 0, nullptr};
 	return launch_muse_filter(s, s->d_model, ldm, B, d_row_ids, M, d_thr, d_bound, out) ? 0 : 1;
