@@ -1,9 +1,11 @@
 #!/bin/bash
 # SQ / cache counters of the K2 matrix-core filter (tools/muse_leg_probe.py launches it 22 times):
 #   tools/k2_filter_counters.sh <out-dir under gpurun_out>
-set -e
-out=gpurun_out/$1
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+set -euo pipefail
+repo=$(cd "$(dirname "$0")/.." && pwd)
+out=gpurun_out/${1:?usage: tools/k2_filter_counters.sh <tag>}
+export TMPDIR=/tmp
+cd "$repo"
 rm -rf "$out" && mkdir -p "$out"
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" \
