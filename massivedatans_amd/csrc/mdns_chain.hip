@@ -100,10 +100,10 @@ __global__ __launch_bounds__(256) void k_box_count(
 	if (wv == 0 && lane < PTS && j < spec.n) {
 		const int total = (part[pt] + part[PTS + pt]) + (part[2 * PTS + pt] + part[3 * PTS + pt]);
 		counts[j] = total;
-		box->counts[j] = total;
+		__hip_atomic_store(&box->counts[j], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 	}
 	if (mail.seq_at) {
-		if (wv == 0) __threadfence_system();
+		if (wv == 0) handover_release();                           // (mdns_internal.h)
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			const int done = atomicAdd(mail.ticket, 1);

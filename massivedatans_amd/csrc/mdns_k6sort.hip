@@ -256,13 +256,13 @@ __global__ __launch_bounds__(kWaves * 64) void k_nearest_culled(
 	}
 	if (!fin.counter) return;
 	// the workgroup that finishes last turns the maxima into {radius, threshold} (as k_nearest_chosen)
-	__threadfence();
+	handover_release();
 	__syncthreads();
 	if (wv != 0) return;
 	unsigned ticket = 0;
 	if (lane == 0) ticket = atomicAdd(fin.counter, 1u);
 	if (__shfl(ticket, 0, 64) != gridDim.x - 1) return;
-	__threadfence();
+	handover_acquire();
 	double best = 0.0;
 	for (int b = lane; b < nround_all; b += 64)
 		best = fmax(best, __hip_atomic_load(round_sq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

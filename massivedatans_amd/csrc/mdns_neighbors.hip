@@ -139,12 +139,14 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 	if (wv == 0 && lane < PTS && j < M) {
 		const int total = (part[pt] + part[PTS + pt]) + (part[2 * PTS + pt] + part[3 * PTS + pt]);
 		if (accumulate) { if (total) atomicAdd(counts + j, total); }
+		else if (mail.seq_at) __hip_atomic_store(counts + j, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 		else counts[j] = total;
 	}
 	if (mail.seq_at) {
-		// `counts` is host memory mapped into the device (no member split: plain stores): once every
-		// workgroup's stores are out, the last one to get here raises `seq` for the polling host
-		if (wv == 0) __threadfence_system();                      // (only wave 0 stored)
+		// `counts` is host memory mapped into the device (no member split; system-scope stores): once every
+		// workgroup's stores are out -- waited for, not fenced: see handover_release -- the last one to get here
+		// raises `seq` for the polling host
+		if (wv == 0) handover_release();                           // (only wave 0 stored)
 		__syncthreads();
 		if (threadIdx.x == 0) {
 			const int done = atomicAdd(mail.ticket, 1);
@@ -331,13 +333,13 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 	if (!fin.counter) return;
 	// The workgroup that finishes last turns the maxima into {radius, threshold} for the
 	// membership kernel (device copy) and for the host (mapped memory, `seq` written last).
-	__threadfence();                                   // this workgroup's atomics before its ticket
+	handover_release();                                   // this workgroup's atomics before its ticket
 	__syncthreads();
 	if (wv != 0) return;
 	unsigned ticket = 0;
 	if (lane == 0) ticket = atomicAdd(fin.counter, 1u);
 	if (__shfl(ticket, 0, 64) != gridDim.x - 1) return;
-	__threadfence();
+	handover_acquire();
 	double best = 0.0;
 	for (int b = lane; b < nround_all; b += 64)
 		best = fmax(best, __hip_atomic_load(round_all + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -426,7 +428,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
 		const double v = fmin(fmin(meet[(0 * RT + b) * 64 + l], meet[(1 * RT + b) * 64 + l]),
 		                      fmin(meet[(2 * RT + b) * 64 + l], meet[(3 * RT + b) * 64 + l]));
 		const int p = blockIdx.x * 64 + l;
-		if (p < K) part[((size_t) blockIdx.y * K + p) * RT + b] = v;
+		// (agent scope when another workgroup of this launch merges them: see handover_release)
+		if (p < K) { if (block_tickets) __hip_atomic_store(&part[((size_t) blockIdx.y * K + p) * RT + b], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else part[((size_t) blockIdx.y * K + p) * RT + b] = v; }
 	}
 	if (!block_tickets) return;                        // (the merge is a kernel of its own: k_nearest_finish)
 	// Round 4: the merge rides in this kernel.  Of the gridDim.y workgroups that share these 64 points the
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
 	// (cneighbors.c:160-168); of those, the last one finishes the radius (k_nearest_chosen's epilogue).
 	__shared__ int s_last;
 	__shared__ double wmax[4][RT];
-	__threadfence();
+	handover_release();
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		const unsigned t = atomicAdd(block_tickets + blockIdx.x, 1u);
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
 	}
 	__syncthreads();
 	if (!s_last) return;
-	__threadfence();
+	handover_acquire();
 	{
 		const int ny = (int) gridDim.y;
 		const int i2 = blockIdx.x * 64 + ((int) threadIdx.x >> 2), yq = threadIdx.x & 3;
@@ -482,13 +485,13 @@ __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
 		}
 	}
 	if (!fin.counter) return;
-	__threadfence();
+	handover_release();
 	__syncthreads();
 	if (wv != 0) return;
 	unsigned ticket = 0;
 	if (lane == 0) ticket = atomicAdd(fin.counter, 1u);
 	if (__shfl(ticket, 0, 64) != gridDim.x - 1) return;
-	__threadfence();
+	handover_acquire();
 	double best = 0.0;
 	for (int b = lane; b < nround_all; b += 64)
 		best = fmax(best, __hip_atomic_load(round_sq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -552,13 +555,13 @@ __global__ __launch_bounds__(kBlock) void k_nearest_finish(
 		if (w > 0.0) atomic_max_nonneg(round_sq + threadIdx.x, w);
 	}
 	if (!fin.counter) return;
-	__threadfence();
+	handover_release();
 	__syncthreads();
 	if (wv != 0) return;
 	unsigned ticket = 0;
 	if (lane == 0) ticket = atomicAdd(fin.counter, 1u);
 	if (__shfl(ticket, 0, 64) != gridDim.x - 1) return;
-	__threadfence();
+	handover_acquire();
 	double best = 0.0;
 	for (int b = lane; b < nround_all; b += 64)
 		best = fmax(best, __hip_atomic_load(round_sq + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -747,9 +750,10 @@ bool launch_bootstrap_packed(const double *d_members, int K, int ndim, const uns
 		ProfileScope prof(3);
 		note_kernel(3, "k_nearest_uniform<%d, %d>", ndim, rt);
 		// MDNS_K6_MERGE=fold: the merge inside the kernel (its last workgroups) instead of k_nearest_finish.
-		// Measured (profiles/r04_k6_sorted.txt): 33.9 / 87.9 / 263.6 / 417.6 us at 1 000 / 2 000 / 5 000 / 9 000
-		// points against 20.1 / 24.2 / 50.9 / 113.6 for the pair of kernels -- the device-scope fence every
-		// workgroup needs before its ticket costs far more than the launch it saves.  Not the default.
+		// With a device-scope fence per workgroup before its ticket (profiles/r04_k6_sorted.txt): 33.9 / 87.9 /
+		// 263.6 / 417.6 us at 1 000 / 2 000 / 5 000 / 9 000 points against 20.1 / 24.2 / 50.9 / 113.6 for the pair of
+		// kernels.  With the hand-over of mdns_internal.h (agent-scope stores, a wait instead of the fence): 20.4 /
+		// 26.2 / 48.1 / 107.1 against 19.1 / 22.3 / 47.6 / 106.3 -- level, so the pair stays the default.
 		static const char *merge = getenv("MDNS_K6_MERGE");
 		const bool fold = merge && !strcmp(merge, "fold");
 		static unsigned *d_tickets = nullptr;
