@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void k_box_count(
 			const int done = atomicAdd(mail.ticket, 1);
 			if (done == (int) gridDim.x - 1) {
 				__hip_atomic_store(mail.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(mail.seq_at, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				mail_raise(mail.seq_at, mail.seq);
 			}
 		}
 	}

@@ -185,18 +185,18 @@ __global__ __launch_bounds__(1024) void k_chunk_commit(
 					st.higher[d] = at_most >= n + 2 ? thr : fmin(L, next);
 				}
 			}
-			if (lane == 0) { fillbits[tile] = word; box->bits[tile] = word; }
+			if (lane == 0) { fillbits[tile] = word; mail_store(&box->bits[tile], word); }
 		}
 	}
-	__threadfence_system();
+	handover_release();
 	__syncthreads();
 	if (threadIdx.x != 0) return;
 	const int accepted = bstar < B ? bstar : -1;
 	header->accepted = accepted;
 	header->status = s_status;
-	box->accepted = accepted;
-	box->status = s_status;
-	__hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	mail_store(&box->accepted, accepted);
+	mail_store(&box->status, s_status);
+	mail_raise(&box->seq, seq);
 }
 
 // ---------------------------------------------------------------------------------------

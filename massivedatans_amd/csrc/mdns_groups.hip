@@ -229,18 +229,18 @@ __global__ __launch_bounds__(1024) void k_groups_compact(const unsigned long lon
 	// the list goes to the host in one sweep of coalesced stores (`box` is host memory mapped into
 	// the device; every thread writing its own run there 4 bytes at a time took 3x as long)
 	const int total = s_total;
-	for (int e = t; e < total; e += 1024) box->distinct[e] = scratch[e];
+	for (int e = t; e < total; e += 1024) mail_store(&box->distinct[e], scratch[e]);
 	// counts, failure bits and the rounds' flags with it; `seq` last: the host polls for it
-	if (t < kMaxRounds) box->header.changed[t] = header->changed[t];
+	if (t < kMaxRounds) mail_store(&box->header.changed[t], header->changed[t]);
 	if (t == 1023) {
-		box->header.ncomponents = header->ncomponents;
-		box->header.ndistinct = total;
-		box->header.status = header->status;
+		mail_store(&box->header.ncomponents, header->ncomponents);
+		mail_store(&box->header.ndistinct, total);
+		mail_store(&box->header.status, header->status);
 		header->ncomponents = 0;                                       // k_groups_finish of the next call counts from here
 	}
-	__threadfence_system();
+	handover_release();
 	__syncthreads();
-	if (t == 0) __hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	if (t == 0) mail_raise(&box->seq, seq);
 }
 
 __global__ __launch_bounds__(kBlock) void k_groups_point_labels(const PLabel *__restrict__ plabel, long long npoints, int call,

@@ -267,6 +267,12 @@ void note_kernel(int which, const char *fmt, ...);
 #ifdef __HIPCC__
 __device__ __forceinline__ void handover_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
 __device__ __forceinline__ void handover_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+// Into host memory mapped into the device, for a host that polls `seq`: system-scope stores act on that memory
+// itself, so `seq` only has to wait for the stores before it (every thread: mail_store()s, handover_release(), a
+// barrier; then one thread: mail_raise()).  A system-scope RELEASE would write back the L2 first -- per mailbox
+// a few microseconds that nobody needs: what the host reads is all in the mailbox.
+template <class T, class V> __device__ __forceinline__ void mail_store(T *at, V v) { __hip_atomic_store(at, (T) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+__device__ __forceinline__ void mail_raise(unsigned long long *seq_at, unsigned long long seq) { handover_release(); mail_store(seq_at, seq); }
 #endif
 
 // smallest double T with sqrt(T) >= r, so that  sqrt(d) < r  <=>  d < T  for every d >= 0

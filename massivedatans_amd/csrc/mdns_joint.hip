@@ -244,13 +244,13 @@ __global__ __launch_bounds__(kBlock) void k_joint_publish(const JointHeader *__r
 {
 	const int accepted = header->accepted;
 	if (accepted >= 0)
-		for (int w = threadIdx.x; w < nwords; w += kBlock) box->bits[w] = fillbits[w];
-	__threadfence_system();
+		for (int w = threadIdx.x; w < nwords; w += kBlock) mail_store(&box->bits[w], fillbits[w]);
+	handover_release();
 	__syncthreads();
 	if (threadIdx.x != 0) return;
-	box->accepted = accepted;
-	box->status = header->status;
-	__hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	mail_store(&box->accepted, accepted);
+	mail_store(&box->status, header->status);
+	mail_raise(&box->seq, seq);
 }
 
 // ---- the draw for scorers that leave a dense L[B, M] (the scale-marginalised likelihood, K2) ----
@@ -364,19 +364,19 @@ __global__ __launch_bounds__(kBlock) void k_joint_band_publish(BandScratch *__re
 	const int n = sc->counter;
 	const int m = n < kBandCap ? n : kBandCap;
 	for (int b = threadIdx.x; b < B; b += kBlock) {
-		box->status[b] = sc->clear[b] ? 1 : (sc->maybe[b] ? 2 : 0);
+		mail_store(&box->status[b], sc->clear[b] ? 1 : (sc->maybe[b] ? 2 : 0));
 		sc->clear[b] = 0; sc->maybe[b] = 0;
 	}
 	for (int t = threadIdx.x; t < m; t += kBlock) {
-		box->pair_b[t] = sc->pair_b[t]; box->pair_k[t] = sc->pair_k[t];
-		box->pair_L[t] = sc->pair_L[t]; box->pair_thr[t] = sc->pair_thr[t];
+		mail_store(&box->pair_b[t], sc->pair_b[t]); mail_store(&box->pair_k[t], sc->pair_k[t]);
+		mail_store(&box->pair_L[t], sc->pair_L[t]); mail_store(&box->pair_thr[t], sc->pair_thr[t]);
 	}
-	__threadfence_system();
+	handover_release();
 	__syncthreads();
 	if (threadIdx.x != 0) return;
 	sc->counter = 0;
-	box->npairs = n;
-	__hip_atomic_store(&box->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	mail_store(&box->npairs, n);
+	mail_raise(&box->seq, seq);
 }
 
 // k_joint_commit_dense for a candidate the HOST names, with its noise row added first

@@ -274,9 +274,9 @@ __global__ __launch_bounds__(kWaves * 64) void k_nearest_culled(
 	fin.d_res->radius = radius;
 	fin.d_res->thresh = thresh;
 	*fin.counter = 0;
-	fin.h_res->radius = radius;
-	fin.h_res->thresh = thresh;
-	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	mail_store(&fin.h_res->radius, radius);
+	mail_store(&fin.h_res->thresh, thresh);
+	mail_raise(&fin.h_res->seq, fin.seq);
 }
 
 static bool launched(const char *name)

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(kBlock) void k_count_within(
 			const int done = atomicAdd(mail.ticket, 1);
 			if (done == (int) (gridDim.x * gridDim.y) - 1) {
 				__hip_atomic_store(mail.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // for the next launch (stream order)
-				__hip_atomic_store(mail.seq_at, mail.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+				mail_raise(mail.seq_at, mail.seq);
 			}
 		}
 	}
@@ -352,9 +352,9 @@ __global__ __launch_bounds__(kBlock) void k_nearest_chosen(
 	fin.d_res->radius = radius;
 	fin.d_res->thresh = thresh;
 	*fin.counter = 0;
-	fin.h_res->radius = radius;
-	fin.h_res->thresh = thresh;
-	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	mail_store(&fin.h_res->radius, radius);
+	mail_store(&fin.h_res->thresh, thresh);
+	mail_raise(&fin.h_res->seq, fin.seq);
 }
 
 // K6 again, for packed choices (the shape every region of a run has): the member a wave looks at
@@ -503,9 +503,9 @@ __global__ __launch_bounds__(kBlock) void k_nearest_uniform(
 	fin.d_res->radius = radius;
 	fin.d_res->thresh = thresh;
 	*fin.counter = 0;
-	fin.h_res->radius = radius;
-	fin.h_res->thresh = thresh;
-	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	mail_store(&fin.h_res->radius, radius);
+	mail_store(&fin.h_res->thresh, thresh);
+	mail_raise(&fin.h_res->seq, fin.seq);
 }
 
 // min over the member chunks, then per round the max over the left-out points with index >= 1
@@ -573,9 +573,9 @@ __global__ __launch_bounds__(kBlock) void k_nearest_finish(
 	fin.d_res->radius = radius;
 	fin.d_res->thresh = thresh;
 	*fin.counter = 0;
-	fin.h_res->radius = radius;
-	fin.h_res->thresh = thresh;
-	__hip_atomic_store(&fin.h_res->seq, fin.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+	mail_store(&fin.h_res->radius, radius);
+	mail_store(&fin.h_res->thresh, thresh);
+	mail_raise(&fin.h_res->seq, fin.seq);
 }
 
 // ---------------------------------------------------------------------------------------
