@@ -29,6 +29,18 @@ def _absorb(logZ, H, shell_logwidth, Li):
     return grown, H
 
 
+def _column_sums(a, one_by_one):
+    """``a.sum(axis=0)``.  numpy adds the rows of a C-contiguous [k, n > 1] array one after the other; with a
+    single column the summed axis is the contiguous one and it sums pairwise.  A rank that integrates ONE
+    column of an analysis with several (``parallel.LocalColumns``) asks for the first order explicitly."""
+    if not one_by_one:
+        return a.sum(axis=0)
+    total = a[0].copy()
+    for row in a[1:]:
+        total += row
+    return total
+
+
 def integrate_remainder(sampler, logwidth, logVolremaining, logZ, H, globalLmax):
     """Evidence still held by the live points, which all share the shell width ``logwidth``
     (multi_nested_integrator.py:26-59).  Returns per running data set: remainder log-evidence,
@@ -45,9 +57,10 @@ def integrate_remainder(sampler, logwidth, logVolremaining, logZ, H, globalLmax)
     # upper / lower Riemann sums: every point takes its upper (resp. lower) neighbour's value
     rel_top = rel.copy()
     rel_top[-1] = numpy.exp(globalLmax - ref)
-    upper = rel_top[1:].sum(axis=0) + rel_top[-1]
-    lower = rel[:-1].sum(axis=0) + rel[0]
-    log_mid = log(rel.sum(axis=0)) + ref
+    one_by_one = bool(getattr(sampler, 'sums_row_by_row', False))
+    upper = _column_sums(rel_top[1:], one_by_one) + rel_top[-1]
+    lower = _column_sums(rel[:-1], one_by_one) + rel[0]
+    log_mid = log(_column_sums(rel, one_by_one)) + ref
     total_mid = logaddexp(logZ, logwidth + log_mid)
     total_up = logaddexp(logZ, logwidth + log(upper) + ref)
     total_lo = logaddexp(logZ, logwidth + log(lower) + ref)
@@ -114,7 +127,8 @@ def multi_nested_integrator(multi_sampler, tolerance=0.01, max_samples=None, min
             done = total_err < tolerance
             if max_samples and it > max_samples:
                 done[:] = True
-            if done.any():
+            # (a sampler whose data sets are spread over ranks takes part in every check: its cut_down is a collective)
+            if done.any() or getattr(multi_sampler, 'collective_checks', False):
                 log_.debug('iteration %d: %d data sets finished', it, done.sum())
                 for j, k in enumerate(numpy.flatnonzero(active)):
                     if done[j]:
@@ -122,7 +136,8 @@ def multi_nested_integrator(multi_sampler, tolerance=0.01, max_samples=None, min
                         tail_w[k] = logwidth
                 multi_sampler.cut_down(~done)
                 active[active] = ~done
-            if not active.any():
+            everybody_done = getattr(multi_sampler, 'everybody_done', None)
+            if (not active.any()) if everybody_done is None else everybody_done(not active.any()):
                 break
         dead_u, dead_x, dead_L = next(multi_sampler)
         logZ[active], H[active] = _absorb(logZ[active], H[active], logwidth, dead_L)

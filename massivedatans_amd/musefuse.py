@@ -137,11 +137,11 @@ class _LinesScorer(object):
 def run(x, y, v, nlive_points=400, nsuperset_draws=10, use_graph=True, max_samples=0, min_samples=0,
         tolerance=0.5, seed=1, backend=None, jitter=True, fused=True, native=None):
     """The whole analysis (musefuse.py:607-648); returns ``(results, sampler, problem, duration)``."""
-    from .sample import build_sampler
+    from .sample import build_sampler, integrate
     problem = MuseProblem(x, y, v, backend=backend, jitter=jitter)
     start = time.time()
     sampler = build_sampler(problem, nlive_points, nsuperset_draws, use_graph, seed, batched=False, fused=fused, native=native)
-    results = multi_nested_integrator(tolerance=tolerance, multi_sampler=sampler, min_samples=min_samples, max_samples=max_samples)
+    results = integrate(sampler, tolerance, min_samples, max_samples)
     if sampler.native is not None:
         sampler.native.sync_gauss_to_numpy()
     return results, sampler, problem, time.time() - start
@@ -169,11 +169,10 @@ def main(argv=None):
         data['x'], data['y'], data['v'], nlive_points=nlive_points, backend=distributed_backend(data['x'], data['y'], data['v']),
         nsuperset_draws=int(os.environ.get('SUPERSET_DRAWS', '10')), use_graph=os.environ.get('USE_GRAPH', '1') == '1',
         max_samples=int(os.environ.get('MAXSAMPLES', 100000)), min_samples=int(os.environ.get('MINSAMPLES', 0)))
-    if int(os.environ.get('RANK', '0')) != 0:
-        return                                     # every rank holds the same results; rank 0 writes
-    from .sample import save_results
+    from .sample import write_outputs
     prefix = '%s_full_.out_%d' % (argv[1], ndata)
-    save_results(prefix, results, sampler, duration, ndata)
+    if not write_outputs(prefix, results, sampler, duration, ndata):
+        return
     print('logZ = %.1f +- %.1f' % (results['logZ'][0], results['logZerr'][0]))
     print('ndraws:', sampler.ndraws, 'niter:', len(results['weights']), 'in %.1f s' % duration)
 

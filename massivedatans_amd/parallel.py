@@ -430,3 +430,105 @@ class ShardedJointState(object):
         parts = self._gather_vectors(np.concatenate((higher, np.asarray(n, dtype=np.float64))))
         return (np.concatenate([p[:len(p) // 2] for p in parts]),
                 np.concatenate([p[len(p) // 2:] for p in parts]).astype(int))
+
+
+class LocalColumns(object):
+    """What the evidence integration sees of a sampler whose data sets are spread over the ranks
+    (``ShardedJointState``): THIS rank's data sets only.  The sampler itself stays whole on every rank
+    -- its draws are collective -- but everything the integrator does is per data set
+    (multi_nested_integrator.py:26-175: one evidence, one information, one stopping test per column), so
+    each rank integrates its block: 1/N of the per-iteration host work, and the live likelihoods are read
+    from the rank's own joint state instead of being gathered every 50 iterations (80 MB at 100 000 data
+    sets x 100 live points).  Two things are collective: which data sets are finished (``cut_down``: one
+    all-gather of flags per check) and whether everybody is (``everybody_done``: one all-reduce).
+    ``gather`` puts the per-data-set results of all ranks together at the end."""
+
+    collective_checks = True
+
+    def __init__(self, sampler):
+        torch, dist = _dist()
+        self.sampler = sampler
+        self.joint = sampler.joint
+        if not isinstance(self.joint, ShardedJointState):
+            raise TypeError("LocalColumns needs a sampler over a ShardedJointState")
+        self.nlive_points = sampler.nlive_points
+        self.lo, self.hi = self.joint.lo, self.joint.hi
+        self._running = np.arange(self.joint.ndata)               # global ids of the data sets still sampled
+        self._live = None
+        self._select()
+
+    # ---- what touches the other ranks / this rank's state (tests replace these three) ----
+    def _min_over_ranks(self, values):
+        """Element-wise minimum of an int32 vector over the ranks."""
+        torch, dist = _dist()
+        t = torch.from_numpy(np.ascontiguousarray(values, dtype=np.int32)).to(_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.cpu().numpy()
+
+    def _local_live(self):
+        """[nlive, this rank's running data sets], fetched from the joint state once per iteration"""
+        if self._live is None:
+            self._live = np.asarray(self.joint.local.live_matrix())
+        return self._live
+
+    def _gather_columns(self, row):
+        return allgather_columns(np.asarray(row, dtype=np.float64)[None, :])[0]
+
+    def _select(self):
+        self._mine = np.flatnonzero((self._running >= self.lo) & (self._running < self.hi))   # places in the sampler's running list
+        #: (numpy sums a lone column pairwise, the columns of a wider matrix row by row: see _column_sums)
+        self.sums_row_by_row = len(self._mine) == 1 and len(self._running) > 1
+
+    @property
+    def ndata(self):
+        return len(self._mine)
+
+    def __getattr__(self, name):                                   # ndraws, nevals, native, ... of the whole sampler
+        return getattr(self.sampler, name)
+
+    def __next__(self):
+        u, x, L = next(self.sampler)
+        self._live = None
+        return u[self._mine], x[self._mine], np.asarray(L)[self._mine]
+
+    next = __next__
+
+    @property
+    def Lmax(self):
+        return self._local_live().max(axis=0)
+
+    def remainder_likelihoods(self):
+        return np.ascontiguousarray(np.sort(self._local_live(), axis=0))
+
+    def remainder_arrays(self, d):
+        """(u[nlive, ndim], x[nlive, ndim], L[nlive]) of this rank's d-th running data set, ascending."""
+        col = self._local_live()[:, d]
+        order = np.argsort(col)
+        p = self.sampler.live_pointsp[order, self._mine[d]]
+        return self.sampler.pointpile[p], self.sampler.pointpilex[p], col[order]
+
+    def cut_down(self, surviving):
+        """``surviving``: flags of this rank's running data sets; every rank calls it at every check."""
+        flags = np.ones(len(self._running), dtype=np.int32)
+        flags[self._mine] = np.asarray(surviving, dtype=np.int32)
+        # (a data set belongs to one rank: the others left their 1 there)
+        keep = self._min_over_ranks(flags).astype(bool)
+        if not keep.all():
+            self.sampler.cut_down(keep)
+            self._running = self._running[keep]
+            self._live = None
+            self._select()
+
+    def everybody_done(self, mine_done):
+        return bool(self._min_over_ranks(np.array([1 if mine_done else 0]))[0])
+
+    def gather(self, results):
+        """The ranks' per-data-set results side by side, in the order of the data sets (the blocks are
+        contiguous): ``logZ``, ``logZerr``, ``information`` of ALL data sets on every rank.  ``weights`` -- the
+        posterior samples, [iterations][u, x, L, w, mask] over this rank's columns -- stay where they are
+        (``columns`` says which)."""
+        out = dict(results)
+        for key in ("logZ", "logZerr", "information"):
+            out[key] = self._gather_columns(results[key])
+        out["columns"] = (self.lo, self.hi)
+        return out

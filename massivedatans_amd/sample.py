@@ -217,13 +217,58 @@ def run(x, y, nlive_points=400, nsuperset_draws=10, use_graph=False, max_samples
         fused = (backend is None or isinstance(backend, ShardedGaussLine)) and os.environ.get('MDNS_FUSED', '1') != '0'
     start = time.time()
     sampler = build_sampler(problem, nlive_points, nsuperset_draws, use_graph, seed, batched, fused)
-    results = multi_nested_integrator(tolerance=tolerance, multi_sampler=sampler,
-                                      min_samples=min_samples, max_samples=max_samples)
+    results = integrate(sampler, tolerance, min_samples, max_samples)
     if sampler.native is not None:
         # the cached second deviate of numpy's Gaussian generator travels with the stream the native
         # constrainers stepped: Python code that draws after the run sees the reference's numbers
         sampler.native.sync_gauss_to_numpy()
     return results, sampler, problem, time.time() - start
+
+
+class _TimedSampler(object):
+    """The sampler as the integrator sees it, with the time spent inside ``next`` added up (the rest of a
+    run is the integrator's own per-data-set work)."""
+
+    def __init__(self, sampler):
+        self.__dict__['_s'] = sampler
+        self.__dict__['seconds'] = 0.0
+
+    def __getattr__(self, name):
+        return getattr(self._s, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._s, name, value)
+
+    def __next__(self):
+        t0 = time.perf_counter()
+        try:
+            return next(self._s)
+        finally:
+            self.__dict__['seconds'] += time.perf_counter() - t0
+
+    next = __next__
+
+
+def integrate(sampler, tolerance, min_samples, max_samples):
+    """multi_nested_integrator over the sampler -- or, with the data sets spread over ranks (a
+    ShardedJointState), every rank over ITS columns (parallel.LocalColumns; MDNS_SHARD_INTEGRATION=0: every
+    rank over all of them): ``logZ``, ``logZerr``, ``information`` of all data sets on every rank, ``weights``
+    of the rank's own columns ``results['columns']``.  ``results['seconds']``: inside the sampler's ``next`` /
+    in the integration around it."""
+    joint = getattr(sampler, 'joint', None)
+    t0 = time.perf_counter()
+    if type(joint).__name__ == 'ShardedJointState' and os.environ.get('MDNS_SHARD_INTEGRATION', '1') != '0':
+        from .parallel import LocalColumns
+        view = LocalColumns(sampler)
+        timed = _TimedSampler(view)
+        results = view.gather(multi_nested_integrator(tolerance=tolerance, multi_sampler=timed,
+                                                      min_samples=min_samples, max_samples=max_samples))
+    else:
+        timed = _TimedSampler(sampler)
+        results = multi_nested_integrator(tolerance=tolerance, multi_sampler=timed,
+                                          min_samples=min_samples, max_samples=max_samples)
+    results['seconds'] = dict(sampler=timed.seconds, integration=time.perf_counter() - t0 - timed.seconds)
+    return results
 
 
 def save_results(prefix, results, sampler, duration, ndata):
@@ -241,7 +286,24 @@ def save_results(prefix, results, sampler, duration, ndata):
         L=numpy.array(L), w=numpy.array(w), mask=numpy.array(mask), ndraws=sampler.ndraws))
     with open(prefix + '.stats.json', 'w') as f:
         json.dump(dict(ndraws=int(sampler.ndraws), duration=duration, ndata=int(ndata), niter=len(w),
-                       nevals=int(sampler.nevals)), f, indent=4)
+                       nevals=int(sampler.nevals), seconds=results.get('seconds'),
+                       fill_seconds=getattr(sampler, 'fill_seconds', None)), f, indent=4)
+
+
+def write_outputs(prefix, results, sampler, duration, ndata):
+    """save_results for a run that may have been sharded; True on the rank that reports (rank 0)."""
+    first = int(os.environ.get('RANK', '0')) == 0
+    if 'columns' in results:
+        # the evidence integration was sharded: every rank writes the posterior samples of its own data sets
+        lo, hi = results['columns']
+        part = dict(results, logZ=results['logZ'][lo:hi], logZerr=results['logZerr'][lo:hi])
+        save_results('%s.cols%d-%d' % (prefix, lo, hi), part, sampler, duration, hi - lo)
+        if first:
+            from . import gen
+            gen.write_datasets(prefix + '.evidence.npz', dict(logZ=results['logZ'], logZerr=results['logZerr']))
+    elif first:
+        save_results(prefix, results, sampler, duration, ndata)         # every rank holds the same results
+    return first
 
 
 def distributed_setup():
@@ -311,10 +373,9 @@ def main(argv=None):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
-    if int(os.environ.get('RANK', '0')) != 0:
-        return                                     # every rank holds the same results; rank 0 writes
     prefix = '%s_%s_nlive%d_%d.out8' % (argv[1], constrainer_type, nlive_points, ndata)
-    save_results(prefix, results, sampler, duration, ndata)
+    if not write_outputs(prefix, results, sampler, duration, ndata):
+        return
     print('logZ = %.1f +- %.1f' % (results['logZ'][0], results['logZerr'][0]))
     print('ndraws:', sampler.ndraws, 'niter:', len(results['weights']), 'likelihood evals:', sampler.nevals,
           'in %.1f s' % duration)

@@ -79,6 +79,23 @@ def _worker(rank, world, port, q):
         ok &= np.random.uniform() == float(g["rng_probe"])
         check_bookkeeping(g, sampler, rec, res)
         check_floats(g, rec, res, rtol=0)
+        # the same again with the evidence integration sharded too (parallel.LocalColumns): every rank
+        # integrates its own columns from its own joint state, the ranks agree on finished data sets at
+        # every check, and the gathered evidences are the reference's, bit for bit
+        np.random.seed(1)
+        backend = parallel.ShardedGaussLine(d12["x"], d12["y"], lambda x, y: OracleSpectra(orc, x, y))
+        problem = sample.GaussLineProblem(d12["x"], d12["y"], backend=backend)
+        sampler = sample.build_sampler(problem, nlive_points=int(g["nlive"]), nsuperset_draws=int(g["nsuperset_draws"]),
+                                       use_graph=False, seed=1, batched=True, fused=True)
+        view = parallel.LocalColumns(sampler)
+        ok &= view.ndata == parallel.shard_range(12, rank, world)[1] - parallel.shard_range(12, rank, world)[0]
+        with np.errstate(all="ignore"):
+            res = view.gather(multi_nested_integrator(tolerance=0.5, multi_sampler=view, min_samples=0,
+                                                      max_samples=int(g["max_samples"])))
+        ok &= np.random.uniform() == float(g["rng_probe"])
+        for key in ("logZ", "logZerr", "information"):
+            ok &= np.array_equal(res[key], g[key])
+        ok &= res["columns"] == parallel.shard_range(12, rank, world) and len(res["weights"][0][2]) == view.joint.hi - view.joint.lo
         q.put((rank, bool(ok), lo, hi))
     finally:
         dist.destroy_process_group()
