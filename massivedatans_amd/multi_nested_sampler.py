@@ -895,6 +895,16 @@ class MultiNestedSampler(object):
         p = self.live_pointsp[order, d]
         return self.pointpile[p], self.pointpilex[p], self.live_pointsL[order, d]
 
+    def remainder_arrays_many(self, ds):
+        """``remainder_arrays`` of several running data sets at once: (u[nlive, n, ndim], x[nlive, n, ndim],
+        L[nlive, n]), every column in order of increasing likelihood (argsort column by column, as there)."""
+        ds = numpy.asarray(ds, dtype=int)
+        L = numpy.asarray(self.live_pointsL)[:, ds]
+        order = numpy.argsort(L, axis=0)
+        cols = numpy.arange(len(ds))[None, :]
+        p = numpy.asarray(self.live_pointsp)[:, ds][order, cols]
+        return self.pointpile[p], self.pointpilex[p], L[order, cols]
+
     def remainder_likelihoods(self):
         """The likelihoods of ``remainder()`` alone: [nlive, running data sets], every column ascending.
         C-contiguous like the array the integrator used to build from the rows: numpy adds up an

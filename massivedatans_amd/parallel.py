@@ -507,6 +507,14 @@ class LocalColumns(object):
         p = self.sampler.live_pointsp[order, self._mine[d]]
         return self.sampler.pointpile[p], self.sampler.pointpilex[p], col[order]
 
+    def remainder_arrays_many(self, ds):
+        ds = np.asarray(ds, dtype=int)
+        L = self._local_live()[:, ds]
+        order = np.argsort(L, axis=0)
+        cols = np.arange(len(ds))[None, :]
+        p = np.asarray(self.sampler.live_pointsp)[:, self._mine[ds]][order, cols]
+        return self.sampler.pointpile[p], self.sampler.pointpilex[p], L[order, cols]
+
     def cut_down(self, surviving):
         """``surviving``: flags of this rank's running data sets; every rank calls it at every check."""
         flags = np.ones(len(self._running), dtype=np.int32)

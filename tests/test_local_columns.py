@@ -91,6 +91,8 @@ class ThreadColumns(parallel.LocalColumns):
     def remainder_arrays(self, d):
         return self.sampler.remainder_arrays(self._mine[d])
 
+    remainder_arrays_many = None                                   # (the fake sampler has the one-by-one form only)
+
 
 @pytest.mark.parametrize("bounds", [[0, 5, 9, 14], [0, 1, 13, 14], [0, 14, 14, 14], [0, 7, 14]])
 def test_sharded_integration_equals_the_whole(bounds):
