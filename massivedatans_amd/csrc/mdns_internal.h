@@ -265,7 +265,14 @@ void note_kernel(int which, const char *fmt, ...);
 // XCD's whole L2, per workgroup that calls it (measured in round 4: a launch of 256 workgroups with two such
 // fences each took 365 us instead of 176; the folded K6 merge 264 us instead of 51).
 #ifdef __HIPCC__
-__device__ __forceinline__ void handover_release() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); }
+// (the workgroup-scope fence orders the compiler's view and emits no instruction; the wait is what makes the stores
+// and atomics of THIS wave complete -- acknowledged by memory -- before the ticket that follows: on gfx9 vmcnt counts
+// them too.  An agent-scope release fence is exactly `buffer_wbl2 sc1` + this wait.)
+__device__ __forceinline__ void handover_release()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 __device__ __forceinline__ void handover_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 // Into host memory mapped into the device, for a host that polls `seq`: system-scope stores act on that memory
 // itself, so `seq` only has to wait for the stores before it (every thread: mail_store()s, handover_release(), a

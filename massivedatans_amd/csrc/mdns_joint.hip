@@ -333,50 +333,80 @@ struct BandBox {                   // mapped host memory
 	double pair_L[kBandCap], pair_thr[kBandCap];
 };
 struct BandScratch {               // device memory
-	int counter, pad;
+	int counter, ticket;           // listed pairs; workgroups of the band pass that are done (zero between launches)
 	int clear[MDNS_JOINT_MAX_BATCH], maybe[MDNS_JOINT_MAX_BATCH];
 	int pair_b[kBandCap], pair_k[kBandCap];
 	double pair_L[kBandCap], pair_thr[kBandCap];
 };
 
-__global__ __launch_bounds__(kBlock) void k_joint_band(const double *__restrict__ L, const double *__restrict__ bound, int B, int M,
-                                                       const int *__restrict__ thr_rows, const double *__restrict__ higher,
-                                                       BandScratch *__restrict__ sc, JointHeader *__restrict__ header)
+// what the host needs of a band pass, into mapped memory (`seq` last), and the scratch ready for the next chunk:
+// by one workgroup that knows every vote is in (a kernel of its own behind the pass, or the pass's last workgroup)
+__device__ __forceinline__ void band_publish(BandScratch *__restrict__ sc, int B, BandBox *__restrict__ box, unsigned long long seq)
 {
-	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) header->status = 0;
-	const int k = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
-	if (k >= M) return;
-	const double v = L[(size_t) b * M + k];
-	const int d = thr_rows ? thr_rows[k] : k;
-	const double thr = higher[d];
-	const double band = 1.01 * bound[b] + 1e-12 * (fabs(v) + fabs(thr));
-	if (v > thr + band) sc->clear[b] = 1;
-	else if (v >= thr - band) {
-		sc->maybe[b] = 1;
-		const int at = atomicAdd(&sc->counter, 1);
-		if (at < kBandCap) { sc->pair_b[at] = b; sc->pair_k[at] = k; sc->pair_L[at] = v; sc->pair_thr[at] = thr; }
-	}
-}
-
-// one workgroup: what the host needs, into mapped memory (`seq` last), and the scratch ready for the next chunk
-__global__ __launch_bounds__(kBlock) void k_joint_band_publish(BandScratch *__restrict__ sc, int B, BandBox *__restrict__ box, unsigned long long seq)
-{
-	const int n = sc->counter;
+	const int n = __hip_atomic_load(&sc->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	const int m = n < kBandCap ? n : kBandCap;
 	for (int b = threadIdx.x; b < B; b += kBlock) {
-		mail_store(&box->status[b], sc->clear[b] ? 1 : (sc->maybe[b] ? 2 : 0));
+		const int cl = __hip_atomic_load(&sc->clear[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int mb = __hip_atomic_load(&sc->maybe[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		mail_store(&box->status[b], cl ? 1 : (mb ? 2 : 0));
 		sc->clear[b] = 0; sc->maybe[b] = 0;
 	}
 	for (int t = threadIdx.x; t < m; t += kBlock) {
-		mail_store(&box->pair_b[t], sc->pair_b[t]); mail_store(&box->pair_k[t], sc->pair_k[t]);
-		mail_store(&box->pair_L[t], sc->pair_L[t]); mail_store(&box->pair_thr[t], sc->pair_thr[t]);
+		mail_store(&box->pair_b[t], __hip_atomic_load(&sc->pair_b[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		mail_store(&box->pair_k[t], __hip_atomic_load(&sc->pair_k[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		mail_store(&box->pair_L[t], __hip_atomic_load(&sc->pair_L[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		mail_store(&box->pair_thr[t], __hip_atomic_load(&sc->pair_thr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 	}
 	handover_release();
 	__syncthreads();
 	if (threadIdx.x != 0) return;
 	sc->counter = 0;
+	sc->ticket = 0;
 	mail_store(&box->npairs, n);
 	mail_raise(&box->seq, seq);
+}
+
+// box != nullptr: the last workgroup to finish publishes (votes and pairs go through agent-scope stores: the
+// hand-over of mdns_internal.h) -- one launch less per chunk than k_joint_band_publish behind it
+__global__ __launch_bounds__(kBlock) void k_joint_band(const double *__restrict__ L, const double *__restrict__ bound, int B, int M,
+                                                       const int *__restrict__ thr_rows, const double *__restrict__ higher,
+                                                       BandScratch *__restrict__ sc, JointHeader *__restrict__ header,
+                                                       BandBox *__restrict__ box, unsigned long long seq)
+{
+	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) header->status = 0;
+	const int k = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
+	if (k < M) {
+		const double v = L[(size_t) b * M + k];
+		const int d = thr_rows ? thr_rows[k] : k;
+		const double thr = higher[d];
+		const double band = 1.01 * bound[b] + 1e-12 * (fabs(v) + fabs(thr));
+		if (v > thr + band) __hip_atomic_store(&sc->clear[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		else if (v >= thr - band) {
+			__hip_atomic_store(&sc->maybe[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			const int at = atomicAdd(&sc->counter, 1);
+			if (at < kBandCap) {
+				__hip_atomic_store(&sc->pair_b[at], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&sc->pair_k[at], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&sc->pair_L[at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				__hip_atomic_store(&sc->pair_thr[at], thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			}
+		}
+	}
+	if (!box) return;
+	__shared__ int s_last;
+	handover_release();
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = atomicAdd(&sc->ticket, 1) == (int) (gridDim.x * gridDim.y) - 1 ? 1 : 0;
+	__syncthreads();
+	if (!s_last) return;
+	handover_acquire();
+	band_publish(sc, B, box, seq);
+}
+
+// (behind the matrix-core filter, whose workgroups do not count themselves)
+__global__ __launch_bounds__(kBlock) void k_joint_band_publish(BandScratch *__restrict__ sc, int B, BandBox *__restrict__ box, unsigned long long seq)
+{
+	band_publish(sc, B, box, seq);
 }
 
 // k_joint_commit_dense for a candidate the HOST names, with its noise row added first
@@ -1635,9 +1665,9 @@ static int band_launch(mdns_joint *j, bool filtered)
 	} else {
 		if (mdns_muse3_loglike_batch_dev(j->s, d_p, B, d_rows, M, j->d_dense) != 0) return 1;
 		hipLaunchKernelGGL(k_joint_band, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream, (const double *) j->d_dense,
-		                   d_b, B, M, d_rows, (const double *) j->st.higher, j->d_band, (JointHeader *) j->d_result);
+		                   d_b, B, M, d_rows, (const double *) j->st.higher, j->d_band, (JointHeader *) j->d_result, j->h_band_dev, ++j->band_seq);
 	}
-	hipLaunchKernelGGL(k_joint_band_publish, dim3(1), dim3(kBlock), 0, c->stream, j->d_band, B, j->h_band_dev, ++j->band_seq);
+	if (filtered) hipLaunchKernelGGL(k_joint_band_publish, dim3(1), dim3(kBlock), 0, c->stream, j->d_band, B, j->h_band_dev, ++j->band_seq);
 	if (!MDNS_HIP(hipGetLastError())) return 1;
 	j->band_exact = !filtered;
 	return 0;

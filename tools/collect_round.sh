@@ -45,5 +45,17 @@ for p in 1 2 3; do MDNS_FILTER_PROBE=$p MDNS_K1_FILTER=mfma python tools/filter_
 python tools/k6_gy_sweep.py > "$out/k6_gy_sweep.log" 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_f64_probe.hip -o /tmp/mfma_probe 2>/dev/null && /tmp/mfma_probe > "$out/mfma_f64_probe.log" 2>&1
 hipcc --offload-arch=gfx950 -O3 tools/probes/valu_rate_probe.hip -o /tmp/valu_probe 2>/dev/null && /tmp/valu_probe > "$out/valu_rate_probe.log" 2>&1
+# round 4: the MUSE analysis end to end, the K2 matrix-core filter (round trips by shape, SQ / cache counters, the f64
+# matrix rate by occupancy), the two-rank rehearsal with the evidence integration sharded
+python tools/e2e_muse.py 6250 4096 40 600 > "$out/e2e_muse600.json" 2> "$out/e2e_muse600.err"
+for shape in "6250 4096 64" "6250 4096 32" "2000 4096 57" "700 4096 40" "6250 1000 64" "777 333 17"; do
+    python tools/k2_filter_bench.py $shape 20 2>&1 | tail -1
+done > "$out/k2_filter_bench.jsonl"
+tools/k2_filter_counters.sh "$tag/k2_counters" > "$out/k2_filter_counters.log" 2>&1 || echo "k2 counters failed"
+hipcc --offload-arch=gfx950 -O3 tools/probes/mfma_f64_occupancy.hip -o /tmp/mfma_occ 2>/dev/null && /tmp/mfma_occ > "$out/mfma_f64_occupancy.log" 2>&1
+tools/spmd_rehearsal.sh 25000 100 300 1 > "$out/spmd_rehearsal.log" 2>&1 || echo "rehearsal failed"
+rm -rf gpurun_out/spmd
+USE_GRAPH=1 python tools/e2e_run.py horns 100000 100 450 > "$out/e2e_c4_450_graph.json" 2> "$out/e2e_c4_450_graph.err"
+find "$out" -name "*.db" -delete
 du -sh "$out"
 echo collected "$out"
