@@ -424,6 +424,8 @@ extern "C" void mdns_spectra_destroy(mdns_spectra *s)
 	void *bufs[] = {s->d_y, s->d_yT, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out, s->d_sel, s->d_ysq};
 	for (void *b : bufs) if (b) (void) hipFree(b);
 	if (s->d_fyw) (void) hipFree(s->d_fyw);
+	if (s->d_fyw_t) (void) hipFree(s->d_fyw_t);
+	if (s->d_fw_t) (void) hipFree(s->d_fw_t);
 	if (s->d_fa) (void) hipFree(s->d_fa);
 	if (s->d_fw && s->fw_owned) (void) hipFree(s->d_fw);
 	delete s;

@@ -59,6 +59,7 @@ struct mdns_spectra {
 	// K2 on the matrix cores (mdns_k2gemm.hip), made on first use: y w and w [ndata, ldf] with ldf = nx rounded
 	// up to 16 (zero padded; d_fw is d_w itself when the strides agree), A = sum y^2 w [ndata]
 	double *d_fyw = nullptr, *d_fw = nullptr, *d_fa = nullptr;
+	double *d_fyw_t = nullptr, *d_fw_t = nullptr;       // the same two in tiles of 16 rows (mdns_k2gemm.hip, tiled_at)
 	int ldf = 0;
 	bool fw_owned = false;
 };

@@ -27,13 +27,20 @@
 namespace mdns {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double4_t k2_join(double2_t a, double2_t b) { return double4_t{a[0], a[1], b[0], b[1]}; }
 // the spectrum operands are read once per launch: past the caches' replacement (the templates are re-read by everybody)
 #define K2_ROWLOAD(p) __builtin_nontemporal_load(p)
 
-// one workgroup per spectrum: y w and w, zero padded to ldf channels, and A = sum y^2 w
+// element (row r, channel c) of a TILED operand: tiles of 16 rows, inside a tile channel pair by channel pair,
+// 16 rows x 2 doubles each -- so that the 16 lanes of a quarter wave, which hold the same channels of 16
+// different rows, read 256 contiguous bytes (row-major they make 16 requests of 16 bytes each)
+__host__ __device__ inline size_t tiled_at(size_t r, int c, int ncp) { return (((r >> 4) * (size_t) ncp + (size_t) (c >> 1)) << 5) + ((r & 15) << 1) + (size_t) (c & 1); }
+
+// one workgroup per spectrum: y w and w, zero padded to ldf channels, row-major and tiled, and A = sum y^2 w
 __global__ __launch_bounds__(256) void k_muse_filter_prepare(const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
                                                             double *__restrict__ YW, double *__restrict__ WF, int ldf,
-                                                            double *__restrict__ A)
+                                                            double *__restrict__ YWt, double *__restrict__ Wt, double *__restrict__ A)
 {
 	__shared__ double part[4];
 	const size_t r = blockIdx.x;
@@ -42,13 +49,23 @@ __global__ __launch_bounds__(256) void k_muse_filter_prepare(const double *__res
 		const double y = j < nx ? Y[r * ld + j] : 0.0, w = j < nx ? W[r * ld + j] : 0.0;
 		const double yw = y * w;
 		YW[r * ldf + j] = yw;
-		if (WF) WF[r * ldf + j] = w;
+		WF[r * ldf + j] = w;
+		YWt[tiled_at(r, j, ldf >> 1)] = yw;
+		Wt[tiled_at(r, j, ldf >> 1)] = w;
 		acc = fma(y, yw, acc);
 	}
 	for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
 	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
 	__syncthreads();
 	if (threadIdx.x == 0) A[r] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+
+// templates [B][ldm] -> tiled (16 candidates per tile; the candidates past B of the last tile stay as they are:
+// a column of the product depends on its own operand column only, and nobody looks at theirs)
+__global__ void k_muse_tile_templates(const double *__restrict__ model, int ldm, int B, int ldf, double *__restrict__ Mt)
+{
+	const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < ldf) Mt[tiled_at((size_t) b, j, ldf >> 1)] = model[(size_t) b * ldm + j];
 }
 
 // lane l holds A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16], D[i = 4 v + l / 16][j = l % 16] in its v-th
@@ -147,7 +164,7 @@ __global__ __launch_bounds__(64 * KW) void k_muse_gemm_band(
 // tests the tile and leaves the count at zero for the next launch.  (Adding the pieces into one scratch tile
 // with f64 atomics measured 365 us against 221 for whole tiles, 6250 x 4096 x 64: 1.6 million device-scope
 // atomics.)
-template <int NC>
+template <int NC, bool TILED>
 __global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
     const double *__restrict__ YW, const double *__restrict__ WF, int ldf, const double *__restrict__ A,
     const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M, int bt,
@@ -173,14 +190,18 @@ __global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
 		u += g1 - g0;
 		const int k0 = (tile / bt) * 16, b0 = (tile % bt) * 16 * NC;
 		for (int t = threadIdx.x; t < NE; t += 64 * KW) red[t] = 0.0;
+		// TILED (the whole set of spectra, rows == nullptr): YW, WF and model are the tiled replicas, a lane's four
+		// channels of a group are two pairs 256 bytes apart, and a quarter wave reads 256 contiguous bytes
 		const int krow = k0 + i < M ? k0 + i : M - 1;
 		const size_t r = rows ? rows[krow] : krow;
-		const double *pyw = YW + r * ldf + 4 * q, *pw = WF + r * ldf + 4 * q;
+		const int ncp = ldf >> 1;
+		const double *pyw = TILED ? YW + (((size_t) (tile / bt) * ncp + 2 * q) << 5) + 2 * i : YW + r * ldf + 4 * q;
+		const double *pw = TILED ? WF + (((size_t) (tile / bt) * ncp + 2 * q) << 5) + 2 * i : WF + r * ldf + 4 * q;
 		const double *pm[NC];
 #pragma unroll
 		for (int c = 0; c < NC; c++) {
 			const int b = b0 + 16 * c + i < B ? b0 + 16 * c + i : B - 1;
-			pm[c] = model + (size_t) b * ldm + 4 * q;
+			pm[c] = TILED ? model + (((size_t) ((b0 >> 4) + c) * ncp + 2 * q) << 5) + 2 * i : model + (size_t) b * ldm + 4 * q;
 		}
 		double4_t acc1[NC], acc2[NC];
 #pragma unroll
@@ -188,14 +209,20 @@ __global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
 		double4_t yw[2], w[2], m[2][NC];
 		// whole rounds of both register sets, straight-line: a group past the end of the stretch takes its spectrum
 		// operands from 16 zeros (and any template), so the loads in flight can be counted and waited for one set at a time
+#define K2_PTR(P, O) (TILED ? (P) + ((O) << 4) : (P) + (O))
+#define K2_LOAD4(PTR) (TILED ? k2_join(K2_ROWLOAD(reinterpret_cast<const double2_t *>(PTR)), K2_ROWLOAD(reinterpret_cast<const double2_t *>((PTR) + 32))) \
+                             : K2_ROWLOAD(reinterpret_cast<const double4_t *>(PTR)))
+#define K2_TLOAD4(PTR) (TILED ? k2_join(*reinterpret_cast<const double2_t *>(PTR), *reinterpret_cast<const double2_t *>((PTR) + 32)) \
+                              : *reinterpret_cast<const double4_t *>(PTR))
 #define K2_FETCH(SET, G) { \
 		const bool ok_ = (G) < g1; \
 		const size_t o_ = (size_t) (ok_ ? (G) : g1 - 1) << 4; \
-		yw[SET] = K2_ROWLOAD(reinterpret_cast<const double4_t *>(ok_ ? pyw + o_ : zr)); \
-		w[SET] = K2_ROWLOAD(reinterpret_cast<const double4_t *>(ok_ ? pw + o_ : zr)); \
-		_Pragma("unroll") for (int c = 0; c < NC; c++) m[SET][c] = *reinterpret_cast<const double4_t *>(pm[c] + o_); }
+		const double *a_ = ok_ ? K2_PTR(pyw, o_) : zr, *b_ = ok_ ? K2_PTR(pw, o_) : zr; \
+		yw[SET] = K2_LOAD4(a_); \
+		w[SET] = K2_LOAD4(b_); \
+		_Pragma("unroll") for (int c = 0; c < NC; c++) { const double *t_ = K2_PTR(pm[c], o_); m[SET][c] = K2_TLOAD4(t_); } }
 		// (the squares first, all of them: a multiplication waiting for the square made just before it held up the
-		// matrix pipe -- the multiplications alone took 153 us of the 176 with the squares in between)
+		// matrix pipe)
 #define K2_BODY(SET) { \
 		double4_t m2[NC]; \
 		_Pragma("unroll") for (int c = 0; c < NC; c++) m2[c] = m[SET][c] * m[SET][c]; \
@@ -234,6 +261,9 @@ __global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
 		}
 #undef K2_BODY
 #undef K2_FETCH
+#undef K2_LOAD4
+#undef K2_TLOAD4
+#undef K2_PTR
 		__syncthreads();                                                  // (the zeros are in place)
 		if (g0 + wave < g1) {
 #pragma unroll
@@ -309,15 +339,16 @@ __global__ __launch_bounds__(512) void k_muse_gemm_band_sk(
 }
 
 // scratch tiles and delivery counts of the stream-K form: grow-only, zero whenever no launch is in flight
-static double *g_sk_scratch = nullptr, *g_sk_zeros = nullptr;
+static double *g_sk_scratch = nullptr, *g_sk_zeros = nullptr, *g_sk_templ = nullptr;
+static size_t g_sk_templ_cap = 0;
 static unsigned *g_sk_delivered = nullptr;
 static size_t g_sk_tiles = 0, g_sk_doubles = 0;
 
 static bool sk_reserve(size_t tiles, size_t doubles)
 {
 	Context *c = ctx();
-	if (!g_sk_zeros && (!MDNS_HIP(hipMalloc((void **) &g_sk_zeros, 16 * sizeof(double))) ||
-	                    !MDNS_HIP(hipMemsetAsync(g_sk_zeros, 0, 16 * sizeof(double), c->stream)))) return false;
+	if (!g_sk_zeros && (!MDNS_HIP(hipMalloc((void **) &g_sk_zeros, 64 * sizeof(double))) ||
+	                    !MDNS_HIP(hipMemsetAsync(g_sk_zeros, 0, 64 * sizeof(double), c->stream)))) return false;
 	if (tiles > g_sk_tiles) {
 		if (g_sk_delivered) { (void) hipStreamSynchronize(c->stream); (void) hipFree(g_sk_delivered); g_sk_delivered = nullptr; g_sk_tiles = 0; }
 		const size_t want = tiles + tiles / 2 + 64;
@@ -366,20 +397,20 @@ bool muse_filter_prepare(mdns_spectra *s)
 	if (s->d_fyw) return true;
 	Context *c = ctx();
 	const int ldf = muse_filter_ld(s->nx);
-	const size_t elems = (size_t) s->ndata * ldf;
-	double *yw = nullptr, *wf = nullptr, *a = nullptr;
-	if (!MDNS_HIP(hipMalloc((void **) &yw, (elems ? elems : 1) * sizeof(double))) ||
-	    !MDNS_HIP(hipMalloc((void **) &a, (size_t) (s->ndata ? s->ndata : 1) * sizeof(double))) ||
-	    !MDNS_HIP(hipMalloc((void **) &wf, (elems ? elems : 1) * sizeof(double)))) {
-		if (yw) (void) hipFree(yw);
-		if (a) (void) hipFree(a);
-		return false;
-	}
-	if (s->ndata > 0)
+	const size_t elems = (size_t) s->ndata * ldf, telems = (size_t) ((s->ndata + 15) / 16) * 16 * ldf;
+	double *buf[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};      // y w, w (row-major), y w, w (tiled), A
+	const size_t want[5] = {elems, elems, telems, telems, (size_t) s->ndata};
+	bool ok = true;
+	for (int t = 0; t < 5 && ok; t++) ok = MDNS_HIP(hipMalloc((void **) &buf[t], (want[t] ? want[t] : 1) * sizeof(double)));
+	// (the rows past the last one of the last tile multiply as zeros)
+	for (int t = 2; t < 4 && ok; t++) ok = MDNS_HIP(hipMemsetAsync(buf[t], 0, (telems ? telems : 1) * sizeof(double), c->stream));
+	if (ok && s->ndata > 0) {
 		hipLaunchKernelGGL(k_muse_filter_prepare, dim3(s->ndata), dim3(256), 0, c->stream, (const double *) s->d_y, (const double *) s->d_w,
-		                   s->ld, s->nx, yw, wf, ldf, a);
-	if (!MDNS_HIP(hipGetLastError())) { (void) hipFree(yw); (void) hipFree(a); (void) hipFree(wf); return false; }
-	s->d_fyw = yw; s->d_fw = wf; s->fw_owned = true; s->d_fa = a; s->ldf = ldf;
+		                   s->ld, s->nx, buf[0], buf[1], ldf, buf[2], buf[3], buf[4]);
+		ok = MDNS_HIP(hipGetLastError());
+	}
+	if (!ok) { for (double *b : buf) if (b) (void) hipFree(b); return false; }
+	s->d_fyw = buf[0]; s->d_fw = buf[1]; s->fw_owned = true; s->d_fyw_t = buf[2]; s->d_fw_t = buf[3]; s->d_fa = buf[4]; s->ldf = ldf;
 	muse_filter_note(3);
 	return true;
 }
@@ -408,13 +439,30 @@ bool launch_muse_filter(mdns_spectra *s, const double *d_model, int ldm, int B, 
 		static const char *p_forced = getenv("MDNS_K2_FILTER_P");        // experiments only; 0: one per tile
 		if (p_forced) { const long long f = atoll(p_forced); P = f > 0 ? f : tiles; }
 		if (!sk_reserve((size_t) tiles, (size_t) P * 2 * nc * 512)) return false;
-		note_kernel(1, "k_muse_gemm_band_sk<%d>", nc);
-#define K2_SK(NC) hipLaunchKernelGGL((k_muse_gemm_band_sk<NC>), dim3((unsigned) P), dim3(512), 0, c->stream, \
-		(const double *) s->d_fyw, (const double *) s->d_fw, s->ldf, (const double *) s->d_fa, d_model, ldm, B, d_rows, M, bt, d_higher, d_bound, gamma, out, \
-		g_sk_scratch, g_sk_delivered, (const double *) g_sk_zeros)
+		// the whole set of spectra in its stored order: tiled operands (every load of a quarter wave contiguous);
+		// the templates are tiled on the way (2 MB: one more small launch)
+		static const char *tiled_forced = getenv("MDNS_K2_FILTER_TILED");    // "0": row-major operands always (experiments)
+		const bool tiled = !d_rows && M == s->ndata && !(tiled_forced && tiled_forced[0] == '0');
+		const double *d_templ = d_model;
+		if (tiled) {
+			const size_t need = (size_t) bt * nc * 16 * s->ldf;
+			if (need > g_sk_templ_cap) {
+				if (g_sk_templ) { (void) hipStreamSynchronize(c->stream); (void) hipFree(g_sk_templ); g_sk_templ = nullptr; g_sk_templ_cap = 0; }
+				if (!MDNS_HIP(hipMalloc((void **) &g_sk_templ, (need + need / 2) * sizeof(double)))) return false;
+				if (!MDNS_HIP(hipMemsetAsync(g_sk_templ, 0, (need + need / 2) * sizeof(double), c->stream))) return false;
+				g_sk_templ_cap = need + need / 2;
+			}
+			hipLaunchKernelGGL(k_muse_tile_templates, dim3((s->ldf + 255) / 256, B), dim3(256), 0, c->stream, d_model, ldm, B, s->ldf, g_sk_templ);
+			d_templ = g_sk_templ;
+		}
+		note_kernel(1, tiled ? "k_muse_gemm_band_sk<%d, tiled>" : "k_muse_gemm_band_sk<%d>", nc);
+#define K2_SK(NC, T) hipLaunchKernelGGL((k_muse_gemm_band_sk<NC, T>), dim3((unsigned) P), dim3(512), 0, c->stream, \
+		(const double *) (T ? s->d_fyw_t : s->d_fyw), (const double *) (T ? s->d_fw_t : s->d_fw), s->ldf, (const double *) s->d_fa, d_templ, ldm, B, d_rows, M, bt, \
+		d_higher, d_bound, gamma, out, g_sk_scratch, g_sk_delivered, (const double *) g_sk_zeros)
 		{
 			ProfileScope prof(1);
-			if (nc == 4) K2_SK(4); else if (nc == 2) K2_SK(2); else K2_SK(1);
+			if (tiled) { if (nc == 4) K2_SK(4, true); else if (nc == 2) K2_SK(2, true); else K2_SK(1, true); }
+			else { if (nc == 4) K2_SK(4, false); else if (nc == 2) K2_SK(2, false); else K2_SK(1, false); }
 		}
 #undef K2_SK
 		if (!MDNS_HIP(hipGetLastError())) return false;

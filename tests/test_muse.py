@@ -34,7 +34,7 @@ def _run(g, backend, fused, native, jitter=True):
 
 
 @pytest.mark.parametrize("case", ["muse6", "muse10_graph"])
-@pytest.mark.parametrize("mode", ["single", "native", "native-block", "native-far-ahead", "native-not-ahead"])
+@pytest.mark.parametrize("mode", ["single", "native", "native-block", "native-far-ahead", "native-not-ahead", "native-threads"])
 def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
     """``single``: one candidate per likelihood call, the noise from numpy.random.normal -- the
     reference's loop.  ``native``: whole chunks, the noise drawn in C from numpy's own Mersenne
@@ -51,6 +51,14 @@ def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
         monkeypatch.setenv("MDNS_JITTER_BAND", "0")
         mode = "native"
     ahead = None
+    if mode == "native-threads":
+        # the blocks of the noise stream made by two helper threads ahead of the scan (host_constrainer.cpp,
+        # BlockProducer; opt-in): the blocks are a function of the stream alone, so the same trace
+        if case != "muse6":
+            pytest.skip("on the short trace only")
+        monkeypatch.setenv("MDNS_BAND_THREADS", "1")
+        monkeypatch.setenv("MDNS_BAND_READY_AFTER", "40")
+        mode = "native"
     if mode in ("native-far-ahead", "native-not-ahead"):
         # the bounds of the candidates that follow a chunk in its batch are made while the chunk is scored
         # (band_chunk, BandLook): as far as the batch goes / not at all -- the same trace either way
