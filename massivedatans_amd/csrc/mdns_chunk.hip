@@ -381,6 +381,101 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_filter(
 	if (lane == 0 && best != 0x7fffffff) atomicMax(lowest, B - best);
 }
 
+// The same filter with BOTH operands read straight from memory into the registers the instruction wants (round 4;
+// what took K2's filter from 183 to 140 us): the channel-major replica in tiles of 64 spectra and the templates in
+// tiles of 16 candidates are both laid out so that the 16 lanes of a quarter wave -- one channel of 16 neighbouring
+// spectra / candidates -- read 128 contiguous bytes.  No LDS, no barrier per chunk of channels; a wave owns
+// 16 spectra x 16 NC candidates (A = spectra, B = candidates), the four waves of a workgroup share the spectra (L1).
+// Channels past nxp come from 16 zeros.
+template <int NC>
+__global__ __launch_bounds__(256) void k_gauss_mfma_direct(
+    const double *__restrict__ YT, int nxp, int nx, const double *__restrict__ model_t, const double *__restrict__ msq, int B,
+    double scale, const int *__restrict__ thr_rows, int M, int nbt,
+    const double *__restrict__ higher, const double *__restrict__ ysq, int *__restrict__ flags, int *__restrict__ ambiguous,
+    int stamp, int *__restrict__ lowest, const double *__restrict__ zeros)
+{
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+	const int i = lane & 15, q = lane >> 4;
+	const int first = blockIdx.x * 16;                                    // first spectrum (place in the selection)
+	const int ct0 = (blockIdx.y * 4 + wave) * NC;                         // first candidate tile of this wave
+	if (ct0 >= nbt) return;                                               // whole waves
+	const int sp = first + i;                                             // (a spectrum past M reads the replica's zero padding)
+	const double *pa = YT + ((size_t) (sp >> 6) * nxp << 6) + (sp & 63);
+	const double *pb[NC];
+#pragma unroll
+	for (int c = 0; c < NC; c++) pb[c] = model_t + (size_t) (ct0 + c < nbt ? ct0 + c : nbt - 1) * nxp * 16 + i;
+	double4_t acc[NC];
+#pragma unroll
+	for (int c = 0; c < NC; c++) acc[c] = double4_t{0, 0, 0, 0};
+	const int ng = (nxp + 15) >> 4;
+	double a[2][4], b[2][NC][4];
+#define GD_FETCH(SET, G) { \
+	const int g_ = (G) < ng ? (G) : ng - 1; \
+	_Pragma("unroll") for (int t = 0; t < 4; t++) { \
+		const int ch = 16 * g_ + 4 * q + t; \
+		const bool in = ch < nxp && (G) < ng; \
+		a[SET][t] = *(in ? pa + ((size_t) ch << 6) : zeros + i); \
+		const int cb = ch < nxp ? ch : nxp - 1; \
+		_Pragma("unroll") for (int c = 0; c < NC; c++) b[SET][c][t] = pb[c][(size_t) cb << 4]; \
+	} }
+#define GD_BODY(SET) { \
+	__builtin_amdgcn_sched_barrier(0); \
+	_Pragma("unroll") for (int t = 0; t < 4; t++) \
+		_Pragma("unroll") for (int c = 0; c < NC; c++) \
+			acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][t], b[SET][c][t], acc[c], 0, 0, 0); \
+	__builtin_amdgcn_sched_barrier(0); }
+	GD_FETCH(0, 0)
+#pragma unroll 1
+	for (int g = 0; g < ng; g += 2) {
+		GD_FETCH(1, g + 1)
+		GD_BODY(0)
+		GD_FETCH(0, g + 2)
+		GD_BODY(1)
+	}
+#undef GD_BODY
+#undef GD_FETCH
+	// votes: lane (i, q) holds, of candidate tile c, candidate 16 (ct0 + c) + i for the spectra first + 4 v + q
+	const double unit = fabs(scale) * (double) (nx + 8) * 0x1p-52;
+	double thr[4], yy[4];
+#pragma unroll
+	for (int v = 0; v < 4; v++) {
+		const int k = first + 4 * v + q;
+		const bool live = k < M;
+		const int kk = live ? k : M - 1;
+		const int d = thr_rows ? thr_rows[kk] : kk;
+		thr[v] = live ? higher[d] : __builtin_nan("");                    // NaN compares false: no vote
+		yy[v] = ysq[d];
+	}
+	int best = 0x7fffffff;                                                // lowest clearly accepted candidate of this wave
+#pragma unroll
+	for (int c = 0; c < NC; c++) {
+		const int cand = (ct0 + c) * 16 + i;
+		const bool valid = ct0 + c < nbt && cand < B;
+		const double mm = msq[valid ? cand : 0];
+		bool hit = false, maybe = false;
+#pragma unroll
+		for (int v = 0; v < 4; v++) {
+			const double S = acc[c][v];
+			const double Lf = scale * ((mm - 2.0 * S) + yy[v]);
+			const double E4 = 4.0 * unit * ((mm + 2.0 * fabs(S)) + yy[v]);
+			const bool h = valid && Lf > thr[v] + E4;
+			hit = hit || h;
+			maybe = maybe || (valid && !h && Lf >= thr[v] - E4);
+		}
+		// a candidate's four lanes (q = 0..3) are 16 apart
+		const unsigned long long hm = __ballot(hit), mb = __ballot(maybe);
+		if (lane < 16) {
+			const unsigned long long mine = 0x0001000100010001ull << lane;
+			if (hm & mine) { flags[cand] = 1; best = cand < best ? cand : best; }
+			else if (mb & mine) ambiguous[cand] = stamp;                      // (never cleared: stamped with the call)
+		}
+	}
+	// lowest accepted candidate of the wave (lanes 0..15 hold one each)
+#pragma unroll
+	for (int off = 8; off > 0; off >>= 1) { const int o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+	if (lane == 0 && best != 0x7fffffff) atomicMax(lowest, B - best);
+}
+
 // The chain's own sums for the candidates the filter could not settle -- the ambiguous ones below
 // the lowest clear vote -- and for that one itself (its likelihoods are wanted): votes (flags) and
 // the trail of likelihoods, exactly as the chain accept kernels leave them.  Every workgroup (one
@@ -570,6 +665,22 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 		// instruction sustains alone (69.7 TFLOP/s) on perfectly balanced SIMDs.
 		static const char *probe = getenv("MDNS_FILTER_PROBE");
 		const int pr = probe ? atoi(probe) : 0;
+		static const char *form = getenv("MDNS_K1_FILTER_FORM");           // "lds": the staged form of round 3
+		if (pr == 0 && !(form && form[0] == 'l')) {
+			static double *d_zeros = nullptr;
+			if (!d_zeros && (!MDNS_HIP(hipMalloc((void **) &d_zeros, 16 * sizeof(double))) ||
+			                 !MDNS_HIP(hipMemsetAsync(d_zeros, 0, 16 * sizeof(double), c->stream)))) return false;
+			const int nc = nbt >= 16 ? 4 : (nbt >= 8 ? 2 : 1);                // candidate tiles per wave
+			const int gy = (nbt + 4 * nc - 1) / (4 * nc);
+			ProfileScope prof(0);
+			note_kernel(0, "k_gauss_mfma_direct<%d>", nc);
+#define GD_LAUNCH(NC) hipLaunchKernelGGL((k_gauss_mfma_direct<NC>), dim3((M + 15) / 16, gy), dim3(256), 0, c->stream, \
+			d_yT, nxp, s->nx, d_model_t, d_msq, B, scale, d_thr_rows, M, nbt, d_higher, (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest, \
+			(const double *) d_zeros)
+			if (nc == 4) GD_LAUNCH(4); else if (nc == 2) GD_LAUNCH(2); else GD_LAUNCH(1);
+#undef GD_LAUNCH
+			if (!launched("k_gauss_mfma_direct")) return false;
+		} else {
 		const int nspec = (M + 31) / 32;
 		const int ngroups = (nbt + 3) / 4;
 		const int blocks = 8 * ((nspec + 7) / 8) * ngroups;
@@ -594,6 +705,7 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 		}
 #undef MFMA_LAUNCH
 		if (!launched("k_gauss_mfma_filter")) return false;
+		}
 	}
 	const size_t lds = ((size_t) nxp * 4 + 4) * sizeof(double);
 	const int nst = nxp / kCH;
