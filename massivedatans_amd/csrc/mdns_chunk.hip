@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_filter(
 }
 
 // The same filter with BOTH operands read straight from memory into the registers the instruction wants (round 4;
-// what took K2's filter from 183 to 140 us): the channel-major replica in tiles of 64 spectra and the templates in
+// what took K2's filter from 183 to 140 us; here it did NOT pay -- see launch_gauss_mfma_filter -- opt-in): the channel-major replica in tiles of 64 spectra and the templates in
 // tiles of 16 candidates are both laid out so that the 16 lanes of a quarter wave -- one channel of 16 neighbouring
 // spectra / candidates -- read 128 contiguous bytes.  No LDS, no barrier per chunk of channels; a wave owns
 // 16 spectra x 16 NC candidates (A = spectra, B = candidates), the four waves of a workgroup share the spectra (L1).
@@ -665,8 +665,12 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 		// instruction sustains alone (69.7 TFLOP/s) on perfectly balanced SIMDs.
 		static const char *probe = getenv("MDNS_FILTER_PROBE");
 		const int pr = probe ? atoi(probe) : 0;
-		static const char *form = getenv("MDNS_K1_FILTER_FORM");           // "lds": the staged form of round 3
-		if (pr == 0 && !(form && form[0] == 'l')) {
+		// MDNS_K1_FILTER_FORM=direct: both operands straight from memory (k_gauss_mfma_direct).  Measured at 10 000 x 256:
+		// 40.5 / 38.7 us against 34.4 / 31.8 staged through LDS; 50 000 x 256: 140.9 against 128.9 -- twenty 8-byte loads
+		// per lane and 16 multiplications (the layouts give a lane one channel per load) cost more than the barriers
+		// they save.  Not the default.
+		static const char *form = getenv("MDNS_K1_FILTER_FORM");
+		if (pr == 0 && form && form[0] == 'd') {
 			static double *d_zeros = nullptr;
 			if (!d_zeros && (!MDNS_HIP(hipMalloc((void **) &d_zeros, 16 * sizeof(double))) ||
 			                 !MDNS_HIP(hipMemsetAsync(d_zeros, 0, 16 * sizeof(double), c->stream)))) return false;
