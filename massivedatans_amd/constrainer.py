@@ -197,7 +197,9 @@ def hip_backend(joint):
             be.draw_band_begin = C.cast(lib.mdns_backend_draw_band_begin, _DRAW_BAND_BEGIN)
             be.draw_band_ready = C.cast(lib.mdns_backend_draw_band_ready, _DRAW_BAND_READY)
             be.draw_band_end = C.cast(lib.mdns_backend_draw_band_end, _DRAW_BAND_END)
-    if os.environ.get("MDNS_CHAIN", "1") != "0" and joint_kind_gauss(joint):
+    # (a state of the scale-marginalised likelihood chains K6 -> proposals -> membership counts only: its first chunk
+    # needs the noise bounds, which the host makes)
+    if os.environ.get("MDNS_CHAIN", "1") != "0":
         be.chain_begin = C.cast(lib.mdns_backend_chain_begin, _CHAIN_BEGIN)
         be.chain_end = C.cast(lib.mdns_backend_chain_end, _CHAIN_END)
     be._keep = joint
