@@ -73,6 +73,8 @@ def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
         from massivedatans_amd import constrainer
         if not constrainer.available():
             pytest.skip("libmdns_host.so not built")
+    if mode == "single" and case != "muse6" and os.environ.get("MDNS_LONG_TESTS") != "1":
+        pytest.skip("one Python call per likelihood evaluation on the longer trace: with MDNS_LONG_TESTS=1")
     if mode == "single" and int(g["ndraws"]) > 400000:
         pytest.skip("one Python call per likelihood evaluation: hours")
     patch_neighbors(monkeypatch, oracle)
@@ -83,7 +85,6 @@ def test_muse_trace_bit_exact(case, mode, oracle, monkeypatch):
     check_floats(g, rec, results, rtol=0)
     assert probe == float(g["rng_probe"])
     if mode == "native":
-        import os
         st = sampler.native.stats()
         assert (st["band_pairs"] + st["band_replays"] > 0) == (os.environ.get("MDNS_JITTER_BAND", "1") != "0") or st["band_pairs"] == 0
         if os.environ.get("MDNS_JITTER_BAND", "1") != "0":

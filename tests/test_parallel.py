@@ -52,17 +52,20 @@ def _worker(rank, world, port, q):
         from tracing import Recorder, check_bookkeeping, check_floats, load_trace
         g = load_trace("horns12")
         d12 = gen.horns(12)
-        backend = parallel.ShardedGaussLine(d12["x"], d12["y"], lambda x, y: OracleSpectra(orc, x, y))
-        problem = sample.GaussLineProblem(d12["x"], d12["y"], backend=backend)
-        sampler = sample.build_sampler(problem, nlive_points=int(g["nlive"]), nsuperset_draws=int(g["nsuperset_draws"]),
-                                       use_graph=False, seed=1, batched=True)
-        rec = Recorder(sampler)
-        with np.errstate(all="ignore"):
-            res = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0,
-                                          max_samples=int(g["max_samples"]))
-        ok &= np.random.uniform() == float(g["rng_probe"])
-        check_bookkeeping(g, sampler, rec, res)
-        check_floats(g, rec, res, rtol=0)
+        if os.environ.get("MDNS_LONG_TESTS") == "1":
+            # (the classic form -- likelihood columns all-gathered per call, Python constrainer -- is the slow third
+            # of this test: with MDNS_LONG_TESTS=1)
+            backend = parallel.ShardedGaussLine(d12["x"], d12["y"], lambda x, y: OracleSpectra(orc, x, y))
+            problem = sample.GaussLineProblem(d12["x"], d12["y"], backend=backend)
+            sampler = sample.build_sampler(problem, nlive_points=int(g["nlive"]), nsuperset_draws=int(g["nsuperset_draws"]),
+                                           use_graph=False, seed=1, batched=True)
+            rec = Recorder(sampler)
+            with np.errstate(all="ignore"):
+                res = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0,
+                                              max_samples=int(g["max_samples"]))
+            ok &= np.random.uniform() == float(g["rng_probe"])
+            check_bookkeeping(g, sampler, rec, res)
+            check_floats(g, rec, res, rtol=0)
         # the same with the joint state sharded (parallel.ShardedJointState over per-rank numpy
         # states): per draw chunk the ranks exchange B accept flags (MAX all-reduce) and the
         # accepted candidate's block -- not L[B, M] -- and still reproduce the reference trace
