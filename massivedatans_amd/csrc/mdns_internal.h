@@ -143,8 +143,11 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
                               const double *d_msq, const JointTrail &trail, int *d_lowest, int *d_scratch, void *d_header);
 // first flagged candidate from the trail of the accept pass: fill bits, shelf appends, thresholds
 // (flag_value: what the accept pass wrote into d_flags for an accepted candidate)
+// box_dev != nullptr: the kernel's last workgroup also fills the mailbox (no k_joint_publish behind it); d_ticket: an int, zero
+// between launches
 bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,
-                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits, int flag_value = 1);
+                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits, int flag_value = 1,
+                               void *box_dev = nullptr, unsigned long long seq = 0, int *d_ticket = nullptr);
 // first flagged candidate: its likelihood row, fill bits, shelf appends, new thresholds
 bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int mstride, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M, const int *d_flags,

@@ -531,6 +531,7 @@ struct mdns_joint {
 	ChainBox *h_chain = nullptr, *h_chain_dev = nullptr;   // mapped
 	double *d_chain_props = nullptr;
 	int *d_chain_counts = nullptr, *d_chain_ticket = nullptr;
+	int *d_commit_ticket = nullptr;    // workgroups of a commit pass that are done (k_joint_commit_trail publishing by itself)
 	// the likelihood noise in band form (mdns_backend_draw_band / _commit)
 	BandBox *h_band = nullptr, *h_band_dev = nullptr;
 	BandScratch *d_band = nullptr;
@@ -572,6 +573,7 @@ extern "C" void mdns_joint_destroy(mdns_joint *j)
 	if (j->d_chain_props) (void) hipFree(j->d_chain_props);
 	if (j->d_chain_counts) (void) hipFree(j->d_chain_counts);
 	if (j->d_chain_ticket) (void) hipFree(j->d_chain_ticket);
+	if (j->d_commit_ticket) (void) hipFree(j->d_commit_ticket);
 	if (j->d_votes) (void) hipFree(j->d_votes);
 	if (j->h_band) (void) hipHostFree(j->h_band);
 	if (j->d_band) (void) hipFree(j->d_band);
@@ -965,6 +967,13 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 extern "C" int *mdns_joint_flags_dev(mdns_joint *j) { return j ? j->d_flags : nullptr; }
 extern "C" const void *mdns_joint_result_dev(mdns_joint *j) { return j ? j->d_result : nullptr; }
 
+static bool commit_ticket(mdns_joint *j)
+{
+	if (j->d_commit_ticket) return true;
+	Context *c = ctx();
+	return MDNS_HIP(hipMalloc((void **) &j->d_commit_ticket, sizeof(int))) && MDNS_HIP(hipMemsetAsync(j->d_commit_ticket, 0, sizeof(int), c->stream));
+}
+
 static int joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M, bool want_row, const char *who)
 {
 	Context *c = ctx();
@@ -992,12 +1001,16 @@ static int joint_commit_dev(mdns_joint *j, const int *d_row_ids, int M, bool wan
 		// who beats its threshold, and with which likelihood, is in the trail of the accept pass:
 		// nothing is computed again
 		const JointTrail trail = {j->d_trail_stamp, j->d_trail_word, j->d_trail_L, j->trail_stamp};
-		if (!launch_joint_commit_trail(d_row_ids, M, j->last_B, j->d_flags, trail, j->st, base, bits)) return 1;
-	} else if (!launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
-	                                     d_row_ids, M, j->d_flags, j->st, base, bits, Lrow)) return 1;
+		// (its last workgroup fills the mailbox)
+		if (!commit_ticket(j) || !launch_joint_commit_trail(d_row_ids, M, j->last_B, j->d_flags, trail, j->st, base, bits, 1, j->h_box_dev,
+		                                                    ++j->box_seq, j->d_commit_ticket)) return 1;
+	} else {
+		if (!launch_gauss_cols_commit(j->s, j->last_yT, j->s->d_model, j->last_bt, j->last_B, j->last_scale, j->last_gather,
+		                              d_row_ids, M, j->d_flags, j->st, base, bits, Lrow)) return 1;
+		hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
+		                   j->h_box_dev, ++j->box_seq);
+	}
 	j->trail_valid = false;                                             // a chunk is committed once
-	hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
-	                   j->h_box_dev, ++j->box_seq);
 	j->box_pending = true;
 	return MDNS_HIP(hipGetLastError()) ? 0 : 1;
 }
@@ -1315,10 +1328,8 @@ extern "C" int mdns_backend_draw_chunk(void *joint, const double *params, int B,
 			// a tile or two: shelf appends, thresholds and the mailbox in ONE workgroup
 			if (!launch_chunk_commit(thr_rows, M, B, j->d_flags, flag, trail, j->st, base, bits, j->h_box_dev, ++j->box_seq)) return 1;
 		} else {
-			if (!launch_joint_commit_trail(thr_rows, M, B, j->d_flags, trail, j->st, base, bits, flag)) return 1;
-			hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
-			                   j->h_box_dev, ++j->box_seq);
-			if (!MDNS_HIP(hipGetLastError())) return 1;
+			if (!commit_ticket(j) || !launch_joint_commit_trail(thr_rows, M, B, j->d_flags, trail, j->st, base, bits, flag, j->h_box_dev,
+			                                                    ++j->box_seq, j->d_commit_ticket)) return 1;
 		}
 		j->box_pending = true;
 		j->trail_valid = false;
@@ -1447,10 +1458,8 @@ extern "C" int mdns_backend_chain_begin(void *joint, void *region, const mdns_ch
 	if (M <= 128) {
 		if (!launch_chunk_commit(thr_rows, M, limit, j->d_flags, flag, trail, j->st, base, bits, j->h_box_dev, ++j->box_seq)) return 1;
 	} else {
-		if (!launch_joint_commit_trail(thr_rows, M, limit, j->d_flags, trail, j->st, base, bits, flag)) return 1;
-		hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, (M + 63) / 64,
-		                   j->h_box_dev, ++j->box_seq);
-		if (!MDNS_HIP(hipGetLastError())) return 1;
+		if (!commit_ticket(j) || !launch_joint_commit_trail(thr_rows, M, limit, j->d_flags, trail, j->st, base, bits, flag, j->h_box_dev,
+		                                                    ++j->box_seq, j->d_commit_ticket)) return 1;
 	}
 	j->box_pending = true;
 	j->trail_valid = false;
@@ -1625,9 +1634,8 @@ extern "C" int mdns_backend_draw_commit(void *joint, int *accepted, unsigned lon
 		if (M <= 128) {
 			if (!launch_chunk_commit(thr_rows, M, B, j->d_votes, 1, trail, j->st, base, bits, j->h_box_dev, ++j->box_seq)) return 1;
 		} else {
-			if (!launch_joint_commit_trail(thr_rows, M, B, j->d_votes, trail, j->st, base, bits, 1)) return 1;
-			hipLaunchKernelGGL(k_joint_publish, dim3(1), dim3(kBlock), 0, c->stream, (const JointHeader *) base, bits, ntiles, j->h_box_dev, ++j->box_seq);
-			if (!MDNS_HIP(hipGetLastError())) return 1;
+			if (!commit_ticket(j) || !launch_joint_commit_trail(thr_rows, M, B, j->d_votes, trail, j->st, base, bits, 1, j->h_box_dev, ++j->box_seq,
+			                                                    j->d_commit_ticket)) return 1;
 		}
 		j->box_pending = true;
 	} else {

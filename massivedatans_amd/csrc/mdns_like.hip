@@ -709,9 +709,11 @@ __global__ void k_row_sumsq(const double *__restrict__ Y, int ld, int nx, int nd
 // k_gauss_cols_commit (multi_nested_sampler.py:482-485, :438-447).
 __global__ __launch_bounds__(kBlock) void k_joint_commit_trail(
     const int *__restrict__ thr_rows, int M, int B, int ntiles, const int *__restrict__ flags, int flag_value, JointTrail trail,
-    JointArrays st, JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits)
+    JointArrays st, JointHeader *__restrict__ header, unsigned long long *__restrict__ fillbits,
+    JointMailbox *__restrict__ box, unsigned long long seq, int *__restrict__ ticket)
 {
 	__shared__ int s_first;
+	__shared__ int s_last;
 	if (threadIdx.x == 0) s_first = 0x7fffffff;
 	__syncthreads();
 	for (int b = threadIdx.x; b < B; b += kBlock)
@@ -719,15 +721,15 @@ __global__ __launch_bounds__(kBlock) void k_joint_commit_trail(
 	__syncthreads();
 	const int bstar = s_first;
 	if (blockIdx.x == 0 && threadIdx.x == 0) header->accepted = bstar < B ? bstar : -1;
-	if (bstar >= B) return;
 	const int lane = threadIdx.x & 63;
 	const int tile = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
-	if (tile >= ntiles) return;
-	const size_t at = (size_t) bstar * ntiles + tile;
+	const bool mine = bstar < B && tile < ntiles;
+	if (!mine && !box) return;
+	const size_t at = mine ? (size_t) bstar * ntiles + tile : 0;
 	// (a candidate flagged by another rank's data sets only has no entry here: nobody beats)
-	const unsigned long long word = trail.stamp_of[at] == trail.stamp ? trail.word[at] : 0ull;
+	const unsigned long long word = mine && trail.stamp_of[at] == trail.stamp ? trail.word[at] : 0ull;
 	const int k = tile * 64 + lane;
-	if (k < M && (word >> lane & 1ull)) {
+	if (mine && k < M && (word >> lane & 1ull)) {
 		const int d = thr_rows ? thr_rows[k] : k;
 		const double L = trail.L[at * 64 + lane];
 		const double thr = st.higher[d];
@@ -761,7 +763,26 @@ __global__ __launch_bounds__(kBlock) void k_joint_commit_trail(
 			st.higher[d] = at_most >= n + 2 ? thr : fmin(L, next);
 		}
 	}
-	if (lane == 0) fillbits[tile] = word;
+	if (!box) { if (lane == 0) fillbits[tile] = word; return; }
+	// box != nullptr: the mailbox is filled by the last workgroup to finish (hand-over of mdns_internal.h: the fill
+	// words go through agent-scope stores) -- one launch less than k_joint_publish behind this kernel
+	if (mine && lane == 0) __hip_atomic_store(&fillbits[tile], word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	handover_release();
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1) == (int) gridDim.x - 1 ? 1 : 0;
+	__syncthreads();
+	if (!s_last) return;
+	handover_acquire();
+	if (bstar < B)
+		for (int w = threadIdx.x; w < ntiles; w += kBlock)
+			mail_store(&box->bits[w], __hip_atomic_load(&fillbits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	handover_release();
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	*ticket = 0;
+	mail_store(&box->accepted, bstar < B ? bstar : -1);
+	mail_store(&box->status, __hip_atomic_load(&header->status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	mail_raise(&box->seq, seq);
 }
 
 // Second half of a draw chunk: the first flagged candidate is THE accepted point
@@ -1309,12 +1330,14 @@ bool launch_gauss_cols_commit(const mdns_spectra *s, const double *d_yT, const d
 }
 
 bool launch_joint_commit_trail(const int *d_thr_rows, int M, int B, const int *d_flags, const JointTrail &trail,
-                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits, int flag_value)
+                               const JointArrays &st, void *d_header, unsigned long long *d_fillbits, int flag_value,
+                               void *box_dev, unsigned long long seq, int *d_ticket)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64;
 	hipLaunchKernelGGL(k_joint_commit_trail, dim3((ntiles + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-	                   d_thr_rows, M, B, ntiles, d_flags, flag_value, trail, st, (JointHeader *) d_header, d_fillbits);
+	                   d_thr_rows, M, B, ntiles, d_flags, flag_value, trail, st, (JointHeader *) d_header, d_fillbits,
+	                   (JointMailbox *) box_dev, seq, d_ticket);
 	return launched("k_joint_commit_trail");
 }
 
