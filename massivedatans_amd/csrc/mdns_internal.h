@@ -158,8 +158,11 @@ bool launch_muse3_model(const double *d_x, int nx, const double *d_params, int B
                         double *d_model, int ldm);
 bool launch_gauss_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
                        double scale, const int *d_rows, int M, double *d_out);
+struct MuseBandFused;
+// band != nullptr (pairs of candidates only: muse_rows_variant(...) == 1): the band test of the likelihood noise and its
+// mailbox ride along with the scoring -- no k_joint_band behind it
 bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int B,
-                      const int *d_rows, int M, double *d_out, int B_shape = 0);
+                      const int *d_rows, int M, double *d_out, int B_shape = 0, const MuseBandFused *band = nullptr);
 int muse_rows_variant(int B, int M);
 // the band test of a chunk (mdns_joint.hip, k_joint_band) on K2 as two matrix products (mdns_k2gemm.hip):
 // where its outcome goes (device memory; clear / maybe per candidate, listed pairs behind a counter)
@@ -284,6 +287,74 @@ __device__ __forceinline__ void handover_acquire() { __builtin_amdgcn_fence(__AT
 // a few microseconds that nobody needs: what the host reads is all in the mailbox.
 template <class T, class V> __device__ __forceinline__ void mail_store(T *at, V v) { __hip_atomic_store(at, (T) v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 __device__ __forceinline__ void mail_raise(unsigned long long *seq_at, unsigned long long seq) { handover_release(); mail_store(seq_at, seq); }
+#endif
+
+
+// ---- the likelihood noise in band form (mdns.h: draw_band / draw_band_commit; kernels in mdns_joint.hip, mdns_like.hip) ----
+// every likelihood against its threshold +- (1.01 bound[b] + 1e-12 (|L| + |thr|)): a pair above the band is beaten whatever
+// the noise (clear[b] = 1), a pair inside it is listed for the host, which alone makes the exact deviates
+#ifdef __HIPCC__
+static constexpr int kBandCap = 4096;
+struct BandBox {                   // mapped host memory
+	unsigned long long seq;
+	int npairs, pad;
+	int status[MDNS_JOINT_MAX_BATCH];
+	int pair_b[kBandCap], pair_k[kBandCap];
+	double pair_L[kBandCap], pair_thr[kBandCap];
+};
+struct BandScratch {               // device memory
+	int counter, ticket;           // listed pairs; workgroups of the band pass that are done (zero between launches)
+	int clear[MDNS_JOINT_MAX_BATCH], maybe[MDNS_JOINT_MAX_BATCH];
+	int pair_b[kBandCap], pair_k[kBandCap];
+	double pair_L[kBandCap], pair_thr[kBandCap];
+};
+
+// what the host needs of a band pass, into mapped memory (`seq` last), and the scratch ready for the next chunk:
+// by one workgroup that knows every vote is in (a kernel of its own behind the pass, or the pass's last workgroup)
+__device__ __forceinline__ void band_publish(BandScratch *__restrict__ sc, int B, BandBox *__restrict__ box, unsigned long long seq)
+{
+	const int n = __hip_atomic_load(&sc->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const int m = n < kBandCap ? n : kBandCap;
+	for (int b = threadIdx.x; b < B; b += (int) blockDim.x) {
+		const int cl = __hip_atomic_load(&sc->clear[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int mb = __hip_atomic_load(&sc->maybe[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		mail_store(&box->status[b], cl ? 1 : (mb ? 2 : 0));
+		sc->clear[b] = 0; sc->maybe[b] = 0;
+	}
+	for (int t = threadIdx.x; t < m; t += (int) blockDim.x) {
+		mail_store(&box->pair_b[t], __hip_atomic_load(&sc->pair_b[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		mail_store(&box->pair_k[t], __hip_atomic_load(&sc->pair_k[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		mail_store(&box->pair_L[t], __hip_atomic_load(&sc->pair_L[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+		mail_store(&box->pair_thr[t], __hip_atomic_load(&sc->pair_thr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+	}
+	handover_release();
+	__syncthreads();
+	if (threadIdx.x != 0) return;
+	sc->counter = 0;
+	sc->ticket = 0;
+	mail_store(&box->npairs, n);
+	mail_raise(&box->seq, seq);
+}
+
+// one (candidate, data set) pair of a band pass (votes and pairs through agent-scope stores: whoever publishes may be
+// another workgroup of the same launch)
+__device__ __forceinline__ void band_vote(BandScratch *__restrict__ sc, int b, int k, double v, double thr, double bnd)
+{
+	const double band = 1.01 * bnd + 1e-12 * (fabs(v) + fabs(thr));
+	if (v > thr + band) __hip_atomic_store(&sc->clear[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else if (v >= thr - band) {
+		__hip_atomic_store(&sc->maybe[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		const int at = atomicAdd(&sc->counter, 1);
+		if (at < kBandCap) {
+			__hip_atomic_store(&sc->pair_b[at], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&sc->pair_k[at], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&sc->pair_L[at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+			__hip_atomic_store(&sc->pair_thr[at], thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
+	}
+}
+// a scoring kernel that votes and publishes by itself (launch_muse_rows): sc == nullptr: it does neither
+struct MuseBandFused { BandScratch *sc; BandBox *box; unsigned long long seq; const double *higher; const double *bound; int *status_zero; };
 #endif
 
 // smallest double T with sqrt(T) >= r, so that  sqrt(d) < r  <=>  d < T  for every d >= 0

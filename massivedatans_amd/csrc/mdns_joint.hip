@@ -324,48 +324,8 @@ __global__ __launch_bounds__(kBlock) void k_joint_commit_dense(
 // every likelihood against its threshold +- (1.01 bound[b] + 1e-12 (|L| + |thr|)): a pair above the band
 // is beaten whatever the noise (clear[b] = 1), a pair inside it is listed for the host, which alone
 // makes the exact deviates
-static constexpr int kBandCap = 4096;
-struct BandBox {                   // mapped host memory
-	unsigned long long seq;
-	int npairs, pad;
-	int status[MDNS_JOINT_MAX_BATCH];
-	int pair_b[kBandCap], pair_k[kBandCap];
-	double pair_L[kBandCap], pair_thr[kBandCap];
-};
-struct BandScratch {               // device memory
-	int counter, ticket;           // listed pairs; workgroups of the band pass that are done (zero between launches)
-	int clear[MDNS_JOINT_MAX_BATCH], maybe[MDNS_JOINT_MAX_BATCH];
-	int pair_b[kBandCap], pair_k[kBandCap];
-	double pair_L[kBandCap], pair_thr[kBandCap];
-};
-
-// what the host needs of a band pass, into mapped memory (`seq` last), and the scratch ready for the next chunk:
-// by one workgroup that knows every vote is in (a kernel of its own behind the pass, or the pass's last workgroup)
-__device__ __forceinline__ void band_publish(BandScratch *__restrict__ sc, int B, BandBox *__restrict__ box, unsigned long long seq)
-{
-	const int n = __hip_atomic_load(&sc->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	const int m = n < kBandCap ? n : kBandCap;
-	for (int b = threadIdx.x; b < B; b += kBlock) {
-		const int cl = __hip_atomic_load(&sc->clear[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		const int mb = __hip_atomic_load(&sc->maybe[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		mail_store(&box->status[b], cl ? 1 : (mb ? 2 : 0));
-		sc->clear[b] = 0; sc->maybe[b] = 0;
-	}
-	for (int t = threadIdx.x; t < m; t += kBlock) {
-		mail_store(&box->pair_b[t], __hip_atomic_load(&sc->pair_b[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-		mail_store(&box->pair_k[t], __hip_atomic_load(&sc->pair_k[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-		mail_store(&box->pair_L[t], __hip_atomic_load(&sc->pair_L[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-		mail_store(&box->pair_thr[t], __hip_atomic_load(&sc->pair_thr[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-	}
-	handover_release();
-	__syncthreads();
-	if (threadIdx.x != 0) return;
-	sc->counter = 0;
-	sc->ticket = 0;
-	mail_store(&box->npairs, n);
-	mail_raise(&box->seq, seq);
-}
-
+// (BandBox, BandScratch, band_vote, band_publish: mdns_internal.h -- the small-chunk row kernel of mdns_like.hip votes and
+// publishes by itself)
 // box != nullptr: the last workgroup to finish publishes (votes and pairs go through agent-scope stores: the
 // hand-over of mdns_internal.h) -- one launch less per chunk than k_joint_band_publish behind it
 __global__ __launch_bounds__(kBlock) void k_joint_band(const double *__restrict__ L, const double *__restrict__ bound, int B, int M,
@@ -376,21 +336,8 @@ __global__ __launch_bounds__(kBlock) void k_joint_band(const double *__restrict_
 	if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) header->status = 0;
 	const int k = blockIdx.x * kBlock + threadIdx.x, b = blockIdx.y;
 	if (k < M) {
-		const double v = L[(size_t) b * M + k];
 		const int d = thr_rows ? thr_rows[k] : k;
-		const double thr = higher[d];
-		const double band = 1.01 * bound[b] + 1e-12 * (fabs(v) + fabs(thr));
-		if (v > thr + band) __hip_atomic_store(&sc->clear[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		else if (v >= thr - band) {
-			__hip_atomic_store(&sc->maybe[b], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			const int at = atomicAdd(&sc->counter, 1);
-			if (at < kBandCap) {
-				__hip_atomic_store(&sc->pair_b[at], b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(&sc->pair_k[at], k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(&sc->pair_L[at], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				__hip_atomic_store(&sc->pair_thr[at], thr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-		}
+		band_vote(sc, b, k, L[(size_t) b * M + k], higher[d], bound[b]);
 	}
 	if (!box) return;
 	__shared__ int s_last;
@@ -1670,6 +1617,12 @@ static int band_launch(mdns_joint *j, bool filtered)
 		const MuseBandOut out = {&j->d_band->counter, j->d_band->clear, j->d_band->maybe, j->d_band->pair_b, j->d_band->pair_k,
 		                         j->d_band->pair_L, j->d_band->pair_thr, kBandCap, &((JointHeader *) j->d_result)->status};
 		if (!launch_muse_filter(j->s, j->s->d_model, ldm, B, d_rows, M, j->st.higher, d_b, out)) return 1;
+	} else if (muse_rows_variant(B, M) == 1 && j->s->d_w && j->s->d_x) {
+		// small chunks (pairs of candidates per workgroup): templates, then ONE kernel that scores, votes and publishes
+		const int ldm = model_ld(j->s->nx);
+		if (!ensure_model(j->s, (size_t) B * ldm) || !launch_muse3_model(j->s->d_x, j->s->nx, d_p, B, j->s->d_model, ldm)) return 1;
+		const MuseBandFused fused = {j->d_band, j->h_band_dev, ++j->band_seq, j->st.higher, d_b, &((JointHeader *) j->d_result)->status};
+		if (!launch_muse_rows(j->s, j->s->d_model, ldm, B, d_rows, M, j->d_dense, 0, &fused)) return 1;
 	} else {
 		if (mdns_muse3_loglike_batch_dev(j->s, d_p, B, d_rows, M, j->d_dense) != 0) return 1;
 		hipLaunchKernelGGL(k_joint_band, dim3((M + kBlock - 1) / kBlock, B), dim3(kBlock), 0, c->stream, (const double *) j->d_dense,

@@ -951,8 +951,9 @@ template <int NP, int CB>
 __global__ __launch_bounds__(kBlock) void k_muse_rows(
     const double *__restrict__ Y, const double *__restrict__ W, int ld, int nx,
     const double *__restrict__ model, int ldm, int B, const int *__restrict__ rows, int M,
-    double *__restrict__ out, int bchunk)
+    double *__restrict__ out, int bchunk, MuseBandFused band)
 {
+	if (band.sc && band.status_zero && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *band.status_zero = 0;
 	// grid.y splits the candidates (chunks of `bchunk`, a multiple of CB) when there are too
 	// few rows to fill the chip: a row is then loaded by several workgroups
 	const int bbeg = blockIdx.y * bchunk;
@@ -1011,10 +1012,24 @@ __global__ __launch_bounds__(kBlock) void k_muse_rows(
 			// redA may be rewritten by the next round only after everybody read it: they all
 			// did before arriving at the barrier inside this call
 			block_sums<CB>(chi, redB);
-			if (threadIdx.x < CB && b0 + threadIdx.x < B)
-				out[(size_t) (b0 + threadIdx.x) * M + k] = -0.5 * (threadIdx.x == 0 ? chi[0] : chi[CB - 1]);
+			if (threadIdx.x < CB && b0 + threadIdx.x < B) {
+				const double L = -0.5 * (threadIdx.x == 0 ? chi[0] : chi[CB - 1]);
+				out[(size_t) (b0 + threadIdx.x) * M + k] = L;
+				// (the band test of the likelihood noise rides along: mdns_internal.h, band_vote)
+				if (band.sc) band_vote(band.sc, b0 + (int) threadIdx.x, k, L, band.higher[row], band.bound[b0 + threadIdx.x]);
+			}
 		}
 	}
+	if (!band.sc) return;
+	// the last workgroup to finish publishes (hand-over of mdns_internal.h)
+	__shared__ int s_last;
+	handover_release();
+	__syncthreads();
+	if (threadIdx.x == 0) s_last = atomicAdd(&band.sc->ticket, 1) == (int) (gridDim.x * gridDim.y) - 1 ? 1 : 0;
+	__syncthreads();
+	if (!s_last) return;
+	handover_acquire();
+	band_publish(band.sc, B, band.box, band.seq);
 }
 
 // Many candidates: the limit of k_muse_rows is the 32 KiB template that every (candidate,
@@ -1442,8 +1457,11 @@ int muse_rows_variant(int B, int M)
 // B_shape > 0: score these B candidates with the instantiation a block of B_shape candidates would take
 // (for variant 1 the caller passes whole pairs of that block)
 bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int B, const int *d_rows,
-                      int M, double *d_out, int B_shape)
+                      int M, double *d_out, int B_shape, const MuseBandFused *band)
 {
+	const MuseBandFused none = {nullptr, nullptr, 0, nullptr, nullptr, nullptr};
+	if (band && muse_rows_variant(B_shape > 0 ? B_shape : B, M) != 1) { set_error("launch_muse_rows: the band test rides along with pairs of candidates only"); return false; }
+	const MuseBandFused fused = band ? *band : none;
 	Context *c = ctx();
 	const int nx = s->nx;
 	int blocks = M < c->num_cus * 8 ? M : c->num_cus * 8;
@@ -1464,9 +1482,9 @@ bool launch_muse_rows(const mdns_spectra *s, const double *d_model, int ldm, int
 #define MUSE_LAUNCH(NP) do { if (two_rows) hipLaunchKernelGGL((k_muse_rows2<NP>), dim3((blocks + 1) / 2), dim3(kBlock), 0, c->stream, \
 		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out); \
 	else if (variant == 1) hipLaunchKernelGGL((k_muse_rows<NP, 2>), dim3(blocks, gy), dim3(kBlock), 0, c->stream, \
-		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, bchunk); \
+		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, bchunk, fused); \
 	else hipLaunchKernelGGL((k_muse_rows<NP, 1>), dim3(blocks), dim3(kBlock), 0, c->stream, \
-		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, B); } while (0)
+		s->d_y, s->d_w, s->ld, nx, d_model, ldm, B, d_rows, M, d_out, B, none); } while (0)
 	if (nx <= 512) MUSE_LAUNCH(1);
 	else if (nx <= 1024) MUSE_LAUNCH(2);
 	else if (nx <= 2048) MUSE_LAUNCH(4);
