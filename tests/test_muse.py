@@ -218,12 +218,14 @@ def test_configs4_whole_on_one_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ndata,nx,B,sparse", [(1500, 700, 40, False), (2000, 4096, 64, False), (1300, 333, 17, True), (600, 1024, 9, True)])
+@pytest.mark.parametrize("ndata,nx,B,sparse", [(1500, 700, 40, False), (2000, 4096, 64, False), (1300, 333, 17, True), (600, 1024, 9, True),
+                                                (6250, 4096, 64, False), (6250, 4096, 57, True)])
 def test_k2_matrix_core_filter_decides_like_the_exact_kernels(ndata, nx, B, sparse):
     """mdns_backend_draw_band through the matrix-core filter (csrc/mdns_k2gemm.hip) against the exact row
     kernels, with thresholds planted on the candidates' own likelihoods at relative distances from 1e-3 down
-    to 0 on both sides: every candidate's status and the listed pairs (which only the exact kernels may
-    produce) are the same; the filter handed the chunk over (it cannot settle a threshold 1e-13 away); and
+    to 0 on both sides (the last two shapes: one GPU's share of BASELINE configs[4], whole -- tiled operands -- and a
+    sparse selection of it -- row-major operands): every candidate's status and the listed pairs (which only the exact
+    kernels may produce) are the same; the filter handed the chunk over (it cannot settle a threshold 1e-13 away); and
     the commit keeps the exact kernel's row."""
     import ctypes as C
     sys.path.insert(0, os.path.join(ROOT, "tools"))
