@@ -222,6 +222,8 @@ __global__ __launch_bounds__(1024) void k_chunk_commit(
 // accepted index and every likelihood that is KEPT are therefore the chain kernel's, bit for bit.
 // ---------------------------------------------------------------------------------------
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double4_t gg_join(double2_t a, double2_t b) { return double4_t{a[0], a[1], b[0], b[1]}; }
 
 // lane l holds A[i = l % 16][k = l / 16], B[k = l / 16][j = l % 16], D[i = 4 v + l / 16][j = l % 16] in
 // its v-th result (tools/probes/mfma_f64_probe.hip checks this on the hardware).
@@ -476,6 +478,116 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_direct(
 	if (lane == 0 && best != 0x7fffffff) atomicMax(lowest, B - best);
 }
 
+// The filter with both operands straight from memory in the TILED16 layout (round 4, after K2's: every load of a quarter
+// wave is 256 contiguous bytes, a lane's four channels of a group are two 16-byte pieces).  A workgroup owns 16 spectra x
+// 16 NC candidates and its four waves split the channel groups (a quarter each: the 200 channels of the bench shape are
+// 13 groups -- too few to pipeline deeply, so 10 000 short waves instead of 2 500 long ones, which also evens out the
+// SIMDs); the partial sums of waves 1-3 meet wave 0's in LDS behind ONE barrier, and wave 0 votes.
+// Measured (MDNS_K1_FILTER_FORM=gemm): 37.0 / 34.4 us at 10 000 x 256 against 34.4 / 31.8 staged through LDS, 138.6 against
+// 128.9 at 50 000 x 256, 113 against 106 at 10 000 x 1024 -- every 16-spectrum tile pulls all the templates through L2
+// again (266 MB a launch at 10 000 x 256).  Opt-in; decisions identical (tests/test_joint.py).
+template <int NC>
+__global__ __launch_bounds__(256) void k_gauss_gemm_filter(
+    const double *__restrict__ YG, int nxg, int nx, const double *__restrict__ model_g, const double *__restrict__ msq, int B,
+    double scale, const int *__restrict__ thr_rows, int M, int nbt,
+    const double *__restrict__ higher, const double *__restrict__ ysq, int *__restrict__ flags, int *__restrict__ ambiguous,
+    int stamp, int *__restrict__ lowest)
+{
+	__shared__ double red[3][NC * 256];
+	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+	const int i = lane & 15, q = lane >> 4;
+	const int first = blockIdx.x * 16;                                    // first spectrum (place in the selection)
+	const int ct0 = blockIdx.y * NC;                                      // first candidate tile
+	const int ncp = nxg >> 1, ng = nxg >> 4;
+	const int g0 = (wave * ng) >> 2, g1 = ((wave + 1) * ng) >> 2;         // this wave's channel groups
+	const double *pa = YG + (((size_t) blockIdx.x * ncp + 2 * q) << 5) + 2 * i;
+	const double *pb[NC];
+#pragma unroll
+	for (int c = 0; c < NC; c++) pb[c] = model_g + (((size_t) (ct0 + c < nbt ? ct0 + c : nbt - 1) * ncp + 2 * q) << 5) + 2 * i;
+	double4_t acc[NC];
+#pragma unroll
+	for (int c = 0; c < NC; c++) acc[c] = double4_t{0, 0, 0, 0};
+	double4_t a[2], b[2][NC];
+#define GG_LOAD4(P, G) gg_join(*reinterpret_cast<const double2_t *>((P) + ((size_t) (G) << 8)), *reinterpret_cast<const double2_t *>((P) + ((size_t) (G) << 8) + 32))
+#define GG_FETCH(SET, G) { \
+	const int g_ = (G) < g1 ? (G) : g1 - 1; \
+	a[SET] = GG_LOAD4(pa, g_); \
+	_Pragma("unroll") for (int c = 0; c < NC; c++) b[SET][c] = GG_LOAD4(pb[c], g_); }
+#define GG_BODY(SET, G) { \
+	__builtin_amdgcn_sched_barrier(0); \
+	if ((G) < g1) { \
+		_Pragma("unroll") for (int t = 0; t < 4; t++) \
+			_Pragma("unroll") for (int c = 0; c < NC; c++) \
+				acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[SET][t], b[SET][c][t], acc[c], 0, 0, 0); \
+	} \
+	__builtin_amdgcn_sched_barrier(0); }
+	if (g0 < g1) {
+		GG_FETCH(0, g0)
+#pragma unroll 1
+		for (int g = g0; g < g1; g += 2) {
+			GG_FETCH(1, g + 1)
+			GG_BODY(0, g)
+			GG_FETCH(0, g + 2)
+			GG_BODY(1, g + 1)
+		}
+	}
+#undef GG_BODY
+#undef GG_FETCH
+#undef GG_LOAD4
+	if (wave != 0) {
+#pragma unroll
+		for (int c = 0; c < NC; c++)
+#pragma unroll
+			for (int v = 0; v < 4; v++) red[wave - 1][(c * 4 + v) * 64 + lane] = acc[c][v];
+	}
+	__syncthreads();
+	if (wave != 0) return;
+#pragma unroll
+	for (int c = 0; c < NC; c++)
+#pragma unroll
+		for (int v = 0; v < 4; v++)
+			acc[c][v] = ((acc[c][v] + red[0][(c * 4 + v) * 64 + lane]) + red[1][(c * 4 + v) * 64 + lane]) + red[2][(c * 4 + v) * 64 + lane];
+	// votes: lane (i, q) holds, of candidate tile c, candidate 16 (ct0 + c) + i for the spectra first + 4 v + q
+	const double unit = fabs(scale) * (double) (nx + 8) * 0x1p-52;
+	double thr[4], yy[4];
+#pragma unroll
+	for (int v = 0; v < 4; v++) {
+		const int k = first + 4 * v + q;
+		const bool live = k < M;
+		const int kk = live ? k : M - 1;
+		const int d = thr_rows ? thr_rows[kk] : kk;
+		thr[v] = live ? higher[d] : __builtin_nan("");                    // NaN compares false: no vote
+		yy[v] = ysq[d];
+	}
+	int best = 0x7fffffff;                                                // lowest clearly accepted candidate of this wave
+#pragma unroll
+	for (int c = 0; c < NC; c++) {
+		const int cand = (ct0 + c) * 16 + i;
+		const bool valid = ct0 + c < nbt && cand < B;
+		const double mm = msq[valid ? cand : 0];
+		bool hit = false, maybe = false;
+#pragma unroll
+		for (int v = 0; v < 4; v++) {
+			const double S = acc[c][v];
+			const double Lf = scale * ((mm - 2.0 * S) + yy[v]);
+			const double E4 = 4.0 * unit * ((mm + 2.0 * fabs(S)) + yy[v]);
+			const bool h = valid && Lf > thr[v] + E4;
+			hit = hit || h;
+			maybe = maybe || (valid && !h && Lf >= thr[v] - E4);
+		}
+		// a candidate's four lanes (q = 0..3) are 16 apart
+		const unsigned long long hm = __ballot(hit), mb = __ballot(maybe);
+		if (lane < 16) {
+			const unsigned long long mine = 0x0001000100010001ull << lane;
+			if (hm & mine) { flags[cand] = 1; best = cand < best ? cand : best; }
+			else if (mb & mine) ambiguous[cand] = stamp;                      // (never cleared: stamped with the call)
+		}
+	}
+#pragma unroll
+	for (int off = 8; off > 0; off >>= 1) { const int o = __shfl_xor(best, off, 64); best = o < best ? o : best; }
+	if (lane == 0 && best != 0x7fffffff) atomicMax(lowest, B - best);
+}
+
 // The chain's own sums for the candidates the filter could not settle -- the ambiguous ones below
 // the lowest clear vote -- and for that one itself (its likelihoods are wanted): votes (flags) and
 // the trail of likelihoods, exactly as the chain accept kernels leave them.  Every workgroup (one
@@ -641,9 +753,21 @@ bool launch_chunk_commit(const int *d_thr_rows, int M, int B, const int *d_flags
 // scored (no column gather); d_model_t must be tiled 16 candidates wide, d_msq
 // from launch_gauss_model_tsq; d_scratch int32[MDNS_JOINT_MAX_BATCH + 16], zeroed once (ambiguous
 // marks, stamped with the trail's stamp); d_lowest: an int the template kernel cleared.
+// MDNS_K1_FILTER_FORM: lds | direct | gemm
+int gauss_mfma_form()
+{
+	static int form = -1;
+	if (form < 0) {
+		const char *e = getenv("MDNS_K1_FILTER_FORM");
+		form = e && e[0] == 'd' ? 1 : (e && e[0] == 'g' ? 2 : 0);
+	}
+	return form;
+}
+
 bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int B, double scale,
                               const int *d_thr_rows, int M, const double *d_higher, int *d_flags,
-                              const double *d_msq, const JointTrail &trail, int *d_lowest, int *d_scratch, void *d_header)
+                              const double *d_msq, const JointTrail &trail, int *d_lowest, int *d_scratch, void *d_header,
+                              const double *d_yG, const double *d_model_g)
 {
 	Context *c = ctx();
 	const int ntiles = (M + 63) / 64, nbt = (B + 15) / 16;
@@ -669,8 +793,17 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 		// 40.5 / 38.7 us against 34.4 / 31.8 staged through LDS; 50 000 x 256: 140.9 against 128.9 -- twenty 8-byte loads
 		// per lane and 16 multiplications (the layouts give a lane one channel per load) cost more than the barriers
 		// they save.  Not the default.
-		static const char *form = getenv("MDNS_K1_FILTER_FORM");
-		if (pr == 0 && form && form[0] == 'd') {
+		if (pr == 0 && d_yG && d_model_g && gauss_mfma_form() == 2) {
+			const int nxg = tiled16_nx(s->nx);
+			const int nc = nbt >= 4 ? 4 : (nbt >= 2 ? 2 : 1);
+			ProfileScope prof(0);
+			note_kernel(0, "k_gauss_gemm_filter<%d>", nc);
+#define GG_LAUNCH(NC) hipLaunchKernelGGL((k_gauss_gemm_filter<NC>), dim3((M + 15) / 16, (nbt + NC - 1) / NC), dim3(256), 0, c->stream, \
+			d_yG, nxg, s->nx, d_model_g, d_msq, B, scale, d_thr_rows, M, nbt, d_higher, (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest)
+			if (nc == 4) GG_LAUNCH(4); else if (nc == 2) GG_LAUNCH(2); else GG_LAUNCH(1);
+#undef GG_LAUNCH
+			if (!launched("k_gauss_gemm_filter")) return false;
+		} else if (pr == 0 && gauss_mfma_form() == 1) {
 			static double *d_zeros = nullptr;
 			if (!d_zeros && (!MDNS_HIP(hipMalloc((void **) &d_zeros, 16 * sizeof(double))) ||
 			                 !MDNS_HIP(hipMemsetAsync(d_zeros, 0, 16 * sizeof(double), c->stream)))) return false;

@@ -400,6 +400,9 @@ extern "C" mdns_spectra *mdns_spectra_create(const double *x, const double *y, c
 		ok = ok && launch_tile_columns(s->d_y, s->ld, ndata, nx, nullptr, s->d_yT);
 		ok = ok && MDNS_HIP(hipMalloc((void **) &s->d_ysq, (size_t) ndata * sizeof(double)));
 		ok = ok && launch_row_sumsq(s->d_y, s->ld, nx, ndata, s->d_ysq);
+		// ... and one in tiles of 16 rows for the matrix-core filter with operands straight from memory
+		ok = ok && MDNS_HIP(hipMalloc((void **) &s->d_yG, (size_t) ((ndata + 15) / 16) * 16 * tiled16_nx(nx) * sizeof(double)));
+		ok = ok && launch_tile_rows16(s->d_y, s->ld, ndata, nx, nullptr, s->d_yG);
 		ok = ok && MDNS_HIP(hipStreamSynchronize(c->stream));
 	}
 	if (ok && v) {
@@ -423,6 +426,9 @@ extern "C" void mdns_spectra_destroy(mdns_spectra *s)
 	if (c) (void) hipStreamSynchronize(c->stream);
 	void *bufs[] = {s->d_y, s->d_yT, s->d_w, s->d_x, s->d_model, s->d_params, s->d_rows, s->d_out, s->d_sel, s->d_ysq};
 	for (void *b : bufs) if (b) (void) hipFree(b);
+	if (s->d_yG) (void) hipFree(s->d_yG);
+	if (s->d_selG) (void) hipFree(s->d_selG);
+	if (s->d_model_g) (void) hipFree(s->d_model_g);
 	if (s->d_fyw) (void) hipFree(s->d_fyw);
 	if (s->d_fyw_t) (void) hipFree(s->d_fyw_t);
 	if (s->d_fw_t) (void) hipFree(s->d_fw_t);

@@ -50,6 +50,10 @@ struct mdns_spectra {
 	double *d_w = nullptr;   // [ndata, ld] inverse variances 1/v (K2), or nullptr
 	double *d_x = nullptr;   // [nx] wavelength grid, or nullptr
 	double *d_ysq = nullptr; // [ndata] sum of squares of every spectrum (K1 accept filter), or nullptr
+	double *d_yG = nullptr;  // K1 on the matrix cores with operands straight from memory (k_gauss_gemm_filter): the spectra in
+	                         // tiles of 16 rows, channel pair by channel pair (tiled16_at), channels padded to 16; or nullptr
+	double *d_selG = nullptr; size_t selG_cap = 0;     // the same of the current selection
+	double *d_model_g = nullptr; size_t model_g_cap = 0;   // templates in the same tiling
 	// per-handle grow-only device buffers for the host-pointer batch API
 	double *d_model = nullptr; size_t model_cap = 0;   // [B, ldm]
 	double *d_params = nullptr; size_t params_cap = 0;
@@ -130,17 +134,31 @@ bool launch_gauss_cols_accept(const mdns_spectra *s, const double *d_yT, const d
 // 0: the chain kernel decides; 1: vector-FMA filter; 2: matrix-core filter
 int gauss_filter_pays(const mdns_spectra *s, int M, int B);
 int gauss_filter_tile(int M, int B);
+// d_model_g != nullptr (bt = 16): the templates also in the tiled16 layout
 bool launch_gauss_model_tsq(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t, double *d_msq,
-                            int *d_zero, int nzero);
+                            int *d_zero, int nzero, double *d_model_g = nullptr);
 bool launch_gauss_cols_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int bt, int B,
                               double scale, const int *d_rows, const int *d_thr_rows, int M,
                               const double *d_higher, int *d_flags, const double *d_msq, const JointTrail &trail, int *d_lowest);
 bool launch_row_sumsq(const double *d_y, int ld, int nx, int ndata, double *d_out);
+// element (row r, channel c) of an operand in tiles of 16 rows, inside a tile channel pair by channel pair, 16 rows x 2
+// doubles: the 16 lanes of a quarter wave (the same channels of 16 rows) read 256 contiguous bytes; ncp = channels / 2
+#ifdef __HIPCC__
+__host__ __device__
+#endif
+inline size_t tiled16_at(size_t r, int c, int ncp) { return (((r >> 4) * (size_t) ncp + (size_t) (c >> 1)) << 5) + ((r & 15) << 1) + (size_t) (c & 1); }
+inline int tiled16_nx(int nx) { return (nx + 15) & ~15; }
+// rows [M or ndata][ld] (d_rows: which, or nullptr) -> tiled16 replica, zero padded
+bool launch_tile_rows16(const double *d_y, int ld, int M, int nx, const int *d_rows, double *d_out);
 // the same decision on the matrix cores (mdns_chunk.hip, k_gauss_mfma_filter + k_exact_list);
 // templates tiled 16 wide; d_scratch int32[MDNS_JOINT_MAX_BATCH + 16], zeroed once
 bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const double *d_model_t, int B, double scale,
                               const int *d_thr_rows, int M, const double *d_higher, int *d_flags,
-                              const double *d_msq, const JointTrail &trail, int *d_lowest, int *d_scratch, void *d_header);
+                              const double *d_msq, const JointTrail &trail, int *d_lowest, int *d_scratch, void *d_header,
+                              const double *d_yG = nullptr, const double *d_model_g = nullptr);
+// which form of the matrix-core filter: 0 staged through LDS (round 3), 1 operands straight from memory in the layouts
+// of the lane kernel (opt-in), 2 operands straight from memory, tiled16 (needs d_yG / d_model_g)
+int gauss_mfma_form();
 // first flagged candidate from the trail of the accept pass: fill bits, shelf appends, thresholds
 // (flag_value: what the accept pass wrote into d_flags for an accepted candidate)
 // box_dev != nullptr: the kernel's last workgroup also fills the mailbox (no k_joint_publish behind it); d_ticket: an int, zero

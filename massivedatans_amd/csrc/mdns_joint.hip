@@ -873,6 +873,7 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 	const double scale = -0.5 / (noise_level * noise_level);
 	const int filter = gauss_filter_pays(s, M, B);
 	const int bt = filter == 2 ? 16 : filter ? gauss_filter_tile(M, B) : gauss_cols_tile(M, B);
+	bool gemm_form = false;
 	if (!ensure_model(s, (size_t) cols_nx(s->nx) * (B + bt))) return 1;
 	if (filter) {
 		if (!j->d_msq && !MDNS_HIP(hipMalloc((void **) &j->d_msq, (size_t) (MDNS_JOINT_MAX_BATCH + 16) * sizeof(double)))) return 1;
@@ -880,14 +881,37 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 			const size_t bytes = (size_t) (MDNS_JOINT_MAX_BATCH + 16) * sizeof(int);
 			if (!MDNS_HIP(hipMalloc((void **) &j->d_filter_scratch, bytes)) || !MDNS_HIP(hipMemsetAsync(j->d_filter_scratch, 0, bytes, c->stream))) return 1;
 		}
-		if (!launch_gauss_model_tsq(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_msq, j->d_flags, kZeroInts)) return 1;
+		// (the matrix-core filter with tiled operands wants the templates in its tiling too)
+		double *model_g = nullptr;
+		if (filter == 2 && gauss_mfma_form() == 2 && s->d_yG) {
+			const size_t need = (size_t) ((B + 15) / 16) * 16 * tiled16_nx(s->nx);
+			if (need > s->model_g_cap) {
+				if (s->d_model_g) { if (!joint_sync(c)) return 1; (void) hipFree(s->d_model_g); s->d_model_g = nullptr; s->model_g_cap = 0; }
+				if (!MDNS_HIP(hipMalloc((void **) &s->d_model_g, (need + need / 2) * sizeof(double)))) return 1;
+				s->model_g_cap = need + need / 2;
+			}
+			model_g = s->d_model_g;
+		}
+		if (!launch_gauss_model_tsq(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_msq, j->d_flags, kZeroInts, model_g)) return 1;
+		gemm_form = model_g != nullptr;
 	} else if (!launch_gauss_model_t(s->d_x, s->nx, d_params, B, bt, s->d_model, j->d_flags, kZeroInts)) return 1;
 	const double *yT = s->d_yT;
 	const int *gather = d_row_ids;
 	// a sparse selection, or many candidate tiles over a selection: first a compact replica of
 	// the selected spectra (one coalesced pass) instead of gathering columns in every tile
 	const bool sparse = (size_t) M * 8 < (size_t) s->ndata;
-	if (d_row_ids && (B >= 128 || sparse || filter == 2)) {
+	const double *yG = s->d_yG;
+	if (d_row_ids && gemm_form) {
+		// (its own compact replica of the selection, in its tiling)
+		const size_t need = (size_t) ((M + 15) / 16) * 16 * tiled16_nx(s->nx);
+		if (need > s->selG_cap) {
+			if (s->d_selG) { if (!joint_sync(c)) return 1; (void) hipFree(s->d_selG); s->d_selG = nullptr; s->selG_cap = 0; }
+			if (!MDNS_HIP(hipMalloc((void **) &s->d_selG, (need + need / 2) * sizeof(double)))) return 1;
+			s->selG_cap = need + need / 2;
+		}
+		if (!launch_tile_rows16(s->d_y, s->ld, M, s->nx, d_row_ids, s->d_selG)) return 1;
+		yG = s->d_selG;
+	} else if (d_row_ids && (B >= 128 || sparse || filter == 2)) {
 		if (!ensure_selection(s, (size_t) ((M + 63) / 64) * 64 * cols_nx(s->nx))) return 1;
 		if (!launch_tile_columns(s->d_y, s->ld, M, s->nx, d_row_ids, s->d_sel)) return 1;
 		yT = s->d_sel;
@@ -898,7 +922,7 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 	if (filter == 2) {
 		int *lowest = (int *) &((JointHeader *) j->d_result)->pad;
 		if (!launch_gauss_mfma_filter(s, yT, s->d_model, B, scale, d_row_ids, M, j->st.higher, j->d_flags, j->d_msq, trail, lowest,
-		                              j->d_filter_scratch, j->d_result)) return 1;
+		                              j->d_filter_scratch, j->d_result, gemm_form ? yG : nullptr, gemm_form ? s->d_model_g : nullptr)) return 1;
 	} else if (filter) {
 		// issue-bound launch: the guarded filter decides -- same flags and trail, bit for bit.  Its
 		// "lowest flagged candidate so far" lives in the header's spare word (cleared with the flags).

@@ -136,7 +136,7 @@ __global__ void k_gauss_model_t(const double *__restrict__ x, int nx, int nxp, c
 // 256 / BT apart, then one thread per candidate adds them in a fixed order)
 __global__ __launch_bounds__(256) void k_gauss_model_tsq(const double *__restrict__ x, int nx, int nxp, const double *__restrict__ params,
                                                          int B, int bt_size, double *__restrict__ model_t, double *__restrict__ msq,
-                                                         int *__restrict__ zero, int nzero)
+                                                         int *__restrict__ zero, int nzero, double *__restrict__ model_g, int nxg)
 {
 	__shared__ double partial[256];
 	const int tile = blockIdx.x, t = threadIdx.x;
@@ -145,13 +145,16 @@ __global__ __launch_bounds__(256) void k_gauss_model_tsq(const double *__restric
 	double A = 0.0, mu = 0.0, sig = 1.0;
 	if (b < B) { A = params[3 * b]; mu = params[3 * b + 1]; sig = params[3 * b + 2]; }
 	double acc = 0.0;
-	for (int j = t / bt_size; j < nxp; j += 256 / bt_size) {
+	const int nj = model_g && nxg > nxp ? nxg : nxp;
+	for (int j = t / bt_size; j < nj; j += 256 / bt_size) {
 		double m = 0.0;
 		if (b < B && j < nx) {
 			const double u = (mu - x[j]) / sig;
 			m = A * exp(-0.5 * (u * u));
 		}
-		model_t[((size_t) tile * nxp + j) * bt_size + bin] = m;
+		if (j < nxp) model_t[((size_t) tile * nxp + j) * bt_size + bin] = m;
+		// (the same value in tiles of 16 candidates, channel pair by channel pair: k_gauss_gemm_filter; bt_size is 16 then)
+		if (model_g && j < nxg) model_g[tiled16_at((size_t) tile * 16 + bin, j, nxg >> 1)] = m;
 		acc = fma(m, m, acc);
 	}
 	partial[t] = acc;
@@ -160,6 +163,20 @@ __global__ __launch_bounds__(256) void k_gauss_model_tsq(const double *__restric
 		double sum = 0.0;
 		for (int q = t; q < 256; q += bt_size) sum += partial[q];
 		msq[tile * bt_size + t] = sum;
+	}
+}
+
+// rows (d_rows: which, or the first M) of Y [.][ld] -> tiled16 replica (zero padded rows and channels); one workgroup per tile
+__global__ __launch_bounds__(256) void k_tile_rows16(const double *__restrict__ Y, int ld, int M, int nx, int nxg,
+                                                     const int *__restrict__ rows, double *__restrict__ out)
+{
+	const int tile = blockIdx.x, ncp = nxg >> 1;
+	for (int e = threadIdx.x; e < 16 * nxg; e += 256) {
+		const int i = e / nxg, c = e - i * nxg;                           // (reads run along a row)
+		const int k = tile * 16 + i;
+		double v = 0.0;
+		if (k < M && c < nx) v = Y[(size_t) (rows ? rows[k] : k) * ld + c];
+		out[tiled16_at((size_t) k, c, ncp)] = v;
 	}
 }
 
@@ -1299,13 +1316,22 @@ int gauss_filter_tile(int M, int B)
 
 // templates + their sums of squares for the filter (also clears d_zero[0 .. nzero))
 bool launch_gauss_model_tsq(const double *d_x, int nx, const double *d_params, int B, int bt, double *d_model_t, double *d_msq,
-                            int *d_zero, int nzero)
+                            int *d_zero, int nzero, double *d_model_g)
 {
 	Context *c = ctx();
 	const int ntile = (B + bt - 1) / bt;
+	if (d_model_g && bt != 16) { set_error("launch_gauss_model_tsq: tiled templates come 16 candidates wide"); return false; }
 	hipLaunchKernelGGL(k_gauss_model_tsq, dim3(ntile), dim3(256), 0, c->stream, d_x, nx, cols_nx(nx), d_params, B, bt, d_model_t, d_msq,
-	                   d_zero, d_zero ? nzero : 0);
+	                   d_zero, d_zero ? nzero : 0, d_model_g, tiled16_nx(nx));
 	return launched("k_gauss_model_tsq");
+}
+
+bool launch_tile_rows16(const double *d_y, int ld, int M, int nx, const int *d_rows, double *d_out)
+{
+	Context *c = ctx();
+	if (M <= 0 || nx <= 0) return true;
+	hipLaunchKernelGGL(k_tile_rows16, dim3((M + 15) / 16), dim3(256), 0, c->stream, d_y, ld, M, nx, tiled16_nx(nx), d_rows, d_out);
+	return launched("k_tile_rows16");
 }
 
 // the accept pass as guarded filter (see k_gauss_cols_filter): same flags and trail as

@@ -270,7 +270,7 @@ def test_chunk_with_no_acceptable_candidate_changes_nothing():
     dev.close()
 
 
-@pytest.mark.parametrize("mode", ["1", "mfma", "mfma-direct", "default"])
+@pytest.mark.parametrize("mode", ["1", "mfma", "mfma-direct", "mfma-gemm", "default"])
 def test_guarded_filter_decides_like_the_chain(hip, monkeypatch, mode):
     """Issue-bound chunks (256 candidates x 10 000 spectra) take the accept test as a guarded filter:
     one FMA per (candidate, channel, spectrum) on the expanded square, a rigorous error band around
@@ -285,13 +285,14 @@ def test_guarded_filter_decides_like_the_chain(hip, monkeypatch, mode):
         # 1024 candidates x 10 000 spectra: the matrix-core filter is what the library picks by itself
         if os.environ.get("MDNS_K1_FILTER") is not None:
             pytest.skip("MDNS_K1_FILTER is set")
-    elif os.environ.get("MDNS_K1_FILTER") != mode.split("-")[0] or (mode == "mfma-direct") != (os.environ.get("MDNS_K1_FILTER_FORM") == "direct"):
+    elif os.environ.get("MDNS_K1_FILTER") != mode.split("-")[0] or os.environ.get("MDNS_K1_FILTER_FORM", "") != (mode.split("-") + [""])[1]:
         # the library reads the switches once per process: run this test in a child with the filter on
-        # ("mfma": staged through LDS; "mfma-direct": both operands straight from memory, opt-in)
+        # ("mfma": staged through LDS; "mfma-direct" / "mfma-gemm": both operands straight from memory, in the lane
+        # kernel's layouts / in tiles of 16 rows)
         env = dict(os.environ, MDNS_K1_FILTER=mode.split("-")[0])
         env.pop("MDNS_K1_FILTER_FORM", None)
-        if mode == "mfma-direct":
-            env["MDNS_K1_FILTER_FORM"] = "direct"
+        if "-" in mode:
+            env["MDNS_K1_FILTER_FORM"] = mode.split("-")[1]
         out = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-m", "gpu",
                               __file__ + "::test_guarded_filter_decides_like_the_chain[%s]" % mode], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "1 passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
@@ -315,7 +316,7 @@ def test_guarded_filter_decides_like_the_chain(hip, monkeypatch, mode):
         _lib.check(hip.mdns_joint_set_live(js._h, _lib.ptr(np.ascontiguousarray(live))), "set_live")
         js.prepare()
         out = js.draw(xs, None)
-        name = "k_gauss_cols_filter" if mode == "1" else ("k_gauss_mfma_direct" if mode == "mfma-direct" else "k_gauss_mfma_filter")
+        name = {"1": "k_gauss_cols_filter", "mfma-direct": "k_gauss_mfma_direct", "mfma-gemm": "k_gauss_gemm_filter"}.get(mode, "k_gauss_mfma_filter")
         assert (hip.mdns_profile_kernel(0) or b"").decode().startswith(name), "the filter did not run"
         return out
 
