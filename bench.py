@@ -687,12 +687,14 @@ def bench_gauss(args):
     if rank == 0:
         evals_per_step = B * nd * world
         value = evals_per_step * args.steps / elapsed
-        mfma = kernel.startswith("k_gauss_mfma_filter")
+        mfma = kernel.startswith("k_gauss_mfma_filter") or kernel.startswith("k_gauss_gemm_filter")
         # per launch.  Chain kernels: subtract, multiply, add per (channel, candidate, spectrum).  The
         # matrix-core filter EXECUTES one multiply-add per element (the cross term of the expanded
         # square): `achieved` counts those 2 flops; the 3 flops of the reference's formula that they
         # stand for are reported beside it, never as the roofline fraction.
-        flops = (2.0 if mfma else 3.0) * nx * B * nd
+        # (k_gauss_gemm_filter multiplies whole groups of 16 channels: the padded ones are executed too)
+        nx_exec = (nx + 15) // 16 * 16 if kernel.startswith("k_gauss_gemm_filter") else nx
+        flops = (2.0 if mfma else 3.0) * nx_exec * B * nd
         tflops = flops / (k1_us * 1e-6) / 1e12 if k1_us > 0 else 0.0
         alg_bytes = (8 * nx + 8) * B * nd                 # 1608 B per eval
         phys_bytes = 8 * nx * nd + 8 * nd + 8 * B * nx    # spectra once + thresholds + templates; flags

@@ -483,24 +483,29 @@ __global__ __launch_bounds__(256) void k_gauss_mfma_direct(
 // 16 NC candidates and its four waves split the channel groups (a quarter each: the 200 channels of the bench shape are
 // 13 groups -- too few to pipeline deeply, so 10 000 short waves instead of 2 500 long ones, which also evens out the
 // SIMDs); the partial sums of waves 1-3 meet wave 0's in LDS behind ONE barrier, and wave 0 votes.
-// Measured (MDNS_K1_FILTER_FORM=gemm): 37.0 / 34.4 us at 10 000 x 256 against 34.4 / 31.8 staged through LDS, 138.6 against
-// 128.9 at 50 000 x 256, 113 against 106 at 10 000 x 1024 -- every 16-spectrum tile pulls all the templates through L2
-// again (266 MB a launch at 10 000 x 256).  Opt-in; decisions identical (tests/test_joint.py).
-template <int NC>
+// Measured in that form: 37.0 / 34.4 us at 10 000 x 256 against 34.4 / 31.8 staged through LDS, 138.6 against 128.9 at
+// 50 000 x 256 -- every 16-spectrum tile pulls all the templates through L2 again.  KSPLIT = false, the default: each wave
+// takes 16 spectra of its own with ALL the channels, the four waves of a workgroup read the same templates at about the same
+// time (L1): 29.8 / 28.3 us and 112.8 / 108.3 -- the fastest of the matrix-core forms, decisions identical (tests/test_joint.py).
+template <int NC, bool KSPLIT>
 __global__ __launch_bounds__(256) void k_gauss_gemm_filter(
     const double *__restrict__ YG, int nxg, int nx, const double *__restrict__ model_g, const double *__restrict__ msq, int B,
     double scale, const int *__restrict__ thr_rows, int M, int nbt,
     const double *__restrict__ higher, const double *__restrict__ ysq, int *__restrict__ flags, int *__restrict__ ambiguous,
     int stamp, int *__restrict__ lowest)
 {
-	__shared__ double red[3][NC * 256];
+	__shared__ double red[KSPLIT ? 3 : 1][KSPLIT ? NC * 256 : 1];
 	const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
 	const int i = lane & 15, q = lane >> 4;
-	const int first = blockIdx.x * 16;                                    // first spectrum (place in the selection)
+	// KSPLIT: the four waves share 16 spectra and split the channel groups; else each wave has 16 spectra of its own and
+	// all the groups -- the waves then read the SAME templates at about the same time (L1)
+	const int rtile = KSPLIT ? blockIdx.x : blockIdx.x * 4 + wave;
+	const int first = rtile * 16;                                         // first spectrum (place in the selection)
+	if (first >= M) return;                                               // (whole waves; no barrier on this path)
 	const int ct0 = blockIdx.y * NC;                                      // first candidate tile
 	const int ncp = nxg >> 1, ng = nxg >> 4;
-	const int g0 = (wave * ng) >> 2, g1 = ((wave + 1) * ng) >> 2;         // this wave's channel groups
-	const double *pa = YG + (((size_t) blockIdx.x * ncp + 2 * q) << 5) + 2 * i;
+	const int g0 = KSPLIT ? (wave * ng) >> 2 : 0, g1 = KSPLIT ? ((wave + 1) * ng) >> 2 : ng;   // this wave's channel groups
+	const double *pa = YG + (((size_t) rtile * ncp + 2 * q) << 5) + 2 * i;
 	const double *pb[NC];
 #pragma unroll
 	for (int c = 0; c < NC; c++) pb[c] = model_g + (((size_t) (ct0 + c < nbt ? ct0 + c : nbt - 1) * ncp + 2 * q) << 5) + 2 * i;
@@ -534,19 +539,21 @@ __global__ __launch_bounds__(256) void k_gauss_gemm_filter(
 #undef GG_BODY
 #undef GG_FETCH
 #undef GG_LOAD4
-	if (wave != 0) {
+	if (KSPLIT) {
+		if (wave != 0) {
+#pragma unroll
+			for (int c = 0; c < NC; c++)
+#pragma unroll
+				for (int v = 0; v < 4; v++) red[wave - 1][(c * 4 + v) * 64 + lane] = acc[c][v];
+		}
+		__syncthreads();
+		if (wave != 0) return;
 #pragma unroll
 		for (int c = 0; c < NC; c++)
 #pragma unroll
-			for (int v = 0; v < 4; v++) red[wave - 1][(c * 4 + v) * 64 + lane] = acc[c][v];
+			for (int v = 0; v < 4; v++)
+				acc[c][v] = ((acc[c][v] + red[0][(c * 4 + v) * 64 + lane]) + red[1][(c * 4 + v) * 64 + lane]) + red[2][(c * 4 + v) * 64 + lane];
 	}
-	__syncthreads();
-	if (wave != 0) return;
-#pragma unroll
-	for (int c = 0; c < NC; c++)
-#pragma unroll
-		for (int v = 0; v < 4; v++)
-			acc[c][v] = ((acc[c][v] + red[0][(c * 4 + v) * 64 + lane]) + red[1][(c * 4 + v) * 64 + lane]) + red[2][(c * 4 + v) * 64 + lane];
 	// votes: lane (i, q) holds, of candidate tile c, candidate 16 (ct0 + c) + i for the spectra first + 4 v + q
 	const double unit = fabs(scale) * (double) (nx + 8) * 0x1p-52;
 	double thr[4], yy[4];
@@ -753,13 +760,13 @@ bool launch_chunk_commit(const int *d_thr_rows, int M, int B, const int *d_flags
 // scored (no column gather); d_model_t must be tiled 16 candidates wide, d_msq
 // from launch_gauss_model_tsq; d_scratch int32[MDNS_JOINT_MAX_BATCH + 16], zeroed once (ambiguous
 // marks, stamped with the trail's stamp); d_lowest: an int the template kernel cleared.
-// MDNS_K1_FILTER_FORM: lds | direct | gemm
+// MDNS_K1_FILTER_FORM: gemm (default) | lds | direct
 int gauss_mfma_form()
 {
 	static int form = -1;
 	if (form < 0) {
 		const char *e = getenv("MDNS_K1_FILTER_FORM");
-		form = e && e[0] == 'd' ? 1 : (e && e[0] == 'g' ? 2 : 0);
+		form = e && e[0] == 'd' ? 1 : (e && e[0] == 'l' ? 0 : 2);
 	}
 	return form;
 }
@@ -795,11 +802,22 @@ bool launch_gauss_mfma_filter(const mdns_spectra *s, const double *d_yT, const d
 		// they save.  Not the default.
 		if (pr == 0 && d_yG && d_model_g && gauss_mfma_form() == 2) {
 			const int nxg = tiled16_nx(s->nx);
-			const int nc = nbt >= 4 ? 4 : (nbt >= 2 ? 2 : 1);
+			// (32 candidates per wave: 29.8 / 28.3 us at 10 000 x 256 against 33.0 / 31.4 with 64 -- twice the waves, evener SIMDs --
+			// and 112.8 / 108.3 against 112.2 / 108.4 at 50 000 x 256; 16: 42 / 179)
+			static const char *ncf = getenv("MDNS_K1_GEMM_NC");                 // experiments only
+			int nc = nbt >= 2 ? 2 : 1;
+			if (ncf && (atoi(ncf) == 1 || atoi(ncf) == 2 || atoi(ncf) == 4) && atoi(ncf) <= nbt) nc = atoi(ncf);
 			ProfileScope prof(0);
 			note_kernel(0, "k_gauss_gemm_filter<%d>", nc);
-#define GG_LAUNCH(NC) hipLaunchKernelGGL((k_gauss_gemm_filter<NC>), dim3((M + 15) / 16, (nbt + NC - 1) / NC), dim3(256), 0, c->stream, \
-			d_yG, nxg, s->nx, d_model_g, d_msq, B, scale, d_thr_rows, M, nbt, d_higher, (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest)
+			// MDNS_K1_GEMM_KSPLIT=1: the four waves of a workgroup share 16 spectra and split the channels (35.7 / 34.3 us at
+			// 10 000 x 256, 138.7 / 135.6 at 50 000 x 256); default: a wave per 16 spectra with all the channels
+			static const char *ks = getenv("MDNS_K1_GEMM_KSPLIT");
+			const bool ksplit = ks && ks[0] == '1';
+			const int rt = (M + 15) / 16;
+#define GG_LAUNCH(NC) do { if (ksplit) hipLaunchKernelGGL((k_gauss_gemm_filter<NC, true>), dim3(rt, (nbt + NC - 1) / NC), dim3(256), 0, c->stream, \
+			d_yG, nxg, s->nx, d_model_g, d_msq, B, scale, d_thr_rows, M, nbt, d_higher, (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest); \
+		else hipLaunchKernelGGL((k_gauss_gemm_filter<NC, false>), dim3((rt + 3) / 4, (nbt + NC - 1) / NC), dim3(256), 0, c->stream, \
+			d_yG, nxg, s->nx, d_model_g, d_msq, B, scale, d_thr_rows, M, nbt, d_higher, (const double *) s->d_ysq, d_flags, d_amb, trail.stamp, d_lowest); } while (0)
 			if (nc == 4) GG_LAUNCH(4); else if (nc == 2) GG_LAUNCH(2); else GG_LAUNCH(1);
 #undef GG_LAUNCH
 			if (!launched("k_gauss_gemm_filter")) return false;

@@ -400,12 +400,6 @@ extern "C" mdns_spectra *mdns_spectra_create(const double *x, const double *y, c
 		ok = ok && launch_tile_columns(s->d_y, s->ld, ndata, nx, nullptr, s->d_yT);
 		ok = ok && MDNS_HIP(hipMalloc((void **) &s->d_ysq, (size_t) ndata * sizeof(double)));
 		ok = ok && launch_row_sumsq(s->d_y, s->ld, nx, ndata, s->d_ysq);
-		// ... and, where it is asked for (MDNS_K1_FILTER_FORM=gemm), one in tiles of 16 rows for the matrix-core filter with
-		// operands straight from memory
-		if (gauss_mfma_form() == 2) {
-			ok = ok && MDNS_HIP(hipMalloc((void **) &s->d_yG, (size_t) ((ndata + 15) / 16) * 16 * tiled16_nx(nx) * sizeof(double)));
-			ok = ok && launch_tile_rows16(s->d_y, s->ld, ndata, nx, nullptr, s->d_yG);
-		}
 		ok = ok && MDNS_HIP(hipStreamSynchronize(c->stream));
 	}
 	if (ok && v) {

@@ -883,7 +883,12 @@ extern "C" int mdns_joint_score_dev(mdns_joint *j, const double *d_params, int B
 		}
 		// (the matrix-core filter with tiled operands wants the templates in its tiling too)
 		double *model_g = nullptr;
-		if (filter == 2 && gauss_mfma_form() == 2 && s->d_yG) {
+		if (filter == 2 && gauss_mfma_form() == 2 && !d_row_ids && !s->d_yG) {
+			// (the whole set in tiles of 16 rows: made on first use)
+			if (!MDNS_HIP(hipMalloc((void **) &s->d_yG, (size_t) ((s->ndata + 15) / 16) * 16 * tiled16_nx(s->nx) * sizeof(double))) ||
+			    !launch_tile_rows16(s->d_y, s->ld, s->ndata, s->nx, nullptr, s->d_yG)) return 1;
+		}
+		if (filter == 2 && gauss_mfma_form() == 2 && (d_row_ids || s->d_yG)) {
 			const size_t need = (size_t) ((B + 15) / 16) * 16 * tiled16_nx(s->nx);
 			if (need > s->model_g_cap) {
 				if (s->d_model_g) { if (!joint_sync(c)) return 1; (void) hipFree(s->d_model_g); s->d_model_g = nullptr; s->model_g_cap = 0; }

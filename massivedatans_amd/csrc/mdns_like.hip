@@ -1298,6 +1298,10 @@ int gauss_filter_pays(const mdns_spectra *s, int M, int B)
 	if (forced && forced[0] == '1') return 1;
 	if (forced && forced[0] == '0') return 0;
 	if (forced && forced[0] == 'm') return 2;
+	// (round 4: with both operands straight from memory in tiles of 16 rows -- k_gauss_gemm_filter -- the filter kernel takes
+	// 29 us against the chain's 43 at 10 000 x 256 and a chunk alone 74.6 / 72.1 us against 86.9 / 81.3 (tools/filter_bench.py);
+	// but inside a whole sampler step the route still loses there: bench.py 96.8 us per step against 92.0 on the same box.  So
+	// the threshold stays where the passes around the product are small beside it.)
 	return B >= 128 && (long long) M * B >= 8000000LL ? 2 : 0;
 }
 

@@ -270,7 +270,7 @@ def test_chunk_with_no_acceptable_candidate_changes_nothing():
     dev.close()
 
 
-@pytest.mark.parametrize("mode", ["1", "mfma", "mfma-direct", "mfma-gemm", "default"])
+@pytest.mark.parametrize("mode", ["1", "mfma", "mfma-direct", "mfma-lds", "default"])
 def test_guarded_filter_decides_like_the_chain(hip, monkeypatch, mode):
     """Issue-bound chunks (256 candidates x 10 000 spectra) take the accept test as a guarded filter:
     one FMA per (candidate, channel, spectrum) on the expanded square, a rigorous error band around
@@ -287,8 +287,8 @@ def test_guarded_filter_decides_like_the_chain(hip, monkeypatch, mode):
             pytest.skip("MDNS_K1_FILTER is set")
     elif os.environ.get("MDNS_K1_FILTER") != mode.split("-")[0] or os.environ.get("MDNS_K1_FILTER_FORM", "") != (mode.split("-") + [""])[1]:
         # the library reads the switches once per process: run this test in a child with the filter on
-        # ("mfma": staged through LDS; "mfma-direct" / "mfma-gemm": both operands straight from memory, in the lane
-        # kernel's layouts / in tiles of 16 rows)
+        # ("mfma": both operands straight from memory in tiles of 16 rows, the default form; "mfma-lds": staged through
+        # LDS, round 3; "mfma-direct": straight from memory in the lane kernel's layouts)
         env = dict(os.environ, MDNS_K1_FILTER=mode.split("-")[0])
         env.pop("MDNS_K1_FILTER_FORM", None)
         if "-" in mode:
@@ -316,7 +316,7 @@ def test_guarded_filter_decides_like_the_chain(hip, monkeypatch, mode):
         _lib.check(hip.mdns_joint_set_live(js._h, _lib.ptr(np.ascontiguousarray(live))), "set_live")
         js.prepare()
         out = js.draw(xs, None)
-        name = {"1": "k_gauss_cols_filter", "mfma-direct": "k_gauss_mfma_direct", "mfma-gemm": "k_gauss_gemm_filter"}.get(mode, "k_gauss_mfma_filter")
+        name = {"1": "k_gauss_cols_filter", "mfma-direct": "k_gauss_mfma_direct", "mfma-lds": "k_gauss_mfma_filter"}.get(mode, "k_gauss_gemm_filter")
         assert (hip.mdns_profile_kernel(0) or b"").decode().startswith(name), "the filter did not run"
         return out
 
