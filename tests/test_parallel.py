@@ -119,7 +119,7 @@ def test_two_rank_gloo():
     assert res == [(0, True, 0, 19), (1, True, 19, 37)]
 
 
-def _muse_worker(rank, world, port, q, cases=("muse6", "muse10_graph")):
+def _muse_worker(rank, world, port, q, cases=("muse6", "muse10_graph"), local_columns=False):
     """configs[4]'s problem with the data sets sharded: the MUSE-style likelihood + its jitter as
     constrained draws over a ShardedJointState, every rank's native constrainer drawing the same
     noise stream and adding the columns of its own block."""
@@ -150,6 +150,18 @@ def _muse_worker(rank, world, port, q, cases=("muse6", "muse10_graph")):
             sampler = sample.build_sampler(problem, nlive_points=int(g["nlive"]), nsuperset_draws=int(g["nsuperset_draws"]),
                                            use_graph=bool(g["use_graph"]), seed=1, batched=False, fused=True, native=True)
             ok &= type(sampler.joint).__name__ == "ShardedJointState" and sampler.native is not None
+            if local_columns:
+                # the evidence integration sharded too: every rank its own columns (here blocks of 2, 2, 1, 1 data sets:
+                # ranks with ONE column of an analysis with several), the gathered evidences are the reference's
+                view = parallel.LocalColumns(sampler)
+                with np.errstate(all="ignore"):
+                    res = view.gather(multi_nested_integrator(tolerance=0.5, multi_sampler=view, min_samples=0, max_samples=int(g["max_samples"])))
+                sampler.native.sync_gauss_to_numpy()
+                ok &= np.random.uniform() == float(g["rng_probe"])
+                for key in ("logZ", "logZerr", "information"):
+                    ok &= np.array_equal(res[key], g[key])
+                ok &= int(sampler.ndraws) == int(g["ndraws"])
+                continue
             rec = Recorder(sampler)
             with np.errstate(all="ignore"):
                 res = multi_nested_integrator(tolerance=0.5, multi_sampler=rec, min_samples=0, max_samples=int(g["max_samples"]))
@@ -162,17 +174,18 @@ def _muse_worker(rank, world, port, q, cases=("muse6", "muse10_graph")):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_sharded_muse_gloo(world):
     """BASELINE configs[4] sharded: reference traces muse6 / muse10_graph bit for bit
-    -- integers, floats, position of the random stream -- with 2 and 3 ranks (ragged blocks)."""
+    -- integers, floats, position of the random stream -- with 2 and 3 ranks (ragged blocks); with 4 ranks
+    (blocks of 2, 2, 1, 1) and the evidence integration sharded as well (parallel.LocalColumns)."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + (os.getpid() % 2000) + world
     # (the longer trace, 100 s through gloo, with MDNS_LONG_TESTS=1: ragged blocks of 4 + 3 + 3 data sets)
     cases = ("muse6", "muse10_graph") if os.environ.get("MDNS_LONG_TESTS") == "1" else ("muse6",)
-    procs = [ctx.Process(target=_muse_worker, args=(r, world, port, q, cases)) for r in range(world)]
+    procs = [ctx.Process(target=_muse_worker, args=(r, world, port, q, cases, world == 4)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
