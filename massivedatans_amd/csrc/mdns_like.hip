@@ -134,19 +134,25 @@ __global__ void k_gauss_model_t(const double *__restrict__ x, int nx, int nxp, c
 // k_gauss_model_t for the filter: one workgroup per candidate tile writes the tile and the sum of
 // squares of every candidate's template (deterministic: per-thread partial sums over the channels
 // 256 / BT apart, then one thread per candidate adds them in a fixed order)
+// (gridDim.y workgroups share a tile's channels: sixteen workgroups of thirteen exponentials per thread took 9 us at 256
+// templates x 200 channels.  Each leaves its partial sums of squares; the last one of a tile to finish -- hand-over of
+// mdns_internal.h -- adds them in the order of the channel shares, so msq does not depend on who was last)
 __global__ __launch_bounds__(256) void k_gauss_model_tsq(const double *__restrict__ x, int nx, int nxp, const double *__restrict__ params,
                                                          int B, int bt_size, double *__restrict__ model_t, double *__restrict__ msq,
-                                                         int *__restrict__ zero, int nzero, double *__restrict__ model_g, int nxg)
+                                                         int *__restrict__ zero, int nzero, double *__restrict__ model_g, int nxg,
+                                                         double *__restrict__ msq_part, int *__restrict__ tickets)
 {
 	__shared__ double partial[256];
-	const int tile = blockIdx.x, t = threadIdx.x;
-	for (int e = tile * 256 + t; e < nzero; e += gridDim.x * 256) zero[e] = 0;      // accept flags + result header
+	__shared__ int s_last;
+	const int tile = blockIdx.x, t = threadIdx.x, ny = gridDim.y, share = blockIdx.y;
+	for (int e = (share * gridDim.x + tile) * 256 + t; e < nzero; e += gridDim.x * ny * 256) zero[e] = 0;      // accept flags + result header
 	const int bin = t % bt_size, b = tile * bt_size + bin;
 	double A = 0.0, mu = 0.0, sig = 1.0;
 	if (b < B) { A = params[3 * b]; mu = params[3 * b + 1]; sig = params[3 * b + 2]; }
 	double acc = 0.0;
 	const int nj = model_g && nxg > nxp ? nxg : nxp;
-	for (int j = t / bt_size; j < nj; j += 256 / bt_size) {
+	const int per = (nj + ny - 1) / ny, j0 = share * per, j1 = j0 + per < nj ? j0 + per : nj;       // this workgroup's channels
+	for (int j = j0 + t / bt_size; j < j1; j += 256 / bt_size) {
 		double m = 0.0;
 		if (b < B && j < nx) {
 			const double u = (mu - x[j]) / sig;
@@ -159,11 +165,23 @@ __global__ __launch_bounds__(256) void k_gauss_model_tsq(const double *__restric
 	}
 	partial[t] = acc;
 	__syncthreads();
-	if (t < bt_size) {
-		double sum = 0.0;
-		for (int q = t; q < 256; q += bt_size) sum += partial[q];
-		msq[tile * bt_size + t] = sum;
+	double mine = 0.0;
+	if (t < bt_size) for (int q = t; q < 256; q += bt_size) mine += partial[q];
+	if (ny == 1) { if (t < bt_size) msq[tile * bt_size + t] = mine; return; }
+	if (t < bt_size) __hip_atomic_store(&msq_part[((size_t) tile * ny + share) * bt_size + t], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	handover_release();
+	__syncthreads();
+	if (t == 0) {
+		const int done = atomicAdd(&tickets[tile], 1);
+		s_last = done == ny - 1 ? 1 : 0;
+		if (s_last) tickets[tile] = 0;                                   // for the next launch (stream order)
 	}
+	__syncthreads();
+	if (!s_last || t >= bt_size) return;
+	handover_acquire();
+	double sum = 0.0;
+	for (int sh = 0; sh < ny; sh++) sum += __hip_atomic_load(&msq_part[((size_t) tile * ny + sh) * bt_size + t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	msq[tile * bt_size + t] = sum;
 }
 
 // rows (d_rows: which, or the first M) of Y [.][ld] -> tiled16 replica (zero padded rows and channels); one workgroup per tile
@@ -1325,8 +1343,23 @@ bool launch_gauss_model_tsq(const double *d_x, int nx, const double *d_params, i
 	Context *c = ctx();
 	const int ntile = (B + bt - 1) / bt;
 	if (d_model_g && bt != 16) { set_error("launch_gauss_model_tsq: tiled templates come 16 candidates wide"); return false; }
-	hipLaunchKernelGGL(k_gauss_model_tsq, dim3(ntile), dim3(256), 0, c->stream, d_x, nx, cols_nx(nx), d_params, B, bt, d_model_t, d_msq,
-	                   d_zero, d_zero ? nzero : 0, d_model_g, tiled16_nx(nx));
+	// partial sums of squares and tickets of the shared tiles: grow-only, the tickets zero between launches
+	static double *d_part = nullptr;
+	static int *d_tickets = nullptr;
+	static int cap_tiles = 0;
+	constexpr int kShares = 4;
+	static const char *one = getenv("MDNS_TSQ_SHARES");                  // "1": one workgroup per tile (experiments)
+	const int ny = one && one[0] == '1' ? 1 : kShares;
+	if (ny > 1 && ntile > cap_tiles) {
+		if (d_part) { (void) hipStreamSynchronize(c->stream); (void) hipFree(d_part); (void) hipFree(d_tickets); d_part = nullptr; d_tickets = nullptr; cap_tiles = 0; }
+		const int cap = ntile + 64;
+		if (!MDNS_HIP(hipMalloc((void **) &d_part, (size_t) cap * kShares * 64 * sizeof(double))) ||
+		    !MDNS_HIP(hipMalloc((void **) &d_tickets, (size_t) cap * sizeof(int))) ||
+		    !MDNS_HIP(hipMemsetAsync(d_tickets, 0, (size_t) cap * sizeof(int), c->stream))) return false;
+		cap_tiles = cap;
+	}
+	hipLaunchKernelGGL(k_gauss_model_tsq, dim3(ntile, ny), dim3(256), 0, c->stream, d_x, nx, cols_nx(nx), d_params, B, bt, d_model_t, d_msq,
+	                   d_zero, d_zero ? nzero : 0, d_model_g, tiled16_nx(nx), d_part, d_tickets);
 	return launched("k_gauss_model_tsq");
 }
 
