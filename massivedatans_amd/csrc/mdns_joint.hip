@@ -378,7 +378,15 @@ __global__ __launch_bounds__(kBlock) void k_joint_commit_band(
 			else {
 				int at_most = 0;
 				double next = INFINITY;
-				for (int p = 0; p < st.nlive; p++) {
+				int p = 0;
+				for (; p + 20 <= st.nlive; p += 20) {                   // 20 loads in flight (as in k_joint_commit_trail: the latency of a round trip is what this costs)
+					double w[20];
+#pragma unroll
+					for (int u = 0; u < 20; u++) w[u] = st.live[(size_t) (p + u) * st.ndata + d];
+#pragma unroll
+					for (int u = 0; u < 20; u++) { if (w[u] <= thr) at_most++; else next = fmin(next, w[u]); }
+				}
+				for (; p < st.nlive; p++) {
 					const double w = st.live[(size_t) p * st.ndata + d];
 					if (w <= thr) at_most++; else next = fmin(next, w);
 				}
